@@ -1,0 +1,115 @@
+/* libsupir_hip.so -- C ABI of the MI355X (gfx950) kernels behind SUPIR's restoration-guided EDM sampling path.
+ *
+ * The reference (Fanghua-Yu/SUPIR) has no native code of its own: its compute arrives through torch.nn modules that
+ * dispatch to cuDNN / cuBLAS / xformers.  Each entry point below replaces one of those dispatches; the comment on each
+ * names the reference call sites (file:line relative to the reference root) it stands in for.  INTEGRATION.md shows
+ * the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - caller owns every buffer (including workspaces); the library allocates nothing and keeps no mutable state;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and stream ordered, never synchronise;
+ *   - return 0 on success, <0 on error (SUPIR_ERR_*); never throws;
+ *   - "bf16" buffers are raw 16-bit bfloat16; activations are NHWC / token-major: element (b, y, x, c) of a
+ *     [B,H,W,C] feature map lives at ((b*H + y)*W + x)*ld + c where ld >= C is the row stride in elements;
+ *   - leading dimensions of bf16 operands must be multiples of 8 elements (16 bytes) unless noted.
+ */
+#ifndef SUPIR_HIP_H
+#define SUPIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUPIR_OK 0
+#define SUPIR_ERR_ARG (-1)   /* null pointer / non-positive size */
+#define SUPIR_ERR_SHAPE (-2) /* shape or alignment not supported by the kernel */
+#define SUPIR_ERR_HIP (-3)   /* HIP launch error */
+
+/* activation codes */
+#define SUPIR_ACT_NONE 0
+#define SUPIR_ACT_SILU 1
+#define SUPIR_ACT_GEGLU 2 /* W rows interleaved [32 value | 32 gate] per 64; output has N/2 columns */
+
+/* output modes */
+#define SUPIR_OUT_BF16 0
+#define SUPIR_OUT_F32 1
+#define SUPIR_OUT_BF16_T 2 /* transposed per batch: C[b][n][t], ldc = padded token count */
+
+/* ABI version; bumped on any signature change. */
+int supir_abi_version(void);
+/* Static string naming the compiled target ("gfx950"). Host pointer. */
+const char* supir_target_arch(void);
+
+/* C = alpha * act(A . W^T + bias + rowbias[batch]) + residual          A:[M][lda] bf16, W:[N][K] bf16 (K contiguous)
+ * Replaces every nn.Linear / 1x1 nn.Conv2d on the path:
+ *   sgm/modules/attention.py:87 (GEGLU.proj) :100,106 (FeedForward) :213-219 (to_q/k/v/out) :587,611 (proj_in/out)
+ *   sgm/modules/diffusionmodules/openaimodel.py:289 (emb_layers) :317 (skip_connection) :666-695 (time/label embed)
+ *   SUPIR/modules/SUPIR_v0.py:48,87 (zero_conv)   sgm/modules/diffusionmodules/model.py:124 (nin_shortcut) :164-175 (q,k,v,proj_out)
+ * K % 64 == 0, N % 4 == 0. bias fp32 [N]. rowbias bf16 [nbatch][ld_rowbias] (row m uses batch m / rows_per_batch).
+ * residual bf16 [M][ldr]. tile: -1 auto, 0..3 force (128x128, 128x64, 64x128, 64x64). */
+int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                    const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
+                    int out_mode, float alpha, int tile, void* stream);
+
+/* 3x3 convolution as implicit GEMM on NHWC bf16.  X:[B][H][W][ldx], W:[Cout][3][3][Cin] bf16, Y:[B][OH][OW][ldy].
+ * Replaces nn.Conv2d(k=3) at openaimodel.py:127 (Upsample.conv, upsample=1 folds F.interpolate(nearest,2x) :145)
+ *   :196 (Downsample.op, stride 2 pad 1) :263,300 (ResBlock in/out conv, rowbias = emb_layers(emb) :338-355,
+ *   residual = skip :356); SUPIR_v0.py:79-83 (ZeroSFT mlp_shared / zero_mul / zero_add);
+ *   model.py:60,77 (VAE Upsample / Downsample: stride 2, pad_t = pad_l = 0 gives F.pad(0,1,0,1) :81-86) :108-115.
+ * Cin % 64 == 0. Padding is implied by (pad_t, pad_l) and OH/OW: taps outside the (virtual) input read zero. */
+int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int Wd, int Cin, int ldx, int Cout,
+                       int ldy, int OH, int OW, int stride, int pad_t, int pad_l, int upsample, const float* bias,
+                       const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,
+                       float alpha, int tile, void* stream);
+
+/* softmax(Q K^T * scale) V for head dim 64.  Q:[B][Tq][ldq], K:[B][Tk][ldk] with head h at columns h*64..h*64+63;
+ * Vt:[B][H*64][ldvt] is V transposed per batch (SUPIR_OUT_BF16_T output of the to_v projection), ldvt >= roundup(Tk,64),
+ * padding finite; O:[B][Tq][ldo].
+ * Replaces xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention at
+ *   sgm/modules/attention.py:273-277, 357-359 and SUPIR/modules/SUPIR_v0.py:146. */
+int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
+                         int ldk, int ldvt, int ldo, float scale, void* stream);
+
+/* P[r][:] = softmax(S[r][:] * scale): fp32 scores -> bf16 probabilities (VAE mid-block single-head attention,
+ * sgm/modules/diffusionmodules/model.py:177-192, 228-256; the score matrix itself comes from supir_gemm_bf16). */
+int supir_softmax_rows(const float* S, void* P, int rows, int T, long ld_s, long ld_p, float scale, void* stream);
+
+/* GroupNorm(32 groups) over NHWC bf16 with fp32 statistics, optional SiLU, optional channel concat of two sources
+ * (channels [0,C1) from x1, [C1,C) from x2), optional ZeroSFT modulation out = GN(x)*(mod_g+1)+mod_b and
+ * control_scale lerp against the raw concat (x2raw = skip before zero_conv; may be NULL when cscale == 1).
+ * workspace: B*1024*64 floats.
+ * Replaces GroupNorm32 (sgm/modules/diffusionmodules/util.py:258-276), Normalize (attention.py:122-125,
+ * model.py:48-51), nonlinearity/SiLU (model.py:44-46, openaimodel.py:261,296) and ZeroSFT.forward's tail
+ * (SUPIR/modules/SUPIR_v0.py:110-113). */
+int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x2raw, int B, int HW, int C, int C1, int ld1,
+                         int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
+                         const void* mod_b, int ldm, float control_scale, void* out, int ldo, float* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* LayerNorm over the last dim of token-major bf16 [rows][ld]; gamma/beta fp32 [C]. (attention.py:437-439,465-486) */
+int supir_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, int ldx, int ldy,
+                    float eps, void* stream);
+
+/* 3x3 s1 p1 conv, fp32 NCHW [B][Cin<=8][H][W] -> bf16 NHWC [B][H][W][ldo] (+ optional bf16 NHWC addend).
+ * w: fp32 [Cout][Cin][3][3] (reference layout). openaimodel.py:704, SUPIR_v0.py:325,482,531; model.py:512,646. */
+int supir_conv3x3_smallcin(const float* x, const float* w, const float* bias, const void* add, void* out, int B,
+                           int Cin, int H, int W, int Cout, int ld_add, int ldo, void* stream);
+
+/* 3x3 s1 p1 conv, bf16 NHWC [B][H][W][ldx] -> fp32 NCHW [B][Cout in {3,4,8}][H][W]. w: bf16 [9][Cout][Cin].
+ * openaimodel.py:951 (UNet out), model.py:563 (encoder conv_out), :694 (decoder conv_out). */
+int supir_conv3x3_smallcout(const void* x, const void* w, const float* bias, float* out, int B, int Cin, int H, int W,
+                            int Cout, int ldx, void* stream);
+
+/* 1x1 conv on fp32 NCHW with <= 8 channels: out = W . (in_scale * x) + bias.
+ * quant_conv / post_quant_conv, sgm/models/autoencoder.py:297-298,308,314 (in_scale folds 1/scale_factor). */
+int supir_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
+                         long HW, float in_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUPIR_HIP_H */

@@ -1,0 +1,63 @@
+"""ctypes binding of libsupir_hip.so (C ABI declared in include/supir_hip.h).
+
+There is no fallback: if the shared library is missing or an entry point returns an error code the call raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsupir_hip.so")
+
+_ERR = {-1: "SUPIR_ERR_ARG (null pointer / bad size)", -2: "SUPIR_ERR_SHAPE (unsupported shape or alignment)",
+        -3: "SUPIR_ERR_HIP (launch failed)"}
+
+P, I, F, L = c_void_p, c_int, c_float, c_long
+
+# name -> argtypes; mirrors include/supir_hip.h one to one (tests/test_abi.py cross-checks against the header)
+SIGNATURES = {
+    "supir_gemm_bf16": [P, P, P, I, I, I, I, I, P, P, I, I, P, I, I, I, F, I, P],
+    "supir_conv3x3_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, I, I, I, F, I, P],
+    "supir_flash_attn_d64": [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
+    "supir_softmax_rows": [P, P, I, I, L, L, F, P],
+    "supir_groupnorm_nhwc": [P, P, P, I, I, I, I, I, I, P, P, F, I, P, P, I, F, P, I, P, c_size_t, P],
+    "supir_layernorm": [P, P, P, P, I, I, I, I, F, P],
+    "supir_conv3x3_smallcin": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "supir_conv3x3_smallcout": [P, P, P, P, I, I, I, I, I, I, P],
+    "supir_pointwise_nchw": [P, P, P, P, I, I, I, L, F, P],
+}
+
+_lib = None
+
+
+class SupirHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (building is __graft_entry__.build()'s / supir_amd.build's job, never done implicitly)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SupirHipError(
+            f"{LIB_PATH} not found: run `python -m supir_amd.build` (hipcc, gfx950). The HIP extension is mandatory; "
+            "there is no CPU / PyTorch fallback on the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.supir_abi_version.restype = c_int
+    lib.supir_abi_version.argtypes = []
+    lib.supir_target_arch.restype = c_char_p
+    lib.supir_target_arch.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    if lib.supir_abi_version() != 1:
+        raise SupirHipError("libsupir_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise SupirHipError(f"{name} failed: {_ERR.get(rc, rc)}")

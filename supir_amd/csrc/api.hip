@@ -1,0 +1,105 @@
+// extern "C" surface of libsupir_hip.so (declared in include/supir_hip.h): argument validation + packing only.
+#include "kernels.h"
+#include "../../include/supir_hip.h"
+
+extern "C" {
+
+int supir_abi_version(void) { return 1; }
+const char* supir_target_arch(void) { return "gfx950"; }
+
+int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                    const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
+                    int out_mode, float alpha, int tile, void* stream) {
+    if (!A || !W || !C) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 3) return SUPIR_ERR_ARG;
+    if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
+    a.bias = bias; a.rowbias = (const bf16_t*)rowbias; a.res = (const bf16_t*)residual;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.ld_rb = ld_rowbias;
+    a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+    a.act = act; a.out_mode = out_mode; a.alpha = alpha;
+    if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)))
+        return SUPIR_ERR_SHAPE;
+    return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
+}
+
+int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int Wd, int Cin, int ldx, int Cout,
+                       int ldy, int OH, int OW, int stride, int pad_t, int pad_l, int upsample, const float* bias,
+                       const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,
+                       float alpha, int tile, void* stream) {
+    if (!X || !W || !Y) return SUPIR_ERR_ARG;
+    if (B <= 0 || H <= 0 || Wd <= 0 || OH <= 0 || OW <= 0) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || tile > 3) return SUPIR_ERR_ARG;
+    if (stride != 1 && stride != 2) return SUPIR_ERR_SHAPE;
+    if (upsample && stride != 1) return SUPIR_ERR_SHAPE;
+    if (ldy % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)) return SUPIR_ERR_SHAPE;
+    GemmArgs a{};
+    a.A = (const bf16_t*)X; a.Wt = (const bf16_t*)W; a.C = Y;
+    a.bias = bias; a.rowbias = (const bf16_t*)rowbias; a.res = (const bf16_t*)residual;
+    a.M = B * OH * OW; a.N = Cout; a.K = 9 * Cin; a.lda = ldx; a.ldc = ldy; a.ldr = ldr; a.ld_rb = ld_rowbias;
+    a.rows_per_batch = OH * OW;
+    a.H = H; a.W = Wd; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.up = upsample ? 1 : 0;
+    a.act = act; a.out_mode = out_mode; a.alpha = alpha;
+    return supir_gemm_launch(a, true, (hipStream_t)stream, tile);
+}
+
+int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
+                         int ldk, int ldvt, int ldo, float scale, void* stream) {
+    if (!Q || !K || !Vt || !O) return SUPIR_ERR_ARG;
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.Vt = (const bf16_t*)Vt; a.O = (bf16_t*)O;
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    return supir_attn_launch(a, (hipStream_t)stream);
+}
+
+int supir_softmax_rows(const float* S, void* P, int rows, int T, long ld_s, long ld_p, float scale, void* stream) {
+    if (!S || !P) return SUPIR_ERR_ARG;
+    return supir_softmax_rows_launch(S, (bf16_t*)P, rows, T, ld_s, ld_p, scale, (hipStream_t)stream);
+}
+
+int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x2raw, int B, int HW, int C, int C1, int ld1,
+                         int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
+                         const void* mod_b, int ldm, float control_scale, void* out, int ldo, float* workspace,
+                         size_t workspace_bytes, void* stream) {
+    if (!x1 || !gamma || !beta || !out || !workspace) return SUPIR_ERR_ARG;
+    if (C1 <= 0 || C1 > C) return SUPIR_ERR_ARG;
+    if (workspace_bytes < (size_t)B * 1024 * 64 * sizeof(float)) return SUPIR_ERR_ARG;
+    GnArgs a{};
+    a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.x2raw = (const bf16_t*)x2raw;
+    a.partial = workspace; a.gamma = gamma; a.beta = beta;
+    a.mod_g = (const bf16_t*)mod_g; a.mod_b = (const bf16_t*)mod_b; a.out = (bf16_t*)out;
+    a.B = B; a.HW = HW; a.C = C; a.C1 = C1; a.ld1 = ld1; a.ld2 = ld2; a.ldm = ldm; a.ldo = ldo;
+    a.act = act; a.eps = eps; a.cscale = control_scale;
+    return supir_groupnorm_launch(a, (hipStream_t)stream);
+}
+
+int supir_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, int ldx, int ldy,
+                    float eps, void* stream) {
+    if (!x || !y || !gamma || !beta) return SUPIR_ERR_ARG;
+    return supir_layernorm_launch((const bf16_t*)x, (bf16_t*)y, gamma, beta, rows, C, ldx, ldy, eps, (hipStream_t)stream);
+}
+
+int supir_conv3x3_smallcin(const float* x, const float* w, const float* bias, const void* add, void* out, int B,
+                           int Cin, int H, int W, int Cout, int ld_add, int ldo, void* stream) {
+    if (!x || !w || !out) return SUPIR_ERR_ARG;
+    return supir_conv3x3_smallcin_launch(x, w, bias, (const bf16_t*)add, (bf16_t*)out, B, Cin, H, W, Cout, ld_add, ldo,
+                                         (hipStream_t)stream);
+}
+
+int supir_conv3x3_smallcout(const void* x, const void* w, const float* bias, float* out, int B, int Cin, int H, int W,
+                            int Cout, int ldx, void* stream) {
+    if (!x || !w || !out) return SUPIR_ERR_ARG;
+    return supir_conv3x3_smallcout_launch((const bf16_t*)x, (const bf16_t*)w, bias, out, B, Cin, H, W, Cout, ldx,
+                                          (hipStream_t)stream);
+}
+
+int supir_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
+                         long HW, float in_scale, void* stream) {
+    if (!x || !w || !out) return SUPIR_ERR_ARG;
+    return supir_pointwise_nchw_launch(x, w, bias, out, B, Cin, Cout, HW, in_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+// Flash attention forward, head dim 64, bf16 in / fp32 online softmax / bf16 out, for gfx950 (MI355X).
+//
+// Replaces xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention at
+// sgm/modules/attention.py:273-277,357-359 (CrossAttention / MemoryEfficientCrossAttention) and the
+// ZeroCrossAttn call at SUPIR/modules/SUPIR_v0.py:146.  softmax(Q K^T / sqrt(64)) V, no mask, no dropout.
+//
+// Layout (chosen so no transpose kernel is ever needed):
+//   Q  [B][Tq][ldq]  head h at columns h*64..h*64+63   (exactly what the to_q GEMM writes: 'b n (h d)')
+//   K  [B][Tk][ldk]  same
+//   Vt [B][H*64][ldvt]  V TRANSPOSED per batch (row = h*64+d, column = key), written by the to_v GEMM's
+//                       transposed epilogue; ldvt >= round_up(Tk,64) and the padding is finite (zero)
+//   O  [B][Tq][ldo]
+// One workgroup = 4 waves = 128 query rows of one (batch, head); K / Vt tiles of 64 keys are staged through LDS
+// by global_load_lds (double buffered, counted vmcnt) and shared by the 4 waves.
+// MFMA 32x32x16 with swapped operands: S^T = K.Q^T puts one query row per lane (softmax needs one shfl_xor 32),
+// and P feeds the PV MFMA straight from those registers: the key order inside each 16-wide k block is
+// permuted identically on the Vt side, so no cross-lane exchange is needed.
+#include "kernels.h"
+
+
+template <int N>
+__device__ __forceinline__ void attn_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(256) void attn_d64_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nqb = (p.Tq + 127) >> 7;
+    const int id = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+    const int bh = id / nqb, qb = id - bh * nqb;  // consecutive ids (same XCD) share K/V of one (b,h)
+    const int b = bh / p.H, h = bh - b * p.H;
+
+    const bf16_t* Kb = p.K + (size_t)b * p.Tk * p.ldk + h * 64;
+    const bf16_t* Vb = p.Vt + ((size_t)b * p.H + h) * 64 * p.ldvt;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane -> query l31, d = 16*ks + 8*half .. +7
+    int q = qb * 128 + wave * 32 + l31;
+    const bool q_ok = q < p.Tq;
+    const int qc = q_ok ? q : p.Tq - 1;
+    const bf16_t* Qp = p.Q + ((size_t)b * p.Tq + qc) * p.ldq + h * 64 + 8 * half;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qp + 16 * ks);
+
+    // ---- loader: slot s = j*256+tid -> row j*32 + (tid>>3), physical chunk tid&7, logical chunk swizzled
+    const int lrow = tid >> 3;
+    const int lchunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const int nt = (p.Tk + 63) >> 6;
+    auto stage = [&](int t, int buf) {
+        char* sK = smem + buf * 16384;
+        char* sV = sK + 8192;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int key = t * 64 + j * 32 + lrow;
+            key = key < p.Tk ? key : p.Tk - 1;
+            glds16(Kb + (size_t)key * p.ldk + lchunk * 8, sK + (j * 256 + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int d = j * 32 + lrow;
+            glds16(Vb + (size_t)d * p.ldvt + t * 64 + lchunk * 8, sV + (j * 256 + wave * 64) * 16);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int sw = (l31 >> 1) & 7;
+    const int row_off = l31 * 128;
+
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) {
+            stage(t + 1, buf ^ 1);
+            attn_wait_vmcnt<4>();
+        } else {
+            attn_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sK = smem + buf * 16384;
+        const char* sV = sK + 8192;
+
+        // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
+        f32x16 s[2];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kf][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kfrag = *(const bf16x8*)(sK + kf * 4096 + row_off + (((2 * ks + half) ^ sw) * 16));
+                s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], s[kf], 0, 0, 0);
+            }
+        }
+        // lane holds query l31, keys t*64 + kf*32 + (r&3) + 8*(r>>2) + 4*half
+        if (t == nt - 1 && (p.Tk & 63)) {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (key >= p.Tk) s[kf][r] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kf][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);
+        m_run = m_new;
+        const float mb = m_new * p.scale_log2e;
+        float psum = 0.f;
+        bf16x8 pf[4];  // pf[kf*2+kb]: keys kf*32 + 16*kb + {4h..4h+3, 8+4h..8+4h+3}
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[kf][r] * p.scale_log2e - mb);
+                psum += pv;
+                pf[kf * 2 + (r >> 3)][r & 7] = (bf16_t)pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        // ---- O^T[d][q] += sum_key Vt[d][key] P[q][key]
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+            const char* vrow = sV + df * 4096 + row_off;
+#pragma unroll
+            for (int kb4 = 0; kb4 < 4; ++kb4) {
+                // 16 keys kbase..kbase+15 = logical chunks 2*kb4, 2*kb4+1 of the row; this lane needs
+                // bytes [8*half, 8*half+8) of each chunk
+                const bf16x4 lo = *(const bf16x4*)(vrow + (((2 * kb4) ^ sw) * 16) + 8 * half);
+                const bf16x4 hi = *(const bf16x4*)(vrow + (((2 * kb4 + 1) ^ sw) * 16) + 8 * half);
+                bf16x8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb4], o[df], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        bf16_t* Op = p.O + ((size_t)b * p.Tq + q) * p.ldo + h * 64;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                u16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[df][rg * 4 + e] * inv);
+                *(u16x4*)(Op + df * 32 + 8 * rg + 4 * half) = ov;
+            }
+    }
+}
+
+int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
+    if (a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0) return SUPIR_ERR_ARG;
+    if ((a.ldq | a.ldk | a.ldvt) % 8 != 0 || a.ldo % 4 != 0) return SUPIR_ERR_SHAPE;
+    if (a.ldvt < ((a.Tk + 63) / 64) * 64) return SUPIR_ERR_SHAPE;
+    const int nqb = (a.Tq + 127) / 128;
+    hipLaunchKernelGGL(attn_d64_kernel, dim3(nqb * a.H * a.B), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row softmax for the VAE mid-block single-head attention (head dim 512, reference:
+// sgm/modules/diffusionmodules/model.py:177-192, 228-256). With 288 GB of HBM the [T][T] score matrix is simply
+// materialised in fp32 by the GEMM kernel (out_mode 1); this kernel turns each fp32 row into bf16 probabilities.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
+                                                            int T, long lds_, long ldp, float scale) {
+    __shared__ float red[8];
+    const float* s = S + (size_t)blockIdx.x * lds_;
+    bf16_t* pr = P + (size_t)blockIdx.x * ldp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid * 4; i < T; i += 1024) {
+        const f32x4 v = *(const f32x4*)(s + i);
+        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = tid * 4; i < T; i += 1024) {
+        const f32x4 v = *(const f32x4*)(s + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += __expf((v[e] - mx) * scale);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int i = tid * 4; i < T; i += 1024) {
+        const f32x4 v = *(const f32x4*)(s + i);
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(__expf((v[e] - mx) * scale) * inv);
+        *(u16x4*)(pr + i) = o;
+    }
+}
+
+int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, long lds_, long ldp, float scale,
+                              hipStream_t st) {
+    if (rows <= 0 || T <= 0 || T % 4 != 0 || lds_ % 4 != 0 || ldp % 4 != 0) return SUPIR_ERR_SHAPE;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, S, P, T, lds_, ldp, scale);
+    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+}

@@ -1,0 +1,216 @@
+// Boundary kernels of the path: the few convolutions whose input or output has <= 8 channels (latent / RGB side).
+// They sit at the NCHW-fp32 boundary the reference exposes (latents [N,4,h,w], images [N,3,H,W]) and convert to /
+// from the internal NHWC bf16 layout on the fly, so no separate layout-conversion pass exists.
+//
+//   conv3x3_smallcin : fp32 NCHW [B,Cin<=8,H,W] -> bf16 NHWC [B,H,W,Cout]   UNet/control input_blocks.0.0 (4->320),
+//                      input_hint_block (4->320, fused "+ guided_hint" add), VAE encoder conv_in (3->128),
+//                      VAE decoder conv_in (4->512)                          (openaimodel.py:704, SUPIR_v0.py:325,482,
+//                                                                             model.py:512,646)
+//   conv3x3_smallcout: bf16 NHWC [B,H,W,Cin] -> fp32 NCHW [B,Cout<=8,H,W]   UNet out.2 (320->4), VAE encoder conv_out
+//                      (512->8), VAE decoder conv_out (128->3)               (openaimodel.py:951, model.py:563,694)
+//   pointwise_nchw   : fp32 NCHW 1x1 conv with <= 8 channels                 quant_conv / post_quant_conv
+//                                                                            (sgm/models/autoencoder.py:297-298)
+// All three are HBM / latency bound (a few MFLOP..GFLOP); none is worth MFMA.
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// weights: fp32 [Cout][Cin][3][3] (the reference's nn.Conv2d layout, untouched)
+__global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias,
+                                                               const bf16_t* __restrict__ add, bf16_t* __restrict__ out,
+                                                               int B, int Cin, int H, int W, int Cout, int ld_add,
+                                                               int ldo) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sw = (float*)smem_raw;  // [Cin*9][Cout]
+    const int tid = threadIdx.x;
+    const int K = Cin * 9;
+    for (int i = tid; i < K * Cout; i += 256) {
+        const int co = i / K, k = i - co * K;
+        sw[k * Cout + co] = w[i];
+    }
+    __syncthreads();
+    const int cvo = Cout >> 3;
+    const long total = (long)B * H * W * cvo;
+    for (long idx = (long)blockIdx.x * 256 + tid; idx < total; idx += (long)gridDim.x * 256) {
+        const int v = (int)(idx % cvo);
+        const long pix = idx / cvo;
+        const int xw = (int)(pix % W);
+        const int yh = (int)((pix / W) % H);
+        const int b = (int)(pix / ((long)W * H));
+        const int co = v * 8;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[co + e] : 0.f;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xp = x + ((size_t)b * Cin + ci) * H * W;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = yh + ky - 1;
+                if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = xw + kx - 1;
+                    if ((unsigned)ix >= (unsigned)W) continue;
+                    const float xv = xp[(size_t)iy * W + ix];
+                    const float* wp = sw + ((ci * 3 + ky) * 3 + kx) * Cout + co;
+                    const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[e] += xv * w0[e];
+                        acc[4 + e] += xv * w1[e];
+                    }
+                }
+            }
+        }
+        if (add) {
+            const u16x8 av = *(const u16x8*)(add + (size_t)pix * ld_add + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(av[e]);
+        }
+        u16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[e]);
+        *(u16x8*)(out + (size_t)pix * ldo + co) = ov;
+    }
+}
+
+int supir_conv3x3_smallcin_launch(const float* x, const float* w, const float* bias, const bf16_t* add, bf16_t* out,
+                                  int B, int Cin, int H, int W, int Cout, int ld_add, int ldo, hipStream_t st) {
+    if (B <= 0 || Cin <= 0 || Cin > 8 || Cout % 8 != 0 || ldo % 8 != 0 || (add && ld_add % 8 != 0)) return SUPIR_ERR_SHAPE;
+    const size_t smem = (size_t)Cin * 9 * Cout * sizeof(float);
+    if (smem > 160 * 1024) return SUPIR_ERR_SHAPE;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv3x3_smallcin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return SUPIR_ERR_HIP;
+        attr = true;
+    }
+    const long total = (long)B * H * W * (Cout / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv3x3_smallcin_kernel, dim3((unsigned)blocks), dim3(256), smem, st, x, w, bias, add, out, B, Cin,
+                       H, W, Cout, ld_add, ldo);
+    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 16 lanes cooperate on one output pixel: each lane owns channel vectors v = l16, l16+16, ...; 9 taps accumulate into
+// COUT partial sums per lane which are then reduced across the 16 lanes with shuffles.
+// weights: bf16 [9][COUT][Cin] (tap-major, prepared once on the host side)
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_smallcout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                int B, int Cin, int H, int W, int ldx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* sw = (bf16_t*)smem_raw;
+    const int tid = threadIdx.x;
+    const int nw8 = 9 * COUT * Cin / 8;
+    for (int i = tid; i < nw8; i += 256) ((u16x8*)sw)[i] = ((const u16x8*)w)[i];
+    __syncthreads();
+    const int l16 = tid & 15;
+    const int cv = Cin >> 3;
+    const long npix = (long)B * H * W;
+    for (long pix = (long)blockIdx.x * 16 + (tid >> 4); pix < npix; pix += (long)gridDim.x * 16) {
+        const int xw = (int)(pix % W);
+        const int yh = (int)((pix / W) % H);
+        const int b = (int)(pix / ((long)W * H));
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = yh + ky - 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = xw + kx - 1;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const bf16_t* xp = x + (((size_t)b * H + iy) * W + ix) * ldx;
+                const bf16_t* wp = sw + (size_t)(ky * 3 + kx) * COUT * Cin;
+                for (int v = l16; v < cv; v += 16) {
+                    const u16x8 xv = *(const u16x8*)(xp + v * 8);
+                    float xf[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xf[e] = bf2f(xv[e]);
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o) {
+                        const u16x8 wv = *(const u16x8*)(wp + (size_t)o * Cin + v * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[o] += xf[e] * bf2f(wv[e]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            float a = acc[o];
+            a += __shfl_xor(a, 8, 64);
+            a += __shfl_xor(a, 4, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 1, 64);
+            acc[o] = a;
+        }
+        if (l16 < COUT) {
+            float r = 0.f;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) r = (l16 == o) ? acc[o] : r;
+            out[(((size_t)b * COUT + l16) * H + yh) * W + xw] = r + (bias ? bias[l16] : 0.f);
+        }
+    }
+}
+
+int supir_conv3x3_smallcout_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* out, int B, int Cin,
+                                   int H, int W, int Cout, int ldx, hipStream_t st) {
+    if (B <= 0 || Cin % 8 != 0 || ldx % 8 != 0) return SUPIR_ERR_SHAPE;
+    const size_t smem = (size_t)9 * Cout * Cin * 2;
+    if (smem > 160 * 1024) return SUPIR_ERR_SHAPE;
+    const long npix = (long)B * H * W;
+    long blocks = (npix + 15) / 16;
+    if (blocks > 1024) blocks = 1024;
+#define SC_LAUNCH(CO)                                                                                              \
+    {                                                                                                              \
+        static bool attr = false;                                                                                  \
+        if (!attr) {                                                                                               \
+            if (hipFuncSetAttribute((const void*)conv3x3_smallcout_kernel<CO>,                                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)         \
+                return SUPIR_ERR_HIP;                                                                              \
+            attr = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL(conv3x3_smallcout_kernel<CO>, dim3((unsigned)blocks), dim3(256), smem, st, x, w, bias,  \
+                           out, B, Cin, H, W, ldx);                                                                \
+    }
+    switch (Cout) {
+        case 3: SC_LAUNCH(3); break;
+        case 4: SC_LAUNCH(4); break;
+        case 8: SC_LAUNCH(8); break;
+        default: return SUPIR_ERR_SHAPE;
+    }
+#undef SC_LAUNCH
+    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pointwise_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int B, int Cin, int Cout, long HW, float in_scale) {
+    const long total = (long)B * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / HW, p = i - b * HW;
+        float xin[8];
+        for (int c = 0; c < Cin; ++c) xin[c] = x[(b * Cin + c) * HW + p] * in_scale;
+        for (int o = 0; o < Cout; ++o) {
+            float a = bias ? bias[o] : 0.f;
+            for (int c = 0; c < Cin; ++c) a += w[o * Cin + c] * xin[c];
+            out[(b * Cout + o) * HW + p] = a;
+        }
+    }
+}
+
+int supir_pointwise_nchw_launch(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
+                                long HW, float in_scale, hipStream_t st) {
+    if (B <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || Cout > 8 || HW <= 0) return SUPIR_ERR_SHAPE;
+    long blocks = ((long)B * HW + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pointwise_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, out, B, Cin, Cout, HW,
+                       in_scale);
+    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+}

@@ -1,0 +1,314 @@
+// bf16 MFMA GEMM / implicit-GEMM conv3x3 for gfx950 (MI355X).
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )        (every nn.Linear / 1x1 conv / 3x3 conv of the path)
+//
+// Replaces the cuBLAS / cuDNN calls issued by the reference's nn.Linear / nn.Conv2d modules
+// (reference: sgm/modules/attention.py:87,100,106,213-219,587,611; sgm/modules/diffusionmodules/
+// openaimodel.py:127,196,263,300; SUPIR/modules/SUPIR_v0.py:48,79-87; sgm/modules/diffusionmodules/model.py:60-124).
+//
+// Design (CDNA4):
+//  * activations are NHWC bf16 ("tokens x channels"), weights are [N][K] bf16 with K contiguous, so both MFMA
+//    operands are K-contiguous rows and are staged with the same code;
+//  * global -> LDS by `global_load_lds_dwordx4` (no VGPR round trip). The LDS image is lane-linear, so the
+//    bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the ds_read_b128 side:
+//    16-B chunk c of row r lives at chunk c ^ ((r>>1)&7)  (conflict-free for the 32x32x16 fragment read);
+//  * 3x3 convolution is the same kernel with an im2col gather in the A loader: K runs (ky,kx,cin) and a
+//    64-wide K step never straddles a tap because Cin % 64 == 0; halo / padding lanes read a zero page;
+//    stride 2, asymmetric padding (VAE Downsample) and nearest-2x upsampling are folded into the gather;
+//  * v_mfma_f32_32x32x16_bf16, 4 waves (2x2), operands swapped (a = W rows, b = A rows) so that every lane
+//    ends up with 4 consecutive output channels of one token -> 8-byte bf16 stores, fused epilogue
+//    (bias, per-batch time-embedding add, residual add, SiLU, GEGLU, scale);
+//  * double-buffered LDS, counted vmcnt so the next K tile stays in flight across the barrier;
+//  * XCD-aware workgroup -> tile mapping (8 private L2s).
+#include "kernels.h"
+
+
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, bool CONV, bool TRANS>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32, LOADS = A_LOADS + B_LOADS;
+    constexpr int MI = BM / 64, NI = BN / 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tile_n = id / tiles_m, tile_m = id - tile_n * tiles_m;  // neighbours share the W panel
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- loader state: slot s = j*256 + tid -> row j*32 + (tid>>3), physical chunk tid&7 ----
+    const int lrow = tid >> 3;
+    const int lchunk = (tid & 7) ^ ((tid >> 4) & 7);  // logical 16-B chunk this lane fetches
+    const bf16_t* a_ptr[A_LOADS];
+    int a_iy0[A_LOADS], a_ix0[A_LOADS];  // conv: oy*stride - pad_t, ox*stride - pad_l
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+        int m = m0 + j * 32 + lrow;
+        m = m < p.M ? m : p.M - 1;
+        if constexpr (CONV) {
+            const int b = m / p.rows_per_batch;
+            const int r = m - b * p.rows_per_batch;
+            const int oy = r / p.OW, ox = r - oy * p.OW;
+            a_iy0[j] = oy * p.stride - p.pad_t;
+            a_ix0[j] = ox * p.stride - p.pad_l;
+            a_ptr[j] = p.A + (size_t)b * p.H * p.W * p.lda + lchunk * 8;
+        } else {
+            a_ptr[j] = p.A + (size_t)m * p.lda + lchunk * 8;
+        }
+    }
+    const bf16_t* b_ptr[B_LOADS];
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+        int n = n0 + j * 32 + lrow;
+        n = n < p.N ? n : p.N - 1;
+        b_ptr[j] = p.Wt + (size_t)n * p.K + lchunk * 8;
+    }
+    const int VH = p.up ? 2 * p.H : p.H, VW = p.up ? 2 * p.W : p.W;
+    const bf16_t* zero = (const bf16_t*)g_zero_page;
+
+    int ld_k0 = 0, ld_cin0 = 0, ld_ky = 0, ld_kx = 0;  // position of the NEXT tile to stage
+    auto stage = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j) {
+            const bf16_t* src;
+            if constexpr (CONV) {
+                int iy = a_iy0[j] + ld_ky, ix = a_ix0[j] + ld_kx;
+                const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                src = ok ? a_ptr[j] + ((size_t)iy * p.W + ix) * p.lda + ld_cin0 : zero;
+            } else {
+                src = a_ptr[j] + ld_k0;
+            }
+            glds16(src, sA + (j * 256 + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) glds16(b_ptr[j] + ld_k0, sB + (j * 256 + wave * 64) * 16);
+        ld_k0 += 64;
+        if constexpr (CONV) {
+            ld_cin0 += 64;
+            if (ld_cin0 == p.Cin) {
+                ld_cin0 = 0;
+                if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: row = base32 + l31, logical chunk 2*ks+half, physical chunk ^ ((row>>1)&7)
+    const int sw = (l31 >> 1) & 7;
+    const int a_row_off = (wm * (BM / 2) + l31) * 128;
+    const int b_row_off = (wn * (BN / 2) + l31) * 128;
+
+    const int nk = p.K >> 6;
+    stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            stage(buf ^ 1);
+            wait_vmcnt<LOADS>();  // tile kt landed (tile kt+1 may still be in flight)
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = ((2 * ks + half) ^ sw) * 16;
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sA + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(sB + b_row_off + j * 32 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr (TRANS)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone done reading buf before it is restaged
+        asm volatile("" ::: "memory");
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    if constexpr (TRANS) {
+        // D[i = token][j = channel]: lane owns channel l31, tokens (r&3)+8*(r>>2)+4*half -> 4 consecutive tokens
+        bf16_t* Cb = (bf16_t*)p.C;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+                if (n >= p.N) continue;
+                const float bz = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + 8 * rg + 4 * half;
+                    if (m >= p.M) continue;
+                    const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
+                    if (m + 3 < p.M && t + 3 < p.rows_per_batch && ((t | p.ldc) & 3) == 0) {
+                        u16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = f2bf(p.alpha * (acc[i][j][rg * 4 + e] + bz));
+                        *(u16x4*)(Cb + ((size_t)b * p.N + n) * p.ldc + t) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int me = m + e;
+                            if (me < p.M) {
+                                const int be = me / p.rows_per_batch, te = me - be * p.rows_per_batch;
+                                ((u16*)Cb)[((size_t)be * p.N + n) * p.ldc + te] =
+                                    f2bf(p.alpha * (acc[i][j][rg * 4 + e] + bz));
+                            }
+                        }
+                    }
+                }
+            }
+        return;
+    } else {
+        // D[i = channel][j = token]: lane owns token l31, channels (r&3)+8*(r>>2)+4*half -> 4 consecutive channels
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 32 + l31;
+            if (m >= p.M) continue;
+            const int bidx = p.rowbias ? m / p.rows_per_batch : 0;
+            if (p.act == 2) {
+                // GEGLU: fragment pair (value, gate) = (j even, j odd) inside the wave's 64 columns
+                if constexpr (NI == 2) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int nl = wn * 64 + 8 * rg + 4 * half;  // column inside the 128-wide tile
+                        const int nv = n0 + nl, ng = n0 + nl + 32;   // interleaved weight rows
+                        if (ng >= p.N) continue;
+                        f32x4 bv = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+                        if (p.bias) { bv = *(const f32x4*)(p.bias + nv); bg = *(const f32x4*)(p.bias + ng); }
+                        u16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[i][0][rg * 4 + e] + bv[e];
+                            const float g = acc[i][1][rg * 4 + e] + bg[e];
+                            o[e] = f2bf(v * gelu_f(g));
+                        }
+                        const int no = (n0 >> 1) + wn * 32 + 8 * rg + 4 * half;
+                        *(u16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + wn * (BN / 2) + j * 32 + 8 * rg + 4 * half;
+                    if (n >= p.N) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
+                    if (p.bias) {
+                        const f32x4 bz = *(const f32x4*)(p.bias + n);
+                        v += bz;
+                    }
+                    if (p.rowbias) {
+                        const u16x4 rb = *(const u16x4*)(p.rowbias + (size_t)bidx * p.ld_rb + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bf2f(rb[e]);
+                    }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+                    if (p.res) {
+                        const u16x4 rr = *(const u16x4*)(p.res + (size_t)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bf2f(rr[e]);
+                    }
+                    if (p.out_mode == 1) {
+                        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+                    } else {
+                        u16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                        *(u16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                    }
+                }
+        }
+    }
+}
+
+template <int BM, int BN, bool CONV, bool TRANS>
+static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    constexpr int smem = 2 * (BM + BN) * 128;
+    auto kern = gemm_bf16_kernel<BM, BN, CONV, TRANS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return SUPIR_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, st, a);
+    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+}
+
+// tile choice: biggest tile that still yields >= ~1 wave of workgroups over 256 CUs
+template <bool CONV, bool TRANS>
+static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
+    auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+    int sel = force_tile;
+    if (a.act == 2) {  // GEGLU needs a 128-wide tile (value+gate fragment pair per wave)
+        if (sel != 0 && sel != 2) sel = -1;
+        if (sel < 0) sel = (tiles(128, 128) >= 200) ? 0 : 2;
+    }
+    if (sel < 0) {
+        if (tiles(128, 128) >= 240) sel = 0;
+        else if (a.N % 128 != 0 && tiles(128, 64) >= 200) sel = 1;
+        else if (tiles(128, 64) >= 240) sel = 1;
+        else if (tiles(64, 128) >= 240) sel = 2;
+        else sel = 3;
+    }
+    switch (sel) {
+        case 0: return launch_gemm<128, 128, CONV, TRANS>(a, st);
+        case 1: return launch_gemm<128, 64, CONV, TRANS>(a, st);
+        case 2: return launch_gemm<64, 128, CONV, TRANS>(a, st);
+        default: return launch_gemm<64, 64, CONV, TRANS>(a, st);
+    }
+}
+
+int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return SUPIR_ERR_ARG;
+    if (a.K % 64 != 0 || a.N % 4 != 0 || a.lda % 8 != 0) return SUPIR_ERR_SHAPE;
+    if (conv && (a.Cin % 64 != 0 || a.K != 9 * a.Cin)) return SUPIR_ERR_SHAPE;
+    if (a.act == 2 && (a.N % 128 != 0 || a.out_mode != 0 || a.res || a.rowbias)) return SUPIR_ERR_SHAPE;
+    if (a.out_mode == 2) {
+        if (a.act != 0 || a.res || a.rowbias) return SUPIR_ERR_SHAPE;
+        return conv ? SUPIR_ERR_SHAPE : dispatch_gemm<false, true>(a, st, force_tile);
+    }
+    return conv ? dispatch_gemm<true, false>(a, st, force_tile) : dispatch_gemm<false, false>(a, st, force_tile);
+}

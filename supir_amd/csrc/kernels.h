@@ -1,0 +1,60 @@
+// Argument blocks and host-side launchers shared between the kernel translation units and the C-ABI (api.hip).
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+    const bf16_t* A;        // plain: [M][lda]; conv: NHWC input [B][H][W][lda]
+    const bf16_t* Wt;       // [N][K]
+    void* C;
+    const float* bias;      // [N] or null
+    const bf16_t* rowbias;  // [batch][ld_rb] or null: added to every row of that batch (time embedding)
+    const bf16_t* res;      // [M][ldr] or null: residual
+    int M, N, K;
+    int lda, ldc, ldr, ld_rb;
+    int rows_per_batch;     // rows (tokens) per batch element
+    int H, W, Cin, OH, OW, stride, pad_t, pad_l, up;  // conv geometry (virtual input = 2H x 2W when up)
+    int act;                // 0 none, 1 SiLU, 2 GEGLU (value/gate interleaved per 32 columns)
+    int out_mode;           // 0 bf16 [M][ldc], 1 fp32 [M][ldc], 2 bf16 transposed [batch][N][ldc]
+    float alpha;            // result = alpha * act(acc + bias + rowbias) + residual
+};
+
+struct AttnArgs {
+    const bf16_t* Q;
+    const bf16_t* K;
+    const bf16_t* Vt;
+    bf16_t* O;
+    int B, H, Tq, Tk;
+    int ldq, ldk, ldvt, ldo;
+    float scale_log2e;  // softmax scale * log2(e)
+};
+
+struct GnArgs {
+    const bf16_t* x1;   // [B][HW][ld1], channels [0,C1)
+    const bf16_t* x2;   // [B][HW][ld2], channels [C1,C)  (null when C1 == C)  -- the ZeroSFT / skip concat
+    const bf16_t* x2raw;  // ZeroSFT lerp only: un-projected skip (h before + zero_conv(c)); may be null
+    float* partial;     // [B][nchunk][32][2]  (sum, sumsq)
+    const float* gamma; // [C]
+    const float* beta;  // [C]
+    const bf16_t* mod_g;  // [B][HW][ldm] ZeroSFT gamma map or null
+    const bf16_t* mod_b;  // [B][HW][ldm] ZeroSFT beta map
+    bf16_t* out;        // [B][HW][ldo]
+    int B, HW, C, C1;
+    int ld1, ld2, ldm, ldo;
+    int nchunk, rows_per_chunk;
+    int act;            // 0 none, 1 SiLU
+    float eps;
+    float cscale;       // ZeroSFT control_scale (1 -> no lerp)
+};
+
+int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile);
+int supir_attn_launch(const AttnArgs& a, hipStream_t st);
+int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, long lds_, long ldp, float scale, hipStream_t st);
+int supir_groupnorm_launch(GnArgs a, hipStream_t st);
+int supir_layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int rows, int C, int ldx,
+                           int ldy, float eps, hipStream_t st);
+int supir_conv3x3_smallcin_launch(const float* x, const float* w, const float* bias, const bf16_t* add, bf16_t* out, int B,
+                                  int Cin, int H, int W, int Cout, int ld_add, int ldo, hipStream_t st);
+int supir_conv3x3_smallcout_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* out, int B, int Cin, int H,
+                                   int W, int Cout, int ldx, hipStream_t st);
+int supir_pointwise_nchw_launch(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
+                                long HW, float in_scale, hipStream_t st);

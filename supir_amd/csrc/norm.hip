@@ -1,0 +1,242 @@
+// GroupNorm(32) (+SiLU, +ZeroSFT modulation) and LayerNorm on NHWC / token-major bf16, for gfx950.
+//
+// Replaces ATen group_norm / layer_norm / silu called from
+//   GroupNorm32  sgm/modules/diffusionmodules/util.py:258-276 (eps 1e-5; ResBlock, ZeroSFT, ZeroCrossAttn, UNet.out)
+//   Normalize    sgm/modules/attention.py:122-125 and sgm/modules/diffusionmodules/model.py:48-51 (eps 1e-6)
+//   nn.LayerNorm sgm/modules/attention.py:437-439
+//   ZeroSFT      SUPIR/modules/SUPIR_v0.py:91-113  (GN(cat[h_ori,h]) * (gamma+1) + beta, lerp by control_scale)
+// These are HBM-bound kernels: 16-byte loads/stores, fp32 statistics, two launches per GroupNorm
+// (partial sums per row-chunk, then normalise+activate); the second read is served by L2 / Infinity Cache.
+#include "kernels.h"
+
+
+__device__ __forceinline__ const bf16_t* gn_src(const GnArgs& p, int b, int row, int c) {
+    return (c < p.C1) ? p.x1 + ((size_t)b * p.HW + row) * p.ld1 + c
+                      : p.x2 + ((size_t)b * p.HW + row) * p.ld2 + (c - p.C1);
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
+    __shared__ float acc[64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    if (tid < 64) acc[tid] = 0.f;
+    __syncthreads();
+    const int cv = p.C >> 3, cpg = p.C >> 5;
+    const int cvb = cv < 256 ? cv : 256;
+    const int TY = 256 / cvb;
+    const int vx = tid % cvb, ty = tid / cvb;
+    const int row0 = chunk * p.rows_per_chunk;
+    const int row1 = min(p.HW, row0 + p.rows_per_chunk);
+    if (ty < TY) {
+        for (int v = vx; v < cv; v += cvb) {
+            float s[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+            const int c = v * 8;
+            int row = row0 + ty;
+            for (; row + 3 * TY < row1; row += 4 * TY) {
+                u16x8 xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = *(const u16x8*)gn_src(p, b, row + u * TY, c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = bf2f(xv[u][e]);
+                        s[e] += f;
+                        q[e] += f * f;
+                    }
+            }
+            for (; row < row1; row += TY) {
+                const u16x8 xv = *(const u16x8*)gn_src(p, b, row, c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bf2f(xv[e]);
+                    s[e] += f;
+                    q[e] += f * f;
+                }
+            }
+            // channels -> groups (a 16-byte vector may straddle groups when C/32 is not a multiple of 8)
+            int g = c / cpg;
+            float gs = 0.f, gq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ge = (c + e) / cpg;
+                if (ge != g) {
+                    atomicAdd(&acc[2 * g], gs);
+                    atomicAdd(&acc[2 * g + 1], gq);
+                    g = ge;
+                    gs = gq = 0.f;
+                }
+                gs += s[e];
+                gq += q[e];
+            }
+            atomicAdd(&acc[2 * g], gs);
+            atomicAdd(&acc[2 * g + 1], gq);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) p.partial[((size_t)b * p.nchunk + chunk) * 64 + tid] = acc[tid];
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchunk_apply, int rows_per_chunk_apply) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sA = (float*)smem_raw;  // [C] scale
+    float* sB = sA + p.C;          // [C] shift
+    __shared__ float s_mean[32], s_rstd[32];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int cv = p.C >> 3, cpg = p.C >> 5;
+    if (tid < 32) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < p.nchunk; ++k) {
+            const float* pp = p.partial + ((size_t)b * p.nchunk + k) * 64 + 2 * tid;
+            s += (double)pp[0];
+            q += (double)pp[1];
+        }
+        const double n = (double)p.HW * (double)cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        const int g = c / cpg;
+        const float a = s_rstd[g] * p.gamma[c];
+        sA[c] = a;
+        sB[c] = p.beta[c] - s_mean[g] * a;
+    }
+    __syncthreads();
+    const int row0 = chunk * rows_per_chunk_apply;
+    const int row1 = min(p.HW, row0 + rows_per_chunk_apply);
+    const int items = (row1 - row0) * cv;
+    const bool lerp = p.cscale != 1.0f;
+    for (int idx = tid; idx < items; idx += 256) {
+        const int r = idx / cv, v = idx - r * cv;
+        const int row = row0 + r, c = v * 8;
+        const u16x8 xv = *(const u16x8*)gn_src(p, b, row, c);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = bf2f(xv[e]) * sA[c + e] + sB[c + e];
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+        }
+        if (p.mod_g) {
+            const size_t mo = ((size_t)b * p.HW + row) * p.ldm + c;
+            const u16x8 gv = *(const u16x8*)(p.mod_g + mo);
+            const u16x8 bv = *(const u16x8*)(p.mod_b + mo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = y[e] * (bf2f(gv[e]) + 1.0f) + bf2f(bv[e]);
+            if (lerp) {
+                u16x8 rv = xv;  // h_raw = cat[h_ori, h] (h BEFORE the zero_conv projection)
+                if (c >= p.C1 && p.x2raw) rv = *(const u16x8*)(p.x2raw + ((size_t)b * p.HW + row) * p.ld2 + (c - p.C1));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = y[e] * p.cscale + bf2f(rv[e]) * (1.0f - p.cscale);
+            }
+        }
+        u16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = f2bf(y[e]);
+        *(u16x8*)(p.out + ((size_t)b * p.HW + row) * p.ldo + c) = ov;
+    }
+}
+
+int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
+    if (a.B <= 0 || a.HW <= 0 || a.C <= 0 || a.C % 32 != 0) return SUPIR_ERR_SHAPE;
+    if (a.C % 8 != 0 || a.C1 % 8 != 0 || a.ld1 % 8 != 0 || a.ldo % 8 != 0) return SUPIR_ERR_SHAPE;
+    if (a.C1 < a.C && (!a.x2 || a.ld2 % 8 != 0)) return SUPIR_ERR_ARG;
+    if (a.mod_g && (!a.mod_b || a.ldm % 8 != 0)) return SUPIR_ERR_ARG;
+    a.nchunk = a.HW / 64;
+    if (a.nchunk < 1) a.nchunk = 1;
+    if (a.nchunk > 1024) a.nchunk = 1024;   // workspace contract: B * 1024 * 64 floats
+    a.rows_per_chunk = (a.HW + a.nchunk - 1) / a.nchunk;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), 0, st, a);
+    // apply: ~64 KB of bf16 per workgroup iteration, at least 2 waves of workgroups when there is enough work
+    long rows_target = (long)(64 * 1024) / (2L * a.C);
+    if (rows_target < 8) rows_target = 8;
+    int nca = (int)((a.HW + rows_target - 1) / rows_target);
+    if (nca > 2048) nca = 2048;
+    const int rpc = (a.HW + nca - 1) / nca;
+    nca = (a.HW + rpc - 1) / rpc;
+    const size_t smem = (size_t)a.C * 2 * sizeof(float);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nca, a.B), dim3(256), smem, st, a, nca, rpc);
+    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm over the channel dim of token-major bf16 [rows][ld]; one wave per row, row kept in registers.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int C, int ldx, int ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int cv = C >> 3;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < cv) {
+            const u16x8 xv = *(const u16x8*)(xr + vi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = bf2f(xv[e]);
+                s += v[i][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < cv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < cv) {
+            const f32x4 g0 = *(const f32x4*)(gamma + vi * 8), g1 = *(const f32x4*)(gamma + vi * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + vi * 8), b1 = *(const f32x4*)(beta + vi * 8 + 4);
+            u16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ov[e] = f2bf((v[i][e] - mean) * rstd * g0[e] + b0[e]);
+                ov[4 + e] = f2bf((v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+            }
+            *(u16x8*)(yr + vi * 8) = ov;
+        }
+    }
+}
+
+int supir_layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int rows, int C,
+                           int ldx, int ldy, float eps, hipStream_t st) {
+    if (rows <= 0 || C <= 0 || C % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || C > 4096) return SUPIR_ERR_SHAPE;
+    const int nv = (C / 8 + 63) / 64;
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+    }
+    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+}

@@ -1,0 +1,295 @@
+"""Tensor-level wrappers over the C ABI (raw device pointers out of torch tensors; torch is only the allocator/stream).
+
+Internal activation layout: bf16, channels last.  A feature map is a tensor of logical shape [B, H, W, C] whose last
+dim is contiguous and whose pixel stride `ld` (>= C) is uniform (so channel slices of a wider buffer are valid
+operands: this is how `torch.cat(dim=1)` of the reference disappears).  Token tensors are [B, T, C] / [M, C].
+"""
+import math
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+
+# --------------------------------------------------------------------------------------------- op trace (bench / roofline)
+_TRACE = None
+
+
+def start_trace():
+    global _TRACE
+    _TRACE = []
+    return _TRACE
+
+
+def stop_trace():
+    global _TRACE
+    t, _TRACE = _TRACE, None
+    return t
+
+
+def _rec(kernel, flops, bytes_, **shape):
+    if _TRACE is not None:
+        _TRACE.append(dict(kernel=kernel, flops=float(flops), bytes=float(bytes_), **shape))
+
+
+# --------------------------------------------------------------------------------------------- helpers
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _rows_ld(t):
+    """(rows, C, ld) of a channels-last tensor whose leading dims are dense in units of the pixel stride."""
+    assert t.stride(-1) == 1, "channel dim must be contiguous"
+    C = t.shape[-1]
+    if t.dim() == 1:
+        return 1, C, C
+    ld = t.stride(-2)
+    rows = 1
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1:
+            assert t.stride(d) == exp, f"non-uniform pixel stride {t.shape} {t.stride()}"
+        exp *= t.shape[d]
+        rows *= t.shape[d]
+    return rows, C, ld
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.SupirHipError("supir_amd ops need CUDA(HIP) tensors: the product path has no CPU fallback")
+
+
+_WS = {}
+
+
+def _gn_workspace(B, device):
+    key = (B, device)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty(B * 1024 * 64, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+# --------------------------------------------------------------------------------------------- GEMM family
+def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=0, alpha=1.0, out=None,
+         out_dtype=BF16, tile=-1):
+    """out[M,N] = alpha*act(a[M,K] @ w[N,K]^T + bias + rowbias[batch]) + residual.  act=2 (GEGLU) -> N/2 columns."""
+    lib = _lib.load()
+    _check_dev(a, w)
+    M, K, lda = _rows_ld(a)
+    N = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous() and w.dtype == BF16 and a.dtype == BF16
+    n_out = N // 2 if act == 2 else N
+    if out is None:
+        out = torch.empty(*a.shape[:-1], n_out, dtype=out_dtype, device=a.device)
+    Mo, No, ldc = _rows_ld(out)
+    assert Mo == M and No == n_out
+    ldr = 0
+    if residual is not None:
+        Mr, Nr, ldr = _rows_ld(residual)
+        assert Mr == M and Nr == n_out and residual.dtype == BF16
+    ld_rb = 0
+    if rowbias is not None:
+        assert rowbias.dtype == BF16 and rowbias.stride(-1) == 1 and rowbias.shape[-1] == N
+        ld_rb = rowbias.stride(0)
+    om = 0 if out.dtype == BF16 else 1
+    rc = lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, ldc, _p(bias), _p(rowbias), ld_rb,
+                             rows_per_batch, _p(residual), ldr, act, om, alpha, tile, _stream())
+    _lib.check(rc, "supir_gemm_bf16")
+    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), M=M, N=N, K=K)
+    return out
+
+
+def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
+    """Transposed projection: out[b][n][t] = (a[b*T+t] @ w[n]) (+bias); out is [B, N, Tpad] (zero padded)."""
+    lib = _lib.load()
+    _check_dev(a, w)
+    M, K, lda = _rows_ld(a)
+    assert M == B * T
+    N = w.shape[0]
+    if out is None:
+        out = torch.zeros(B, N, Tpad, dtype=BF16, device=a.device) if Tpad != T else \
+            torch.empty(B, N, Tpad, dtype=BF16, device=a.device)
+    rc = lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, Tpad, _p(bias), 0, 0, T, 0, 0, 0, 2,
+                             1.0, tile, _stream())
+    _lib.check(rc, "supir_gemm_bf16(T)")
+    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), M=M, N=N, K=K)
+    return out
+
+
+def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=None, rowbias=None, residual=None,
+            act=0, alpha=1.0, out=None, tile=-1):
+    """x [B,H,W,Cin(ld)] bf16 -> [B,OH,OW,Cout]. w [Cout,3,3,Cin] bf16. pad=(top,left); bottom/right implied by out_hw."""
+    lib = _lib.load()
+    _check_dev(x, w)
+    B, H, W, Cin = x.shape
+    _, _, ldx = _rows_ld(x)
+    Cout = w.shape[0]
+    assert w.shape[1:] == (3, 3, Cin) and w.is_contiguous() and w.dtype == BF16 and x.dtype == BF16
+    if out_hw is None:
+        if upsample:
+            out_hw = (2 * H, 2 * W)
+        elif stride == 1:
+            out_hw = (H, W)
+        else:
+            out_hw = ((H + 2 * pad[0] - 3) // stride + 1, (W + 2 * pad[1] - 3) // stride + 1)
+    OH, OW = out_hw
+    if out is None:
+        out = torch.empty(B, OH, OW, Cout, dtype=BF16, device=x.device)
+    _, _, ldy = _rows_ld(out)
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == BF16
+        _, _, ldr = _rows_ld(residual)
+    ld_rb = 0
+    if rowbias is not None:
+        assert rowbias.dtype == BF16 and rowbias.shape == (B, Cout) and rowbias.stride(-1) == 1
+        ld_rb = rowbias.stride(0)
+    om = 0 if out.dtype == BF16 else 1
+    rc = lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cin, ldx, Cout, ldy, OH, OW, stride,
+                                pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb, _p(residual), ldr,
+                                act, om, alpha, tile, _stream())
+    _lib.check(rc, "supir_conv3x3_bf16")
+    M = B * OH * OW
+    _rec("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout), M=M, N=Cout, K=9 * Cin)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- attention
+def flash_attn(q, k, vt, B, H, Tq, Tk, out=None):
+    """q [B,Tq,>=H*64] k [B,Tk,>=H*64] (views with row stride), vt [B,H*64,Tpad]; returns [B,Tq,H*64]."""
+    lib = _lib.load()
+    _check_dev(q, k, vt)
+    assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and vt.is_contiguous()
+    ldq, ldk, ldvt = q.stride(-2), k.stride(-2), vt.shape[-1]
+    assert q.shape[0] == B and q.stride(0) == Tq * ldq and k.stride(0) == Tk * ldk
+    if out is None:
+        out = torch.empty(B, Tq, H * 64, dtype=BF16, device=q.device)
+    rc = lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
+                                  out.stride(-2), 0.125, _stream())
+    _lib.check(rc, "supir_flash_attn_d64")
+    _rec("attn", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * H * 64 * (2 * Tq + 2 * Tk), B=B, H=H, Tq=Tq, Tk=Tk)
+    return out
+
+
+def softmax_rows(s, scale, out=None):
+    lib = _lib.load()
+    _check_dev(s)
+    rows, T = s.shape
+    assert s.dtype == torch.float32 and s.stride(1) == 1
+    if out is None:
+        out = torch.empty(rows, T, dtype=BF16, device=s.device)
+    rc = lib.supir_softmax_rows(s.data_ptr(), out.data_ptr(), rows, T, s.stride(0), out.stride(0), scale, _stream())
+    _lib.check(rc, "supir_softmax_rows")
+    _rec("softmax", 0, 6.0 * rows * T)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- norms
+def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=None, control_scale=1.0, x2raw=None,
+              out=None):
+    """GroupNorm(32) over channels-last x (optionally the channel concat [x | x2]); see supir_groupnorm_nhwc."""
+    lib = _lib.load()
+    _check_dev(x, gamma, beta)
+    B = x.shape[0]
+    HW = int(math.prod(x.shape[1:-1]))
+    _, C1, ld1 = _rows_ld(x)
+    C, ld2 = C1, 0
+    if x2 is not None:
+        _, C2, ld2 = _rows_ld(x2)
+        assert x2.shape[:-1] == x.shape[:-1]
+        C = C1 + C2
+    assert gamma.numel() == C and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    if out is None:
+        out = torch.empty(*x.shape[:-1], C, dtype=BF16, device=x.device)
+    _, Co, ldo = _rows_ld(out)
+    assert Co == C
+    ldm = 0
+    if mod_g is not None:
+        _, Cm, ldm = _rows_ld(mod_g)
+        _, Cm2, ldm2 = _rows_ld(mod_b)
+        assert Cm == C and Cm2 == C and ldm == ldm2
+    ws = _gn_workspace(B, x.device)
+    rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
+                                  beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
+                                  out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _stream())
+    _lib.check(rc, "supir_groupnorm_nhwc")
+    n = B * HW * C
+    _rec("groupnorm", 0, 2.0 * n * (3 + (2 if mod_g is not None else 0)), B=B, HW=HW, C=C)
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    lib = _lib.load()
+    _check_dev(x, gamma, beta)
+    rows, C, ldx = _rows_ld(x)
+    if out is None:
+        out = torch.empty(*x.shape, dtype=BF16, device=x.device)
+    _, _, ldy = _rows_ld(out)
+    rc = lib.supir_layernorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, ldx, ldy, eps,
+                             _stream())
+    _lib.check(rc, "supir_layernorm")
+    _rec("layernorm", 0, 4.0 * rows * C, rows=rows, C=C)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- boundary convs
+def conv3x3_smallcin(x_nchw, w, bias, add=None, out=None):
+    """fp32 NCHW [B,Cin<=8,H,W] -> bf16 [B,H,W,Cout]; w fp32 [Cout,Cin,3,3]."""
+    lib = _lib.load()
+    _check_dev(x_nchw, w)
+    x_nchw = x_nchw.contiguous()
+    assert x_nchw.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous()
+    B, Cin, H, W = x_nchw.shape
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty(B, H, W, Cout, dtype=BF16, device=x_nchw.device)
+    _, _, ldo = _rows_ld(out)
+    ld_add = 0
+    if add is not None:
+        _, _, ld_add = _rows_ld(add)
+    rc = lib.supir_conv3x3_smallcin(x_nchw.data_ptr(), w.data_ptr(), _p(bias), _p(add), out.data_ptr(), B, Cin, H, W, Cout,
+                                    ld_add, ldo, _stream())
+    _lib.check(rc, "supir_conv3x3_smallcin")
+    _rec("conv_smallcin", 2.0 * B * H * W * Cout * 9 * Cin, B * H * W * (4.0 * Cin + 2.0 * Cout))
+    return out
+
+
+def conv3x3_smallcout(x, w9, bias, out=None):
+    """bf16 [B,H,W,Cin] -> fp32 NCHW [B,Cout,H,W]; w9 bf16 [9,Cout,Cin]."""
+    lib = _lib.load()
+    _check_dev(x, w9)
+    B, H, W, Cin = x.shape
+    _, _, ldx = _rows_ld(x)
+    Cout = w9.shape[1]
+    assert w9.shape == (9, Cout, Cin) and w9.dtype == BF16 and w9.is_contiguous()
+    if out is None:
+        out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    rc = lib.supir_conv3x3_smallcout(x.data_ptr(), w9.data_ptr(), _p(bias), out.data_ptr(), B, Cin, H, W, Cout, ldx,
+                                     _stream())
+    _lib.check(rc, "supir_conv3x3_smallcout")
+    _rec("conv_smallcout", 2.0 * B * H * W * Cout * 9 * Cin, B * H * W * (2.0 * Cin + 4.0 * Cout))
+    return out
+
+
+def pointwise_nchw(x, w, bias, in_scale=1.0):
+    lib = _lib.load()
+    _check_dev(x, w)
+    x = x.contiguous()
+    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    w2 = w.reshape(Cout, Cin).contiguous()
+    out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    rc = lib.supir_pointwise_nchw(x.data_ptr(), w2.data_ptr(), _p(bias), out.data_ptr(), B, Cin, Cout, H * W, in_scale,
+                                  _stream())
+    _lib.check(rc, "supir_pointwise_nchw")
+    return out

@@ -1,0 +1,43 @@
+"""One-time conversion of reference-layout fp32 parameters into the kernel layouts (bf16, K-contiguous).
+
+The state-dict keys/shapes stay exactly the reference's (drop-in `load_state_dict`); these helpers build the derived
+device buffers the kernels read, once, instead of autocast re-casting 3.9 G parameters on every step
+(reference: sgm/modules/diffusionmodules/wrappers.py:87).
+"""
+import torch
+
+BF16 = torch.bfloat16
+
+
+def linear_w(w):
+    """nn.Linear / 1x1 conv weight [N, K(,1,1)] -> bf16 [N, K]."""
+    return w.detach().reshape(w.shape[0], -1).to(BF16).contiguous()
+
+
+def conv3x3_w(w):
+    """nn.Conv2d weight [Cout, Cin, 3, 3] -> bf16 [Cout, 3, 3, Cin] (K = (ky, kx, cin), cin fastest)."""
+    return w.detach().permute(0, 2, 3, 1).to(BF16).contiguous()
+
+
+def conv3x3_w9(w):
+    """nn.Conv2d weight [Cout<=8, Cin, 3, 3] -> bf16 [9, Cout, Cin] for supir_conv3x3_smallcout."""
+    co, ci = w.shape[:2]
+    return w.detach().permute(2, 3, 0, 1).reshape(9, co, ci).to(BF16).contiguous()
+
+
+def f32(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+def interleave_geglu(w, b):
+    """GEGLU.proj weight [2N, K] (first half value, second half gate; sgm/modules/attention.py:89-91) ->
+    rows interleaved in blocks of 32 value rows + 32 gate rows so that one wave's fragment pair holds value and gate
+    of the same 32 output columns (supir_gemm_bf16 act=GEGLU)."""
+    n2, k = w.shape
+    n = n2 // 2
+    assert n % 32 == 0 and n2 % 128 == 0
+    wi = torch.stack([w[:n].reshape(n // 32, 32, k), w[n:].reshape(n // 32, 32, k)], dim=1).reshape(n2, k).contiguous()
+    bi = None
+    if b is not None:
+        bi = torch.stack([b[:n].reshape(n // 32, 32), b[n:].reshape(n // 32, 32)], dim=1).reshape(n2).contiguous()
+    return wi, bi

@@ -1,0 +1,293 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch fp32 reference of the same op, on the GPU.
+
+Inputs are rounded to bf16 first so both sides see identical operands; the tolerance then only has to absorb
+fp32-accumulation order and the final bf16 rounding of the output (rel 2^-8 per element).
+Tolerances (stated): GEMM / conv / attention rel-L2 <= 4e-3, GroupNorm / LayerNorm <= 4e-3
+(bf16 output rounding dominates), max-abs <= 2^-7 * max|ref| + small.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from supir_amd import ops  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def check(out, ref, rel=4e-3, name=""):
+    out = out.float()
+    ref = ref.float()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{name}: non-finite output"
+    err = (out - ref).norm() / (ref.norm() + 1e-12)
+    mx = (out - ref).abs().max().item()
+    bound = 2.0 ** -7 * ref.abs().max().item() + 1e-3
+    assert err.item() <= rel, f"{name}: rel-L2 {err.item():.3e} > {rel} (max-abs {mx:.3e})"
+    assert mx <= bound * 1.5, f"{name}: max-abs {mx:.3e} > {bound * 1.5:.3e}"
+
+
+GEMM_SHAPES = [
+    # (M, N, K) -- production shapes of one CFG-doubled 1024^2 step plus ragged / tiny cases
+    (2048, 1280, 1280), (2048, 10240, 1280), (2048, 1280, 5120), (154, 1280, 2048), (8192, 640, 640),
+    (8192, 5120, 640), (8192, 640, 2560), (32768, 320, 320), (2, 1280, 320), (2, 1280, 2816), (32, 320, 320),
+    (77, 640, 2048), (200, 64, 64), (130, 132, 128),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
+def test_gemm_plain(M, N, K, tile):
+    if tile >= 0 and M * N > 2048 * 1280:
+        pytest.skip("forced tiles only on small/medium shapes")
+    a = rnd(M, K).to(BF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N, seed=2)
+    out = ops.gemm(a, w, bias, tile=tile)
+    ref = a.float() @ w.float().T + bias
+    check(out, ref, name=f"gemm{(M, N, K)} tile{tile}")
+
+
+def test_gemm_epilogues():
+    B, T, N, K = 2, 96, 640, 320
+    M = B * T
+    a = rnd(M, K).to(BF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N, seed=2)
+    res = rnd(M, N, seed=3).to(BF)
+    rb = rnd(B, N, seed=4).to(BF)
+    base = a.float() @ w.float().T + bias
+    # residual + alpha
+    out = ops.gemm(a, w, bias, residual=res, alpha=0.5)
+    check(out, 0.5 * base + res.float(), name="res+alpha")
+    # rowbias (time-embedding style) + silu
+    out = ops.gemm(a, w, bias, rowbias=rb, rows_per_batch=T, act=1)
+    check(out, F.silu(base + rb.float().repeat_interleave(T, 0)), name="rowbias+silu")
+    # fp32 output
+    out = ops.gemm(a, w, None, out_dtype=torch.float32)
+    check(out, a.float() @ w.float().T, rel=1e-4, name="fp32out")
+    # strided A (column slice of a wider buffer) and strided C
+    wide = rnd(M, K + 64).to(BF)
+    cbuf = torch.zeros(M, N + 128, dtype=BF, device=DEV)
+    ops.gemm(wide[:, 64:], w, bias, out=cbuf[:, 128:])
+    check(cbuf[:, 128:], wide[:, 64:].float() @ w.float().T + bias, name="strided")
+    assert cbuf[:, :128].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("M,K,N2", [(2048, 1280, 10240), (8192, 640, 5120), (96, 320, 2560)])
+def test_gemm_geglu(M, K, N2):
+    """GEGLU epilogue (reference: sgm/modules/attention.py:89-91: first half value, second half gate, erf GELU)."""
+    from supir_amd.weights import interleave_geglu
+    a = rnd(M, K).to(BF)
+    w = rnd(N2, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N2, seed=2)
+    wi, bi = interleave_geglu(w, bias)
+    out = ops.gemm(a, wi, bi, act=2)
+    y = a.float() @ w.float().T + bias
+    v, g = y.chunk(2, dim=-1)
+    check(out, v * F.gelu(g), name="geglu")
+
+
+@pytest.mark.parametrize("B,T,N,K", [(2, 1024, 1280, 1280), (2, 77, 640, 2048), (2, 16, 640, 640), (1, 4096, 640, 640)])
+def test_gemm_transposed(B, T, N, K):
+    a = rnd(B * T, K).to(BF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
+    Tp = (T + 63) // 64 * 64
+    out = ops.gemm_t(a, w, None, B, T, Tp)
+    ref = (a.float() @ w.float().T).view(B, T, N).permute(0, 2, 1)
+    check(out[:, :, :T], ref, name="gemm_t")
+    if Tp != T:
+        assert out[:, :, T:].abs().max().item() == 0.0
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, stride, pad(top,left), upsample, out_hw
+    (2, 32, 32, 1280, 1280, 1, (1, 1), False, None),
+    (2, 64, 64, 640, 640, 1, (1, 1), False, None),
+    (2, 128, 128, 320, 320, 1, (1, 1), False, None),
+    (2, 32, 32, 1920, 1280, 1, (1, 1), False, None),
+    (2, 64, 64, 320, 320, 2, (1, 1), False, None),          # UNet Downsample (openaimodel.py:196)
+    (1, 64, 64, 128, 128, 2, (0, 0), False, (32, 32)),      # VAE Downsample, F.pad(0,1,0,1) (model.py:81-86)
+    (2, 16, 16, 640, 640, 1, (1, 1), True, None),           # Upsample nearest 2x folded (openaimodel.py:145)
+    (1, 24, 40, 256, 128, 1, (1, 1), False, None),          # non-square, VAE-like
+    (2, 8, 8, 320, 128, 1, (1, 1), False, None),            # ZeroSFT mlp_shared
+    (1, 5, 7, 64, 64, 1, (1, 1), False, None),              # ragged tiny
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3(case):
+    B, H, W, Cin, Cout, stride, pad, up, out_hw = case
+    x = rnd(B, H, W, Cin).to(BF)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
+    bias = rnd(Cout, seed=2)
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw)
+    xr = x.float().permute(0, 3, 1, 2)
+    if up:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    if pad == (0, 0):
+        xr = F.pad(xr, (0, 1, 0, 1))
+        ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=0)
+    else:
+        ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=1)
+    check(out, ref.permute(0, 2, 3, 1), name=f"conv{case}")
+
+
+def test_conv3x3_epilogue():
+    """ResBlock fusion: conv + bias + emb broadcast add (openaimodel.py:338-355) and + skip (:356)."""
+    B, H, W, Cin, Cout = 2, 16, 16, 320, 640
+    x = rnd(B, H, W, Cin).to(BF)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
+    bias = rnd(Cout, seed=2)
+    emb = rnd(B, Cout, seed=3).to(BF)
+    res = rnd(B, H, W, Cout, seed=4).to(BF)
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    out = ops.conv3x3(x, wk, bias, rowbias=emb)
+    check(out, ref + emb.float()[:, None, None, :], name="conv+emb")
+    out = ops.conv3x3(x, wk, bias, residual=res)
+    check(out, ref + res.float(), name="conv+res")
+    out = ops.conv3x3(x, wk, bias, act=1)
+    check(out, F.silu(ref), name="conv+silu")
+
+
+ATTN_CASES = [(2, 20, 1024, 1024), (2, 10, 4096, 4096), (2, 20, 1024, 77), (2, 10, 4096, 77), (1, 5, 64, 64),
+              (2, 10, 16, 16), (1, 3, 200, 130), (2, 20, 1024, 4096)]
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk", ATTN_CASES)
+def test_flash_attn(B, H, Tq, Tk):
+    C = H * 64
+    q = rnd(B, Tq, C).to(BF)
+    k = rnd(B, Tk, C, seed=1).to(BF)
+    v = rnd(B, Tk, C, seed=2).to(BF)
+    Tp = (Tk + 63) // 64 * 64
+    vt = torch.zeros(B, C, Tp, dtype=BF, device=DEV)
+    vt[:, :, :Tk] = v.permute(0, 2, 1)
+    out = ops.flash_attn(q, k, vt, B, H, Tq, Tk)
+    qf, kf, vf = (t.float().view(B, -1, H, 64).permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qf, kf, vf).permute(0, 2, 1, 3).reshape(B, Tq, C)
+    check(out, ref, rel=6e-3, name=f"attn{(B, H, Tq, Tk)}")
+
+
+def test_flash_attn_strided_qk_and_spike():
+    """q,k as column slices of a fused [M, 2C] projection; a spiked key forces the online-softmax rescale branch."""
+    B, H, T = 2, 10, 512
+    C = H * 64
+    qk = rnd(B, T, 2 * C).to(BF)
+    qk[:, 300, C:] *= 12.0  # one huge key in the 5th KV tile
+    v = rnd(B, T, C, seed=2).to(BF)
+    vt = v.permute(0, 2, 1).contiguous()
+    out = ops.flash_attn(qk[:, :, :C], qk[:, :, C:], vt, B, H, T, T)
+    qf, kf, vf = (t.float().reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in (qk[:, :, :C], qk[:, :, C:], v))
+    ref = F.scaled_dot_product_attention(qf, kf, vf).permute(0, 2, 1, 3).reshape(B, T, C)
+    check(out, ref, rel=6e-3, name="attn-spike")
+
+
+@pytest.mark.parametrize("rows,T", [(64, 16384), (100, 1024), (7, 260)])
+def test_softmax_rows(rows, T):
+    s = rnd(rows, T, scale=3.0)
+    out = ops.softmax_rows(s, 512 ** -0.5)
+    check(out, torch.softmax(s * 512 ** -0.5, dim=-1), name="softmax")
+
+
+GN_CASES = [(2, 128 * 128, 320), (2, 64 * 64, 640), (2, 32 * 32, 1280), (2, 32 * 32, 2560), (2, 64 * 64, 960),
+            (2, 32 * 32, 1920), (1, 256 * 256, 128), (1, 50, 256), (2, 16, 512), (2, 9, 64)]
+
+
+@pytest.mark.parametrize("B,HW,C", GN_CASES)
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(B, HW, C, silu):
+    x = (rnd(B, HW, C) * 1.5 + 0.7).to(BF)
+    gamma = rnd(C, seed=1) * 0.2 + 1.0
+    beta = rnd(C, seed=2) * 0.2
+    out = ops.groupnorm(x, gamma, beta, 1e-5, silu=silu)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    check(out, ref.permute(0, 2, 1), name=f"gn{(B, HW, C, silu)}")
+
+
+def test_groupnorm_concat_and_sft():
+    """ZeroSFT tail (SUPIR/modules/SUPIR_v0.py:102-113): GN over cat[h_ori, h], *(gamma+1)+beta, control_scale lerp."""
+    B, HW, Cd, Cs = 2, 16 * 16, 640, 320
+    C = Cd + Cs
+    h_ori = rnd(B, HW, Cd).to(BF)
+    h = rnd(B, HW, Cs, seed=1).to(BF)
+    h_raw = rnd(B, HW, Cs, seed=5).to(BF)
+    gm = (rnd(B, HW, C, seed=2) * 0.3).to(BF)
+    bt = (rnd(B, HW, C, seed=3) * 0.3).to(BF)
+    gamma = rnd(C, seed=1) * 0.2 + 1.0
+    beta = rnd(C, seed=2) * 0.2
+    cat = torch.cat([h_ori, h], -1).float()
+    gn = F.group_norm(cat.permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+    out = ops.groupnorm(h_ori, gamma, beta, 1e-5, x2=h)
+    check(out, gn, name="gn-cat")
+    out = ops.groupnorm(h_ori, gamma, beta, 1e-5, x2=h, mod_g=gm, mod_b=bt)
+    ref = gn * (gm.float() + 1) + bt.float()
+    check(out, ref, name="sft")
+    cs = 0.6
+    out = ops.groupnorm(h_ori, gamma, beta, 1e-5, x2=h, mod_g=gm, mod_b=bt, control_scale=cs, x2raw=h_raw)
+    raw = torch.cat([h_ori, h_raw], -1).float()
+    check(out, ref * cs + raw * (1 - cs), name="sft-lerp")
+
+
+@pytest.mark.parametrize("rows,C", [(2048, 1280), (8192, 640), (77, 320), (5, 2048), (3, 64)])
+def test_layernorm(rows, C):
+    x = (rnd(rows, C) * 2 + 0.3).to(BF)
+    gamma = rnd(C, seed=1) * 0.2 + 1.0
+    beta = rnd(C, seed=2) * 0.2
+    out = ops.layernorm(x, gamma, beta, 1e-5)
+    check(out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), name="ln")
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 4, 32, 32, 320), (1, 3, 40, 24, 128), (1, 4, 16, 16, 512)])
+def test_conv_smallcin(B, Cin, H, W, Cout):
+    x = rnd(B, Cin, H, W)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1)
+    bias = rnd(Cout, seed=2)
+    add = rnd(B, H, W, Cout, seed=3).to(BF)
+    out = ops.conv3x3_smallcin(x, w, bias)
+    ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1)
+    check(out, ref, name="smallcin")
+    out = ops.conv3x3_smallcin(x, w, bias, add=add)
+    check(out, ref + add.float(), name="smallcin+add")
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 320, 32, 32, 4), (1, 512, 16, 24, 8), (1, 128, 64, 64, 3)])
+def test_conv_smallcout(B, Cin, H, W, Cout):
+    x = rnd(B, H, W, Cin).to(BF)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
+    bias = rnd(Cout, seed=2)
+    w9 = w.permute(2, 3, 0, 1).reshape(9, Cout, Cin).contiguous()
+    out = ops.conv3x3_smallcout(x, w9, bias)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1)
+    check(out, ref, rel=1e-4, name="smallcout")
+
+
+def test_pointwise():
+    x = rnd(2, 8, 16, 16)
+    w = rnd(8, 8, 1, 1, seed=1)
+    b = rnd(8, seed=2)
+    out = ops.pointwise_nchw(x, w, b, in_scale=1.0 / 0.13025)
+    check(out, F.conv2d(x / 0.13025, w, b), rel=1e-5, name="pointwise")
+
+
+def test_errors_are_loud():
+    from supir_amd._lib import SupirHipError
+    a = rnd(64, 100).to(BF)  # K % 64 != 0
+    w = rnd(64, 100).to(BF)
+    with pytest.raises((SupirHipError, AssertionError)):
+        ops.gemm(a, w)
+    with pytest.raises(SupirHipError):
+        ops.gemm(a.cpu(), w.cpu())
