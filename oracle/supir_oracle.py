@@ -319,12 +319,13 @@ def gaussian_weights(tile_width, tile_height):
     """gaussian_weights (sampling.py:733-750): float64, var 0.01, x midpoint (w-1)/2, y midpoint h/2 (asymmetric on
     purpose: reproduces the reference). Returns [1, 4, h, w] float64."""
     import numpy as np
+    from numpy import exp, pi, sqrt
     var = 0.01
     mid = (tile_width - 1) / 2
-    xp = [math.exp(-(x - mid) * (x - mid) / (tile_width * tile_width) / (2 * var)) / math.sqrt(2 * math.pi * var)
+    xp = [exp(-(x - mid) * (x - mid) / (tile_width * tile_width) / (2 * var)) / sqrt(2 * pi * var)
           for x in range(tile_width)]
     mid = tile_height / 2
-    yp = [math.exp(-(y - mid) * (y - mid) / (tile_height * tile_height) / (2 * var)) / math.sqrt(2 * math.pi * var)
+    yp = [exp(-(y - mid) * (y - mid) / (tile_height * tile_height) / (2 * var)) / sqrt(2 * pi * var)
           for y in range(tile_height)]
     return torch.tile(torch.tensor(np.outer(yp, xp)), (1, 4, 1, 1))
 

@@ -1,0 +1,158 @@
+"""The oracle (oracle/supir_oracle.py, plain fp32 PyTorch restatement) against the golden vectors produced by the REAL
+reference (oracle/gen_golden.py).  CPU only.  Tolerance: fp32 re-association only -> rel-L2 <= 2e-5."""
+import pytest
+import torch
+
+from oracle import supir_oracle as O
+from tests.helpers import golden, manifest, rel_l2, synth_sd, synth_tensor
+
+TOL = 2e-5
+B = 2
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth_sd(manifest("mini"))
+
+
+@pytest.fixture(scope="module")
+def g():
+    return golden()
+
+
+def test_schedules(g):
+    assert torch.equal(O.denoiser_table(), g["denoiser_table"])
+    for n in (50, 2, 8):
+        ours = torch.cat([O.ddpm_sigmas(n), torch.zeros(1)])
+        assert torch.equal(ours, g[f"sigmas_{n}"]), n
+    assert abs(g["sigmas_50"][0].item() - 14.6146) < 1e-3
+    assert torch.equal(O.gaussian_weights(16, 16), g["gaussian_weights_16"])
+    assert O.sliding_windows(24, 40, 16, 8) == g["sliding_windows_24_40_16_8"]
+
+
+def _ctx():
+    return synth_tensor("emb", (B, 1280)), synth_tensor("context", (B, 77, 2048))
+
+
+def test_modules(sd, g):
+    emb, ctx = _ctx()
+    m = g["modules"]
+    D = "model.diffusion_model."
+    x320 = synth_tensor("x320", (B, 320, 8, 8))
+    x640 = synth_tensor("x640", (B, 640, 8, 8))
+    x1280 = synth_tensor("x1280", (B, 1280, 4, 4))
+    hori1280 = synth_tensor("hori1280", (B, 1280, 4, 4))
+    c1280 = synth_tensor("c1280", (B, 1280, 4, 4))
+    c640 = synth_tensor("c640", (B, 640, 4, 4))
+    c320 = synth_tensor("c320", (B, 320, 8, 8))
+    cases = {
+        "res.input_blocks.1.0": lambda: O.res_block(sd, D + "input_blocks.1.0", x320, emb),
+        "res.input_blocks.4.0": lambda: O.res_block(sd, D + "input_blocks.4.0", x320, emb),
+        "res.output_blocks.0.0": lambda: O.res_block(sd, D + "output_blocks.0.0", synth_tensor("x2560", (B, 2560, 4, 4)), emb),
+        "down.input_blocks.3.0": lambda: O.timestep_embed_sequential(sd, D + "input_blocks.3", x320, emb, ctx),
+        "up.output_blocks.2.2": lambda: O._conv(sd, D + "output_blocks.2.2.conv",
+                                                torch.nn.functional.interpolate(x1280, scale_factor=2, mode="nearest")),
+        "st.input_blocks.4.1": lambda: O.spatial_transformer(sd, D + "input_blocks.4.1", x640, ctx),
+        "st.middle_block.1": lambda: O.spatial_transformer(sd, D + "middle_block.1", x1280, ctx),
+        "btb.input_blocks.7.1.0": lambda: O.basic_transformer_block(
+            sd, D + "input_blocks.7.1.transformer_blocks.0", synth_tensor("tok1280", (B, 16, 1280)), ctx, 20),
+        "sft.11": lambda: O.zero_sft(sd, D + "project_modules.11", c1280, x1280),
+        "sft.10": lambda: O.zero_sft(sd, D + "project_modules.10", c1280, x1280, hori1280),
+        "sft.10.cs0.7": lambda: O.zero_sft(sd, D + "project_modules.10", c1280, x1280, hori1280, control_scale=0.7),
+        "sft.0": lambda: O.zero_sft(sd, D + "project_modules.0", c320, x320, synth_tensor("hori320", (B, 320, 8, 8))),
+        "xattn.7": lambda: O.zero_cross_attn(sd, D + "project_modules.7", c640, x1280),
+        "xattn.3": lambda: O.zero_cross_attn(sd, D + "project_modules.3", c320, x640),
+    }
+    assert set(cases) == set(m)
+    with torch.no_grad():
+        for name, fn in cases.items():
+            e = rel_l2(fn(), m[name])
+            assert e <= TOL, (name, e)
+
+
+def _wrapper_inputs():
+    x = synth_tensor("xt", (B, 4, 16, 16))
+    lq = synth_tensor("lq", (B, 4, 16, 16))
+    y = synth_tensor("vector", (B, 2816))
+    ctx = synth_tensor("context", (B, 77, 2048))
+    t = torch.tensor([500, 37], dtype=torch.int64)
+    return x, t, {"crossattn": ctx, "vector": y, "control": lq}
+
+
+def test_control_and_wrapper(sd, g):
+    x, t, cond = _wrapper_inputs()
+    with torch.no_grad():
+        hs = O.glv_control(sd, cond["control"], t, x, cond["crossattn"], cond["vector"], p="model.control_model.")
+        assert len(hs) == 10
+        for h, d in zip(hs, g["control_digest"]):
+            assert list(h.shape) == d["shape"]
+            assert rel_l2(h.flatten()[:32], d["head"]) <= TOL and rel_l2(h.flatten()[-32:], d["tail"]) <= TOL
+            assert abs(h.std().item() - d["std"]) <= 1e-4 * d["std"]
+        assert rel_l2(O.control_wrapper(sd, x, t, cond, 1.0), g["wrapper_eps"]) <= TOL
+        assert rel_l2(O.control_wrapper(sd, x, t, cond, 0.5), g["wrapper_eps_cs0.5"]) <= TOL
+
+
+def _sampler_io(N=1):
+    _, _, cond = _wrapper_inputs()
+    ctx, y, lq = cond["crossattn"], cond["vector"], cond["control"]
+    c = {"crossattn": ctx[:1], "vector": y[:1], "control": lq[:1]}
+    uc = {"crossattn": ctx[1:], "vector": y[1:], "control": lq[:1]}
+    return c, uc, synth_tensor("x_center", (N, 4, 16, 16)), synth_tensor("noised_z", (N, 4, 16, 16))
+
+
+def _fake_net(xin, tt, cc, cs):
+    return torch.tanh(xin * 0.7 + cc["control"] * 0.1) * (1.0 + 0.001 * tt.view(-1, 1, 1, 1).float()) * cs
+
+
+@pytest.mark.parametrize("name,steps,rcfg", [("fake_50_r-1", 50, -1.0), ("fake_50_r4", 50, 4.0), ("fake_8_r2", 8, 2.0)])
+def test_sampler_numerics(g, name, steps, rcfg):
+    c, uc, xc, x0 = _sampler_io()
+    table = O.denoiser_table()
+    noises = [synth_tensor(f"{name}.eps{i}", (1, 4, 16, 16)) for i in range(steps)]
+    den = lambda xin, s, cc, cs: O.discrete_denoiser_with_control(_fake_net, table, xin, s, cc, cs)
+    out = O.restore_edm_sample(den, x0.clone(), c, uc, xc, noises, num_steps=steps, s_churn=5, s_noise=1.01,
+                               restore_cfg=rcfg, scale=1.0, scale_min=4.0, control_scale=0.9)
+    assert rel_l2(out, g["sampler_" + name]) <= 5e-5
+
+
+def test_tiled_sampler(g):
+    c, uc, _, _ = _sampler_io()
+    big = (1, 4, 24, 40)
+    lqb = synth_tensor("lq_big", big)
+    c, uc = dict(c, control=lqb), dict(uc, control=lqb)
+    table = O.denoiser_table()
+    noises = [synth_tensor(f"tiled.eps{i}", big) for i in range(3)]
+    den = lambda xin, s, cc, cs: O.discrete_denoiser_with_control(_fake_net, table, xin, s, cc, cs)
+    out = O.tiled_restore_edm_sample(den, synth_tensor("noised_big", big), c, uc, synth_tensor("xc_big", big), noises,
+                                     tile_size=16, tile_stride=8, num_steps=3, s_churn=5, s_noise=1.01, restore_cfg=4.0)
+    assert rel_l2(out, g["sampler_tiled_fake"]) <= 5e-5
+
+
+def test_sampler_with_network(sd, g):
+    c, uc, xc, x0 = _sampler_io()
+    table = O.denoiser_table()
+    noises = [synth_tensor(f"eps{i}", (1, 4, 16, 16)) for i in range(2)]
+    net = lambda xin, t, cc, cs: O.control_wrapper(sd, xin, t, cc, cs)
+    den = lambda xin, s, cc, cs: O.discrete_denoiser_with_control(net, table, xin, s, cc, cs)
+    with torch.no_grad():
+        out = O.restore_edm_sample(den, x0.clone(), c, uc, xc, noises, num_steps=2, s_churn=5, s_noise=1.01, restore_cfg=4.0,
+                                   scale=1.0, scale_min=4.0, control_scale=1.0)
+    assert rel_l2(out, g["sampler_2step"]) <= 5e-5
+
+
+def test_vae(sd, g):
+    img = synth_tensor("img", (1, 3, 64, 64), scale=0.5)
+    with torch.no_grad():
+        mom = O.vae_moments(sd, img, encoder="denoise_encoder")
+        assert rel_l2(mom, g["vae_denoise_moments"]) <= TOL
+        z = O.encode_first_stage_with_denoise(sd, img)
+        assert rel_l2(z, g["vae_z"]) <= TOL
+        xs1 = O.vae_decode(sd, g["vae_z"] / 0.13025)
+        assert rel_l2(xs1, g["vae_x_stage1"]) <= TOL
+        zs1 = O.encode_first_stage(sd, g["vae_x_stage1"], synth_tensor("posterior_noise", (1, 4, 8, 8)))
+        assert rel_l2(zs1, g["vae_z_stage1"]) <= TOL
+
+
+def test_wavelet(g):
+    out = O.wavelet_reconstruction(synth_tensor("wa", (1, 3, 64, 64)), synth_tensor("wb", (1, 3, 64, 64)))
+    assert rel_l2(out, g["wavelet"]) <= 1e-6
