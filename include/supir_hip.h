@@ -80,12 +80,13 @@ int supir_softmax_rows(const float* S, void* P, int rows, int T, long ld_s, long
 
 /* GroupNorm(32 groups) over NHWC bf16 with fp32 statistics, optional SiLU, optional channel concat of two sources
  * (channels [0,C1) from x1, [C1,C) from x2), optional ZeroSFT modulation out = GN(x)*(mod_g+1)+mod_b and
- * control_scale lerp against the raw concat (x2raw = skip before zero_conv; may be NULL when cscale == 1).
+ * control_scale lerp against the raw concat (x1raw / x2raw = the tensors before zero_conv; NULL -> x1 / x2 themselves;
+ * with the same leading dimensions ld1 / ld2).
  * workspace: B*1024*64 floats.
  * Replaces GroupNorm32 (sgm/modules/diffusionmodules/util.py:258-276), Normalize (attention.py:122-125,
  * model.py:48-51), nonlinearity/SiLU (model.py:44-46, openaimodel.py:261,296) and ZeroSFT.forward's tail
  * (SUPIR/modules/SUPIR_v0.py:110-113). */
-int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x2raw, int B, int HW, int C, int C1, int ld1,
+int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, const void* x2raw, int B, int HW, int C, int C1, int ld1,
                          int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
                          const void* mod_b, int ldm, float control_scale, void* out, int ldo, float* workspace,
                          size_t workspace_bytes, void* stream);

@@ -60,7 +60,7 @@ int supir_softmax_rows(const float* S, void* P, int rows, int T, long ld_s, long
     return supir_softmax_rows_launch(S, (bf16_t*)P, rows, T, ld_s, ld_p, scale, (hipStream_t)stream);
 }
 
-int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x2raw, int B, int HW, int C, int C1, int ld1,
+int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, const void* x2raw, int B, int HW, int C, int C1, int ld1,
                          int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
                          const void* mod_b, int ldm, float control_scale, void* out, int ldo, float* workspace,
                          size_t workspace_bytes, void* stream) {
@@ -68,7 +68,7 @@ int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x2raw, int 
     if (C1 <= 0 || C1 > C) return SUPIR_ERR_ARG;
     if (workspace_bytes < (size_t)B * 1024 * 64 * sizeof(float)) return SUPIR_ERR_ARG;
     GnArgs a{};
-    a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.x2raw = (const bf16_t*)x2raw;
+    a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.x1raw = (const bf16_t*)x1raw; a.x2raw = (const bf16_t*)x2raw;
     a.partial = workspace; a.gamma = gamma; a.beta = beta;
     a.mod_g = (const bf16_t*)mod_g; a.mod_b = (const bf16_t*)mod_b; a.out = (bf16_t*)out;
     a.B = B; a.HW = HW; a.C = C; a.C1 = C1; a.ld1 = ld1; a.ld2 = ld2; a.ldm = ldm; a.ldo = ldo;

@@ -31,7 +31,8 @@ struct AttnArgs {
 struct GnArgs {
     const bf16_t* x1;   // [B][HW][ld1], channels [0,C1)
     const bf16_t* x2;   // [B][HW][ld2], channels [C1,C)  (null when C1 == C)  -- the ZeroSFT / skip concat
-    const bf16_t* x2raw;  // ZeroSFT lerp only: un-projected skip (h before + zero_conv(c)); may be null
+    const bf16_t* x1raw;  // ZeroSFT lerp only: raw counterpart of x1 (null -> x1 itself)
+    const bf16_t* x2raw;  // ZeroSFT lerp only: un-projected skip (h before + zero_conv(c)); null -> x2 itself
     float* partial;     // [B][nchunk][32][2]  (sum, sumsq)
     const float* gamma; // [C]
     const float* beta;  // [C]

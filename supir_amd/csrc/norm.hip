@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchun
             for (int e = 0; e < 8; ++e) y[e] = y[e] * (bf2f(gv[e]) + 1.0f) + bf2f(bv[e]);
             if (lerp) {
                 u16x8 rv = xv;  // h_raw = cat[h_ori, h] (h BEFORE the zero_conv projection)
-                if (c >= p.C1 && p.x2raw) rv = *(const u16x8*)(p.x2raw + ((size_t)b * p.HW + row) * p.ld2 + (c - p.C1));
+                if (c < p.C1) {
+                    if (p.x1raw) rv = *(const u16x8*)(p.x1raw + ((size_t)b * p.HW + row) * p.ld1 + c);
+                } else if (p.x2raw) {
+                    rv = *(const u16x8*)(p.x2raw + ((size_t)b * p.HW + row) * p.ld2 + (c - p.C1));
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = y[e] * p.cscale + bf2f(rv[e]) * (1.0f - p.cscale);
             }

@@ -1,0 +1,168 @@
+"""SpatialTransformer stack on the HIP kernels; same constructor kwargs / state-dict keys / call signatures as
+sgm/modules/attention.py (CrossAttention :196-285, MemoryEfficientCrossAttention :288-373, GEGLU/FeedForward :84-110,
+BasicTransformerBlock :376-486, SpatialTransformer :533-635).
+
+Per transformer block: 3 LayerNorm launches, 8 GEMM launches (fused q|k projection, transposed v projection, GEGLU
+epilogue, residual epilogues) and 2 flash-attention launches; the token stream stays bf16 [B*T, C] throughout.
+K / V^T of the text context are computed once per context tensor and reused across all sampling steps.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .. import weights as Wt
+from .base import BF16, Linear, Norm, Normalize, Passthrough, Prep, to_nchw, to_nhwc, tokens_bf16
+
+
+def _pad64(t):
+    return (t + 63) // 64 * 64
+
+
+class CrossAttention(nn.Module):
+    """q = to_q(x), k/v = to_k/to_v(context or x), softmax(q k^T / sqrt(64)) v, to_out.0 (+bias).
+    Head split 'b n (h d) -> b h n d' (attention.py:254) is the column layout the flash kernel reads directly."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0, backend=None, **kwargs):
+        super().__init__()
+        if dim_head != 64:
+            raise ValueError("the gfx950 flash-attention kernel is built for head dim 64 (SDXL / SUPIR)")
+        inner = dim_head * heads
+        self.is_self = context_dim is None
+        context_dim = query_dim if context_dim is None else context_dim
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.to_q = Linear(query_dim, inner, bias=False)
+        self.to_k = Linear(context_dim, inner, bias=False)
+        self.to_v = Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(Linear(inner, query_dim), Passthrough())
+        object.__setattr__(self, "_qk", Prep())
+        object.__setattr__(self, "_kv_cache", None)
+
+    def _w_qk(self):
+        return self._qk.get((self.to_q.weight, self.to_k.weight),
+                            lambda: torch.cat([Wt.linear_w(self.to_q.weight), Wt.linear_w(self.to_k.weight)], 0).contiguous())
+
+    def _context_kv(self, context):
+        """K [B,Tk,C] and V^T [B,C,Tpad] of a context tensor, cached on tensor identity + version."""
+        c = self._kv_cache
+        wk, wv = self.to_k.w(), self.to_v.w()
+        if c is not None and c[0] is context and c[1] == context._version and c[2] is wk and c[3] is wv:
+            return c[4], c[5]
+        ctx = tokens_bf16(context)
+        B, Tk, _ = ctx.shape
+        k = ops.gemm(ctx, wk)
+        vt = ops.gemm_t(ctx, wv, None, B, Tk, _pad64(Tk))
+        object.__setattr__(self, "_kv_cache", (context, context._version, wk, wv, k, vt))
+        return k, vt
+
+    def attend(self, x, context=None, residual=None, alpha=1.0, inplace=False):
+        """x [B,T,C] bf16 tokens -> to_out(attention) (* alpha) (+ residual); inplace writes into `residual`."""
+        B, T, C = x.shape
+        H = self.heads
+        inner = H * 64
+        if context is None:
+            qk = ops.gemm(x, self._w_qk())                      # [B,T,2*inner]
+            vt = ops.gemm_t(x, self.to_v.w(), None, B, T, _pad64(T))
+            a = ops.flash_attn(qk[:, :, :inner], qk[:, :, inner:], vt, B, H, T, T)
+        else:
+            q = ops.gemm(x, self.to_q.w())
+            k, vt = self._context_kv(context)
+            a = ops.flash_attn(q, k, vt, B, H, T, k.shape[1])
+        out = residual if (inplace and residual is not None) else None
+        return ops.gemm(a, self.to_out[0].w(), self.to_out[0].b32(), residual=residual, alpha=alpha, out=out)
+
+    def forward(self, x, context=None, mask=None, additional_tokens=None, n_times_crossframe_attn_in_self=0):
+        if mask is not None or additional_tokens is not None or n_times_crossframe_attn_in_self:
+            raise NotImplementedError("mask / additional_tokens / crossframe attention are not on SUPIR's path")
+        return self.attend(tokens_bf16(x), context)
+
+
+MemoryEfficientCrossAttention = CrossAttention  # the xformers variant is the same math (attention.py:313-373)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+        object.__setattr__(self, "_il", Prep())
+
+    def w_interleaved(self):
+        return self._il.get((self.proj.weight, self.proj.bias),
+                            lambda: Wt.interleave_geglu(Wt.linear_w(self.proj.weight), Wt.f32(self.proj.bias)))
+
+    def forward(self, x):
+        w, b = self.w_interleaved()
+        return ops.gemm(tokens_bf16(x), w, b, act=2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.0):
+        super().__init__()
+        if not glu:
+            raise NotImplementedError("SUPIR uses gated_ff=True everywhere")
+        inner = int(dim * mult)
+        self.net = nn.Sequential(GEGLU(dim, inner), Passthrough(), Linear(inner, dim if dim_out is None else dim_out))
+
+    def forward(self, x, residual=None, inplace=False):
+        h = self.net[0](x)
+        return ops.gemm(h, self.net[2].w(), self.net[2].b32(), residual=residual, out=residual if inplace else None)
+
+
+class BasicTransformerBlock(nn.Module):
+    ATTENTION_MODES = {"softmax": CrossAttention, "softmax-xformers": MemoryEfficientCrossAttention}
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False, attn_mode="softmax", sdp_backend=None):
+        super().__init__()
+        assert attn_mode in self.ATTENTION_MODES
+        self.disable_self_attn = disable_self_attn
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head,
+                                    context_dim=context_dim if disable_self_attn else None)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head)
+        self.norm1 = Norm(dim, 1e-5)
+        self.norm2 = Norm(dim, 1e-5)
+        self.norm3 = Norm(dim, 1e-5)
+
+    def forward(self, x, context=None, additional_tokens=None, n_times_crossframe_attn_in_self=0, inplace=False):
+        """x [B,T,C] -> x + attn1(LN x) ... (attention.py:465-486). inplace=True updates the token stream in place
+        (SpatialTransformer owns it)."""
+        x = tokens_bf16(x)
+        n = ops.layernorm(x, self.norm1.g32(), self.norm1.b32(), self.norm1.eps)
+        x = self.attn1.attend(n, context if self.disable_self_attn else None, residual=x, inplace=inplace)
+        n = ops.layernorm(x, self.norm2.g32(), self.norm2.b32(), self.norm2.eps, out=n)
+        x = self.attn2.attend(n, context, residual=x, inplace=True)
+        n = ops.layernorm(x, self.norm3.g32(), self.norm3.b32(), self.norm3.eps, out=n)
+        return self.ff(n, residual=x, inplace=True)
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None, disable_self_attn=False,
+                 use_linear=False, attn_type="softmax", use_checkpoint=True, sdp_backend=None):
+        super().__init__()
+        if isinstance(context_dim, (list, tuple)):
+            context_dim = list(context_dim)
+            assert all(c == context_dim[0] for c in context_dim)
+            context_dim = context_dim[0]
+        self.in_channels = in_channels
+        inner = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        self.use_linear = use_linear
+        self.proj_in = Linear(in_channels, inner, conv1x1=not use_linear)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim,
+                                  disable_self_attn=disable_self_attn, attn_mode=attn_type, checkpoint=use_checkpoint)
+            for _ in range(depth)])
+        self.proj_out = Linear(inner, in_channels, conv1x1=not use_linear)
+
+    def forward(self, x, context=None):
+        """x logical [B,C,H,W] -> same (attention.py:614-635; linear and 1x1-conv projections are the same GEMM)."""
+        if isinstance(context, list):
+            context = context[0]
+        xh = to_nhwc(x)
+        B, H, W, C = xh.shape
+        n = ops.groupnorm(xh, self.norm.g32(), self.norm.b32(), self.norm.eps)
+        t = ops.gemm(n.view(B, H * W, C), self.proj_in.w(), self.proj_in.b32())
+        for blk in self.transformer_blocks:
+            t = blk(t, context=context, inplace=True)
+        out = ops.gemm(t, self.proj_out.w(), self.proj_out.b32(), residual=xh.view(B, H * W, C))
+        return to_nchw(out.view(B, H, W, C))

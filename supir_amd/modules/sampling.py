@@ -1,0 +1,290 @@
+"""Host-side numerics of the sampling loop: discretisation, denoiser scaling, CFG guider, Restore-EDM samplers.
+
+Same classes / constructor kwargs / call signatures as sgm/modules/diffusionmodules/{discretizer.py:42-69,
+denoiser.py:31-73, denoiser_scaling.py:16-22, guiders.py:44-74, sampling.py:25-61,528-660,733-766}.  These are scalar
+schedules and elementwise updates on [N,4,h,w] latents ("negligible bytes; keep in PyTorch"): they stay
+torch ops on the device; what changes is that the sigma schedule lives on the HOST, so the loop has no device->host
+sync per step (the reference compares device tensors in Python twice per step, sampling.py:563,581).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+SIGMA_MAX = 14.6146
+
+
+def append_dims(x, ndim):
+    return x[(...,) + (None,) * (ndim - x.ndim)]
+
+
+# ----------------------------------------------------------------------------------------------- discretisation
+class LegacyDDPMDiscretization:
+    def __init__(self, linear_start=0.00085, linear_end=0.0120, num_timesteps=1000):
+        self.num_timesteps = num_timesteps
+        betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, num_timesteps, dtype=np.float64) ** 2
+        self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+
+    def get_sigmas(self, n, device="cpu"):
+        if n < self.num_timesteps:
+            ts = np.linspace(self.num_timesteps - 1, 0, n, endpoint=False).astype(int)[::-1]
+            ac = self.alphas_cumprod[ts]
+        elif n == self.num_timesteps:
+            ac = self.alphas_cumprod
+        else:
+            raise ValueError
+        sig = torch.tensor((1 - ac) / ac, dtype=torch.float32, device=device) ** 0.5
+        return torch.flip(sig, (0,))
+
+    def __call__(self, n, do_append_zero=True, device="cpu", flip=False):
+        sig = self.get_sigmas(n, device=device)
+        if do_append_zero:
+            sig = torch.cat([sig, sig.new_zeros([1])])
+        return sig if not flip else torch.flip(sig, (0,))
+
+
+class EpsScaling:
+    def __call__(self, sigma):
+        return torch.ones_like(sigma), -sigma, 1 / (sigma ** 2 + 1.0) ** 0.5, sigma.clone()
+
+
+class EpsWeighting:
+    def __call__(self, sigma):
+        return sigma ** -2.0
+
+
+def _make(cfg, default):
+    """Accepts None, an instance, or a reference-style {"target": ..., "params": ...} config."""
+    if cfg is None:
+        return default()
+    if isinstance(cfg, dict) or hasattr(cfg, "get") and cfg.get("target") is not None:
+        from ..plugin import instantiate_from_config
+        return instantiate_from_config(cfg)
+    return cfg
+
+
+# ----------------------------------------------------------------------------------------------- denoiser
+class DiscreteDenoiserWithControl(nn.Module):
+    def __init__(self, weighting_config=None, scaling_config=None, num_idx=1000, discretization_config=None,
+                 do_append_zero=False, quantize_c_noise=True, flip=True):
+        super().__init__()
+        self.weighting = _make(weighting_config, EpsWeighting)
+        self.scaling = _make(scaling_config, EpsScaling)
+        sigmas = _make(discretization_config, LegacyDDPMDiscretization)(num_idx, do_append_zero=do_append_zero, flip=flip)
+        self.register_buffer("sigmas", sigmas)
+        self.quantize_c_noise = quantize_c_noise
+
+    def sigma_to_idx(self, sigma):
+        return (sigma - self.sigmas[:, None]).abs().argmin(dim=0).view(sigma.shape)
+
+    def idx_to_sigma(self, idx):
+        return self.sigmas[idx]
+
+    def w(self, sigma):
+        return self.weighting(sigma)
+
+    def __call__(self, network, input, sigma, cond, control_scale, **kwargs):
+        """denoiser.py:66-73: sigma snapped to the 1000-entry table; the network sees the int64 table index."""
+        idx = self.sigma_to_idx(sigma)
+        sigma = self.idx_to_sigma(idx)
+        s = append_dims(sigma, input.ndim)
+        c_skip, c_out, c_in, c_noise = self.scaling(s)
+        c_noise = self.sigma_to_idx(c_noise.reshape(sigma.shape)) if self.quantize_c_noise else c_noise.reshape(sigma.shape)
+        return network(input * c_in, c_noise, cond, control_scale, **kwargs) * c_out + input * c_skip
+
+
+# ----------------------------------------------------------------------------------------------- guiders
+class NoDynamicThresholding:
+    def __call__(self, uncond, cond, scale):
+        return uncond + scale.view(-1, 1, 1, 1) * (cond - uncond)
+
+
+_CAT_KEYS = ("vector", "crossattn", "concat", "control", "control_vector", "mask_x")
+
+
+class LinearCFG:
+    def __init__(self, scale, scale_min=None, dyn_thresh_config=None):
+        self.scale, self.scale_min = scale, scale if scale_min is None else scale_min
+        self.dyn_thresh = NoDynamicThresholding()
+
+    def scale_schedule(self, sigma):
+        return (self.scale - self.scale_min) * sigma / SIGMA_MAX + self.scale_min
+
+    def __call__(self, x, sigma):
+        x_u, x_c = x.chunk(2)
+        return self.dyn_thresh(x_u, x_c, self.scale_schedule(sigma))
+
+    def prepare_cond(self, c, uc):
+        """[uncond; cond] concat of the conditioning (guiders.py:65-74). Step independent, so samplers call it ONCE."""
+        out = {}
+        for k in c:
+            if k in _CAT_KEYS:
+                out[k] = torch.cat((uc[k], c[k]), 0)
+            else:
+                assert c[k] == uc[k]
+                out[k] = c[k]
+        return out
+
+    def prepare_inputs(self, x, s, c, uc):
+        return torch.cat([x] * 2), torch.cat([s] * 2), self.prepare_cond(c, uc)
+
+
+class VanillaCFG(LinearCFG):
+    def __init__(self, scale, dyn_thresh_config=None):
+        super().__init__(scale, scale)
+
+
+class IdentityGuider:
+    def __call__(self, x, sigma):
+        return x
+
+    def prepare_cond(self, c, uc):
+        return dict(c)
+
+    def prepare_inputs(self, x, s, c, uc):
+        return x, s, dict(c)
+
+
+# ----------------------------------------------------------------------------------------------- samplers
+class BaseDiffusionSampler:
+    def __init__(self, discretization_config=None, num_steps=None, guider_config=None, verbose=False, device="cuda"):
+        self.num_steps = num_steps
+        self.discretization = _make(discretization_config, LegacyDDPMDiscretization)
+        self.guider = _make(guider_config, IdentityGuider)
+        self.verbose = verbose
+        self.device = device
+
+    def prepare_sampling_loop(self, x, cond, uc=None, num_steps=None):
+        n = self.num_steps if num_steps is None else num_steps
+        sig_host = self.discretization(n, device="cpu")          # schedule on the host: no per-step syncs
+        sigmas = sig_host.to(x.device)
+        uc = cond if uc is None else uc
+        x *= torch.sqrt(1.0 + sigmas[0] ** 2.0)                  # in place, like the reference (sampling.py:51)
+        s_in = x.new_ones([x.shape[0]])
+        return x, s_in, sigmas, len(sigmas), cond, uc, [float(v) for v in sig_host]
+
+
+class RestoreEDMSampler(BaseDiffusionSampler):
+    def __init__(self, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, restore_cfg=4.0,
+                 restore_cfg_s_tmin=0.05, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
+        self.restore_cfg, self.restore_cfg_s_tmin = restore_cfg, restore_cfg_s_tmin
+        self.sigma_max = SIGMA_MAX
+
+    def denoise(self, x, denoiser, sigma, cond, uc, control_scale=1.0, cond_cat=None):
+        if cond_cat is None:
+            cond_cat = self.guider.prepare_cond(cond, uc)
+        twice = not isinstance(self.guider, IdentityGuider)
+        xin = torch.cat([x] * 2) if twice else x
+        sin = torch.cat([sigma] * 2) if twice else sigma
+        return self.guider(denoiser(xin, sin, cond_cat, control_scale), sigma)
+
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None, gamma=0.0, x_center=None, eps_noise=None,
+                     control_scale=1.0, use_linear_control_scale=False, control_scale_start=0.0, cond_cat=None,
+                     sigma_f=None, next_sigma_f=None):
+        """sampling.py:548-570. sigma_f / next_sigma_f: host copies of sigma[0] / next_sigma[0] (avoid device syncs)."""
+        sigma_hat = sigma * (gamma + 1.0)
+        if gamma > 0:
+            eps = (eps_noise if eps_noise is not None else torch.randn_like(x)) * self.s_noise
+            x = x + eps * append_dims(sigma_hat ** 2 - sigma ** 2, x.ndim) ** 0.5
+        if sigma_f is None:
+            sigma_f, next_sigma_f = float(sigma[0]), float(next_sigma[0])
+        if use_linear_control_scale:
+            control_scale = (sigma_f / self.sigma_max) * (control_scale_start - control_scale) + control_scale
+        denoised = self.denoise(x, denoiser, sigma_hat, cond, uc, control_scale=control_scale, cond_cat=cond_cat)
+        if (next_sigma_f > self.restore_cfg_s_tmin) and (self.restore_cfg > 0):
+            d_center = denoised - x_center
+            denoised = denoised - d_center * ((sigma.view(-1, 1, 1, 1) / self.sigma_max) ** self.restore_cfg)
+        d = (x - denoised) / append_dims(sigma_hat, x.ndim)
+        return x + append_dims(next_sigma - sigma_hat, x.ndim) * d
+
+    def _gamma(self, sig_f, num_sigmas):
+        return min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sig_f <= self.s_tmax else 0.0
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, x_center=None, control_scale=1.0,
+                 use_linear_control_scale=False, control_scale_start=0.0):
+        x, s_in, sigmas, num_sigmas, cond, uc, sf = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        cond_cat = self.guider.prepare_cond(cond, uc)            # constant over the loop: concat once
+        for i in range(num_sigmas - 1):
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, self._gamma(sf[i], num_sigmas),
+                                  x_center, control_scale=control_scale, use_linear_control_scale=use_linear_control_scale,
+                                  control_scale_start=control_scale_start, cond_cat=cond_cat, sigma_f=sf[i],
+                                  next_sigma_f=sf[i + 1])
+        return x
+
+
+def gaussian_weights(tile_width, tile_height, nbatches, device="cuda"):
+    """sampling.py:733-750 (float64; x midpoint (w-1)/2, y midpoint h/2 -- reproduced as is)."""
+    from numpy import exp, pi, sqrt
+    var = 0.01
+    mid = (tile_width - 1) / 2
+    xp = [exp(-(x - mid) * (x - mid) / (tile_width * tile_width) / (2 * var)) / sqrt(2 * pi * var) for x in range(tile_width)]
+    mid = tile_height / 2
+    yp = [exp(-(y - mid) * (y - mid) / (tile_height * tile_height) / (2 * var)) / sqrt(2 * pi * var) for y in range(tile_height)]
+    return torch.tile(torch.tensor(np.outer(yp, xp), device=device), (nbatches, 4, 1, 1))
+
+
+def _sliding_windows(h, w, tile_size, tile_stride):
+    hi_list = list(range(0, h - tile_size + 1, tile_stride))
+    if (h - tile_size) % tile_stride != 0:
+        hi_list.append(h - tile_size)
+    wi_list = list(range(0, w - tile_size + 1, tile_stride))
+    if (w - tile_size) % tile_stride != 0:
+        wi_list.append(w - tile_size)
+    return [(hi, hi + tile_size, wi, wi + tile_size) for hi in hi_list for wi in wi_list]
+
+
+class TiledRestoreEDMSampler(RestoreEDMSampler):
+    """sampling.py:600-660: per step, every 128x128 latent tile takes a full sampler step; Gaussian-weighted blend."""
+
+    def __init__(self, tile_size=128, tile_stride=64, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tile_size, self.tile_stride = tile_size, tile_stride
+        self.tile_weights = None
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, x_center=None, control_scale=1.0,
+                 use_linear_control_scale=False, control_scale_start=0.0):
+        use_local_prompt = isinstance(cond, list)
+        b, _, h, w = x.shape
+        tiles = _sliding_windows(h, w, self.tile_size, self.tile_stride)
+        if self.tile_weights is None or self.tile_weights.device != x.device:
+            self.tile_weights = gaussian_weights(self.tile_size, self.tile_size, 1, device=x.device)
+        tile_weights = self.tile_weights.repeat(b, 1, 1, 1)
+        if use_local_prompt:
+            assert len(cond) == len(tiles), "Number of local prompts should be equal to number of tiles"
+            lq = cond[0]["control"]
+        else:
+            lq = cond["control"]
+        x, s_in, sigmas, num_sigmas, cond, uc, sf = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        uc = dict(uc)
+        conds = [dict(cj) for cj in cond] if use_local_prompt else [dict(cond)]
+        # the text / vector halves of the CFG batch are tile independent: concat them once per prompt
+        static = []
+        for cj in conds:
+            cat = self.guider.prepare_cond({k: v for k, v in cj.items() if k != "control"},
+                                           {k: v for k, v in uc.items() if k != "control"})
+            static.append(cat)
+        for i in range(num_sigmas - 1):
+            gamma = self._gamma(sf[i], num_sigmas)
+            x_next = torch.zeros_like(x)
+            count = torch.zeros_like(x)
+            eps_noise = torch.randn_like(x)
+            for j, (hi, he, wi, we) in enumerate(tiles):
+                cj = conds[j] if use_local_prompt else conds[0]
+                ctl = lq[:, :, hi:he, wi:we]
+                cj["control"] = ctl
+                uc["control"] = ctl
+                cat = dict(static[j if use_local_prompt else 0])
+                cat["control"] = torch.cat((ctl, ctl), 0) if not isinstance(self.guider, IdentityGuider) else ctl
+                _x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x[:, :, hi:he, wi:we], cj, uc, gamma,
+                                       x_center[:, :, hi:he, wi:we], eps_noise=eps_noise[:, :, hi:he, wi:we],
+                                       control_scale=control_scale, use_linear_control_scale=use_linear_control_scale,
+                                       control_scale_start=control_scale_start, cond_cat=cat, sigma_f=sf[i],
+                                       next_sigma_f=sf[i + 1])
+                x_next[:, :, hi:he, wi:we] += _x * tile_weights
+                count[:, :, hi:he, wi:we] += tile_weights
+            x_next /= count
+            x = x_next
+        return x

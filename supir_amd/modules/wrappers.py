@@ -1,0 +1,73 @@
+"""ControlWrapper (sgm/modules/diffusionmodules/wrappers.py:68-102): control_model -> diffusion_model -> fp32.
+
+`dtype` is kept for the attribute protocol (`model.model.dtype = ...`, test.py:67-68): the HIP path computes in bf16
+MFMA with fp32 accumulation whatever it says; fp16 requests are honoured as "16-bit compute" (bf16 has the wider
+exponent, which is what removes the reference's fp16 NaN guards).
+
+Optional hipGraph replay: one CFG-doubled step is ~1700 kernel launches issued from Python; `enable_graph()` captures
+them once per (shape, control_scale) and replays the graph on later steps (inputs copied into static buffers).
+"""
+import torch
+import torch.nn as nn
+
+
+class ControlWrapper(nn.Module):
+    def __init__(self, diffusion_model, compile_model: bool = False, dtype=torch.float32):
+        super().__init__()
+        self.diffusion_model = diffusion_model
+        self.control_model = None
+        self.dtype = dtype
+        self._graph_on = False
+        self._graphs = {}
+
+    def load_control_model(self, control_model):
+        self.control_model = control_model
+
+    # ------------------------------------------------------------------ eager
+    def _forward_eager(self, x, t, c, control_scale, **kwargs):
+        control = self.control_model(x=c.get("control", None), timesteps=t, xt=x,
+                                     control_vector=c.get("control_vector", None), mask_x=c.get("mask_x", None),
+                                     context=c.get("crossattn", None), y=c.get("vector", None))
+        out = self.diffusion_model(x, timesteps=t, context=c.get("crossattn", None), y=c.get("vector", None),
+                                   control=control, control_scale=control_scale, **kwargs)
+        return out.float()
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def enable_graph(self, on=True):
+        self._graph_on = bool(on)
+        if not on:
+            self._graphs.clear()
+
+    def _forward_graph(self, x, t, c, control_scale):
+        ctx, vec, ctl = c["crossattn"], c["vector"], c["control"]
+        key = (tuple(x.shape), float(control_scale), id(ctx), ctx._version, id(vec), vec._version)
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 4:
+                self._graphs.clear()
+            sx, st, sc = x.clone(), t.clone(), ctl.clone()
+            cond = {"crossattn": ctx, "vector": vec, "control": sc}
+            # warm-up on a side stream: fills the weight / text-KV caches outside the capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._forward_eager(sx, st, cond, control_scale)
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward_eager(sx, st, cond, control_scale)
+            g = (graph, sx, st, sc, out, ctx, vec)  # keep ctx/vec alive: the key uses their identity
+            self._graphs[key] = g
+        graph, sx, st, sc, out, _, _ = g
+        sx.copy_(x)
+        st.copy_(t)
+        sc.copy_(ctl)
+        graph.replay()
+        return out
+
+    def forward(self, x, t, c, control_scale=1, **kwargs):
+        with torch.no_grad():
+            if self._graph_on and not kwargs and x.is_cuda:
+                return self._forward_graph(x, t, c, control_scale)
+            return self._forward_eager(x, t, c, control_scale, **kwargs)

@@ -194,8 +194,8 @@ def softmax_rows(s, scale, out=None):
 
 
 # --------------------------------------------------------------------------------------------- norms
-def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=None, control_scale=1.0, x2raw=None,
-              out=None):
+def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=None, control_scale=1.0, x1raw=None,
+              x2raw=None, out=None):
     """GroupNorm(32) over channels-last x (optionally the channel concat [x | x2]); see supir_groupnorm_nhwc."""
     lib = _lib.load()
     _check_dev(x, gamma, beta)
@@ -218,7 +218,7 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
         _, Cm2, ldm2 = _rows_ld(mod_b)
         assert Cm == C and Cm2 == C and ldm == ldm2
     ws = _gn_workspace(B, x.device)
-    rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
+    rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
                                   beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
                                   out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _stream())
     _lib.check(rc, "supir_groupnorm_nhwc")

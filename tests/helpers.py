@@ -33,3 +33,47 @@ def golden():
 def rel_l2(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+# ------------------------------------------------------------------------------------------ product-model builders
+SUPIR_NET = dict(mode="XL-base", project_type="ZeroSFT", project_channel_scale=2, adm_in_channels=2816,
+                 num_classes="sequential", use_checkpoint=True, in_channels=4, out_channels=4, model_channels=320,
+                 attention_resolutions=[4, 2], num_res_blocks=2, channel_mult=[1, 2, 4], num_head_channels=64,
+                 use_spatial_transformer=True, use_linear_in_transformer=True, transformer_depth=[1, 2, 10],
+                 context_dim=2048, spatial_transformer_attn_type="softmax-xformers", legacy=False)
+VAE_DD = dict(attn_type="vanilla-xformers", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
+def fill_module(module, prefix, device):
+    """Synthetic weights by reference key name (prefix + local name), generated directly on `device`."""
+    with torch.no_grad():
+        for k, t in module.state_dict().items():
+            if t.is_floating_point() and not k.endswith("sigmas"):
+                t.copy_(synth_param(prefix + k, t.shape, device=device))
+    return module
+
+
+def build_unet(depth=(1, 2, 10), device="cuda"):
+    from supir_amd.modules.supir_v0 import GLVControl, LightGLVUNet
+    from supir_amd.modules.wrappers import ControlWrapper
+    net = dict(SUPIR_NET, transformer_depth=list(depth))
+    ctl = {k: v for k, v in net.items() if k not in ("mode", "project_type", "project_channel_scale")}
+    with torch.device(device):
+        unet = LightGLVUNet(**net)
+        ctrl = GLVControl(**ctl, input_upscale=1)
+    fill_module(unet, "model.diffusion_model.", device)
+    fill_module(ctrl, "model.control_model.", device)
+    wrap = ControlWrapper(unet, dtype=torch.bfloat16)
+    wrap.load_control_model(ctrl)
+    return wrap
+
+
+def build_vae(device="cuda"):
+    import copy
+    from supir_amd.modules.vae import AutoencoderKLInferenceWrapper
+    with torch.device(device):
+        vae = AutoencoderKLInferenceWrapper(embed_dim=4, ddconfig=dict(VAE_DD), lossconfig={"target": "torch.nn.Identity"})
+        vae.denoise_encoder = copy.deepcopy(vae.encoder)
+    fill_module(vae, "first_stage_model.", device)
+    return vae
