@@ -145,6 +145,8 @@ def main():
         run_mod("sft.10", P[10], c1280, x1280, synth_tensor("hori1280", (B, 1280, 4, 4)))
         run_mod("sft.10.cs0.7", P[10], c1280, x1280, synth_tensor("hori1280", (B, 1280, 4, 4)), control_scale=0.7)
         run_mod("sft.0", P[0], c320, x320, synth_tensor("hori320", (B, 320, 8, 8)))
+        run_mod("sft.11.cs0.6", P[11], c1280, x1280, control_scale=0.6)
+        run_mod("xattn.7.cs0.6", P[7], c640, x1280, control_scale=0.6)
         run_mod("xattn.7", P[7], c640, x1280)
         run_mod("xattn.3", P[3], c320, x640)
         gold["modules"] = mods

@@ -16,14 +16,16 @@ __device__ __forceinline__ const bf16_t* gn_src(const GnArgs& p, int b, int row,
 }
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
-    __shared__ float acc[64];
+    // per-channel partial sums go through LDS and are reduced in a FIXED order (no atomics): results are bitwise
+    // reproducible run to run, which the parity tests and hipGraph-vs-eager checks rely on.
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
-    if (tid < 64) acc[tid] = 0.f;
-    __syncthreads();
     const int cv = p.C >> 3, cpg = p.C >> 5;
     const int cvb = cv < 256 ? cv : 256;
     const int TY = 256 / cvb;
+    float* ssum = (float*)smem_raw;        // [TY][C]
+    float* ssq = ssum + TY * p.C;          // [TY][C]
     const int vx = tid % cvb, ty = tid / cvb;
     const int row0 = chunk * p.rows_per_chunk;
     const int row1 = min(p.HW, row0 + p.rows_per_chunk);
@@ -56,27 +58,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
                     q[e] += f * f;
                 }
             }
-            // channels -> groups (a 16-byte vector may straddle groups when C/32 is not a multiple of 8)
-            int g = c / cpg;
-            float gs = 0.f, gq = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int ge = (c + e) / cpg;
-                if (ge != g) {
-                    atomicAdd(&acc[2 * g], gs);
-                    atomicAdd(&acc[2 * g + 1], gq);
-                    g = ge;
-                    gs = gq = 0.f;
-                }
-                gs += s[e];
-                gq += q[e];
+                ssum[ty * p.C + c + e] = s[e];
+                ssq[ty * p.C + c + e] = q[e];
             }
-            atomicAdd(&acc[2 * g], gs);
-            atomicAdd(&acc[2 * g + 1], gq);
         }
     }
     __syncthreads();
-    if (tid < 64) p.partial[((size_t)b * p.nchunk + chunk) * 64 + tid] = acc[tid];
+    if (tid < 64) {
+        const int g = tid >> 1;
+        const float* src = (tid & 1) ? ssq : ssum;
+        float a = 0.f;
+        for (int t = 0; t < TY; ++t)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += src[t * p.C + c];
+        p.partial[((size_t)b * p.nchunk + chunk) * 64 + tid] = a;
+    }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchunk_apply, int rows_per_chunk_apply) {
@@ -157,7 +154,12 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
     if (a.nchunk < 1) a.nchunk = 1;
     if (a.nchunk > 1024) a.nchunk = 1024;   // workspace contract: B * 1024 * 64 floats
     a.rows_per_chunk = (a.HW + a.nchunk - 1) / a.nchunk;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), 0, st, a);
+    {
+        const int cv = a.C / 8, cvb = cv < 256 ? cv : 256, TY = 256 / cvb;
+        const size_t smem_stats = (size_t)TY * a.C * 2 * sizeof(float);
+        if (smem_stats > 64 * 1024) return SUPIR_ERR_SHAPE;
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), smem_stats, st, a);
+    }
     // apply: ~64 KB of bf16 per workgroup iteration, at least 2 waves of workgroups when there is enough work
     long rows_target = (long)(64 * 1024) / (2L * a.C);
     if (rows_target < 8) rows_target = 8;

@@ -25,6 +25,16 @@ def _hash_uniform(numel, seed, device):
     return (u.to(torch.float32) - 32768.0) * (1.0 / 32768.0)
 
 
+_ZERO_INIT_MARKERS = (".out_layers.3.", ".proj_out.", ".zero_mul.", ".zero_add.", ".zero_conv.", ".out.2.",
+                      "input_hint_block.0.")
+
+
+def _is_zero_init(key):
+    """Parameters the reference zero-initialises (openaimodel.py:299-307,947-953; attention.py:606-611;
+    SUPIR_v0.py:82-87,481-483).  VAE keys (first_stage_model.*) are never zero-initialised."""
+    return (not key.startswith("first_stage_model.")) and any(m in key for m in _ZERO_INIT_MARKERS)
+
+
 def synth_param(key, shape, device="cpu", seed=0):
     """Value of parameter `key` (reference state-dict name) with `shape`."""
     shape = tuple(int(s) for s in shape)
@@ -37,6 +47,8 @@ def synth_param(key, shape, device="cpu", seed=0):
         name = last[-2] if len(last) >= 2 else ""
         if name in ("to_q", "to_k", "q", "k"):
             gain = 3.0  # peaky softmax: makes attention a real test
+        elif _is_zero_init(key):
+            gain = 0.4  # the reference zero-initialises these (zero_module): trained residual branches stay modest
         v = v * torch.tensor(gain / math.sqrt(fan_in), dtype=torch.float32, device=device)
     elif key.endswith("weight"):  # 1-D weight == GroupNorm / LayerNorm scale
         v = 1.0 + 0.1 * v

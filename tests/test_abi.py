@@ -1,0 +1,45 @@
+"""The C-ABI shared library loads (no GPU needed for dlopen) and exports every symbol include/supir_hip.h declares, with
+the argument counts the ctypes binding uses."""
+import os
+import re
+
+from supir_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "supir_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    fns = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(supir_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        fns[m.group(1)] = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
+    return fns
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    fns = _header_functions()
+    assert len(fns) >= 11
+    for name in fns:
+        assert hasattr(lib, name), f"{name} declared in supir_hip.h but not exported"
+    assert lib.supir_abi_version() == 1
+    assert lib.supir_target_arch() == b"gfx950"
+
+
+def test_ctypes_signatures_match_header():
+    fns = _header_functions()
+    for name, argtypes in _lib.SIGNATURES.items():
+        assert name in fns, name
+        assert len(argtypes) == fns[name], (name, len(argtypes), fns[name])
+    assert set(fns) - set(_lib.SIGNATURES) == {"supir_abi_version", "supir_target_arch"}
+
+
+def test_bad_arguments_return_error_codes_without_a_gpu():
+    lib = _lib.load()
+    # null pointers are rejected before any launch
+    rc = lib.supir_gemm_bf16(None, None, None, 64, 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 0, 1.0, -1, None)
+    assert rc == -1
+    rc = lib.supir_layernorm(None, None, None, None, 4, 64, 64, 64, 1e-5, None)
+    assert rc == -1

@@ -1,0 +1,168 @@
+"""Host-side logic of the product path on CPU: schedules, denoiser scaling, CFG guider, Restore-EDM / tiled samplers
+(pure torch, checked against the reference-generated goldens), the plugin mechanism and state-dict compatibility.
+No compute kernels are called here (no GPU in this tier)."""
+import copy
+
+import pytest
+import torch
+
+from supir_amd import plugin
+from supir_amd.modules import sampling as S
+from supir_amd.synth import synth_param
+from tests.helpers import SUPIR_NET, VAE_DD, golden, manifest, rel_l2, synth_tensor
+
+
+@pytest.fixture(scope="module")
+def g():
+    return golden()
+
+
+def test_schedules_match_reference(g):
+    den = S.DiscreteDenoiserWithControl()
+    assert torch.equal(den.sigmas, g["denoiser_table"])
+    d = S.LegacyDDPMDiscretization()
+    for n in (50, 2, 8):
+        assert torch.equal(d(n, device="cpu"), g[f"sigmas_{n}"])
+    assert torch.equal(S.gaussian_weights(16, 16, 1, device="cpu"), g["gaussian_weights_16"])
+    assert S._sliding_windows(24, 40, 16, 8) == g["sliding_windows_24_40_16_8"]
+    # 4096^2 px -> 512^2 latent -> 7x7 tiles of 128 stride 64
+    assert len(S._sliding_windows(512, 512, 128, 64)) == 49
+
+
+def test_denoiser_quantisation_and_scaling():
+    den = S.DiscreteDenoiserWithControl()
+    sig = torch.tensor([16.08, 14.6146, 1.0, 0.03])
+    idx = den.sigma_to_idx(sig)
+    assert idx.tolist()[0] == 999 and idx.dtype == torch.int64
+    seen = {}
+
+    def net(x, t, c, cs):
+        seen["t"], seen["x"] = t, x
+        return torch.ones_like(x)
+
+    x = torch.full((4, 4, 2, 2), 2.0)
+    out = den(net, x, sig, {}, 1.0)
+    q = den.sigmas[idx]
+    assert seen["t"].dtype == torch.int64 and torch.equal(seen["t"], idx)
+    assert torch.allclose(seen["x"], x / (q.view(-1, 1, 1, 1) ** 2 + 1).sqrt())
+    assert torch.allclose(out, x - q.view(-1, 1, 1, 1))
+
+
+def test_linear_cfg_uncond_first_and_schedule():
+    gd = S.LinearCFG(scale=1.0, scale_min=4.0)
+    c = {"crossattn": torch.ones(1, 2, 3), "vector": torch.ones(1, 4), "control": torch.ones(1, 4, 2, 2)}
+    uc = {k: v * 0 for k, v in c.items()}
+    x, s, cc = gd.prepare_inputs(torch.zeros(1, 4, 2, 2), torch.tensor([14.6146]), c, uc)
+    assert x.shape[0] == 2 and cc["crossattn"][0].sum() == 0 and cc["crossattn"][1].sum() == 6  # [uncond; cond]
+    assert abs(gd.scale_schedule(torch.tensor(14.6146)).item() - 1.0) < 1e-6
+    assert abs(gd.scale_schedule(torch.tensor(0.0)).item() - 4.0) < 1e-6
+    assert abs(gd.scale_schedule(torch.tensor(16.07606)).item() - 0.7) < 1e-3  # extrapolates on step 0
+
+
+def _fake_net(xin, tt, cc, cs):
+    return torch.tanh(xin * 0.7 + cc["control"] * 0.1) * (1.0 + 0.001 * tt.view(-1, 1, 1, 1).float()) * cs
+
+
+def _io():
+    ctx, y, lq = synth_tensor("context", (2, 77, 2048)), synth_tensor("vector", (2, 2816)), synth_tensor("lq", (2, 4, 16, 16))
+    c = {"crossattn": ctx[:1], "vector": y[:1], "control": lq[:1]}
+    uc = {"crossattn": ctx[1:], "vector": y[1:], "control": lq[:1]}
+    return c, uc
+
+
+class _Noise:
+    def __init__(self, tensors):
+        self.it = iter(tensors)
+        self.orig = torch.randn_like
+
+    def __enter__(self):
+        torch.randn_like = lambda t, **kw: next(self.it).to(t)
+
+    def __exit__(self, *a):
+        torch.randn_like = self.orig
+
+
+@pytest.mark.parametrize("name,steps,rcfg", [("fake_50_r-1", 50, -1.0), ("fake_50_r4", 50, 4.0), ("fake_8_r2", 8, 2.0)])
+def test_restore_edm_sampler_vs_reference(g, name, steps, rcfg):
+    c, uc = _io()
+    den = S.DiscreteDenoiserWithControl()
+    smp = S.RestoreEDMSampler(num_steps=steps, s_churn=5, s_noise=1.01, restore_cfg=rcfg, device="cpu",
+                              guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearCFG",
+                                             "params": {"scale": 1.0, "scale_min": 4.0}})
+    with _Noise([synth_tensor(f"{name}.eps{i}", (1, 4, 16, 16)) for i in range(steps)]):
+        out = smp(lambda i, s, cc, cs: den(_fake_net, i, s, cc, cs), synth_tensor("noised_z", (1, 4, 16, 16)).clone(), cond=c,
+                  uc=uc, x_center=synth_tensor("x_center", (1, 4, 16, 16)), control_scale=0.9)
+    assert rel_l2(out, g["sampler_" + name]) <= 5e-5
+
+
+def test_tiled_sampler_vs_reference(g):
+    c, uc = _io()
+    big = (1, 4, 24, 40)
+    lqb = synth_tensor("lq_big", big)
+    c, uc = dict(c, control=lqb), dict(uc, control=lqb)
+    den = S.DiscreteDenoiserWithControl()
+    smp = S.TiledRestoreEDMSampler(tile_size=16, tile_stride=8, num_steps=3, s_churn=5, s_noise=1.01, restore_cfg=4.0,
+                                   device="cpu", guider_config=S.LinearCFG(1.0, 4.0))
+    with _Noise([synth_tensor(f"tiled.eps{i}", big) for i in range(3)]):
+        out = smp(lambda i, s, cc, cs: den(_fake_net, i, s, cc, cs), synth_tensor("noised_big", big), cond=c, uc=uc,
+                  x_center=synth_tensor("xc_big", big), control_scale=1.0)
+    assert rel_l2(out, g["sampler_tiled_fake"]) <= 5e-5
+
+
+def test_plugin_resolves_reference_targets():
+    cfg = {"target": "sgm.modules.diffusionmodules.sampling.RestoreEDMSampler",
+           "params": {"num_steps": 7, "restore_cfg": 4.0, "s_churn": 0, "s_noise": 1.003, "device": "cpu",
+                      "discretization_config": {"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+                      "guider_config": {"target": "sgm.modules.diffusionmodules.guiders.LinearCFG",
+                                        "params": {"scale": 7.5, "scale_min": 4.0}}}}
+    smp = plugin.instantiate_from_config(cfg)
+    assert isinstance(smp, S.RestoreEDMSampler) and isinstance(smp.guider, S.LinearCFG) and smp.num_steps == 7
+    for ref_path in plugin.TARGET_MAP:
+        assert plugin.get_obj_from_str(ref_path) is not None
+
+
+def test_full_model_state_dict_is_reference_compatible():
+    """Keys AND shapes of the whole hot-path model equal the reference's (manifest recorded from the real reference)."""
+    from supir_amd.models.supir_model import SUPIRModel
+    net = dict(SUPIR_NET)
+    ctl = {k: v for k, v in net.items() if k not in ("mode", "project_type", "project_channel_scale")}
+    ddpm = {"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"}
+    cfg = dict(
+        control_stage_config={"target": "SUPIR.modules.SUPIR_v0.GLVControl", "params": dict(ctl, input_upscale=1)},
+        network_config={"target": "SUPIR.modules.SUPIR_v0.LightGLVUNet", "params": net},
+        network_wrapper="sgm.modules.diffusionmodules.wrappers.ControlWrapper",
+        denoiser_config={"target": "sgm.modules.diffusionmodules.denoiser.DiscreteDenoiserWithControl",
+                         "params": {"num_idx": 1000, "discretization_config": ddpm,
+                                    "weighting_config": {"target": "sgm.modules.diffusionmodules.denoiser_weighting.EpsWeighting"},
+                                    "scaling_config": {"target": "sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling"}}},
+        first_stage_config={"target": "sgm.models.autoencoder.AutoencoderKLInferenceWrapper",
+                            "params": {"embed_dim": 4, "ddconfig": dict(VAE_DD), "lossconfig": {"target": "torch.nn.Identity"}}},
+        sampler_config={"target": "sgm.modules.diffusionmodules.sampling.RestoreEDMSampler",
+                        "params": {"num_steps": 100, "restore_cfg": 4.0, "s_churn": 0, "s_noise": 1.003, "device": "cpu",
+                                   "discretization_config": ddpm,
+                                   "guider_config": {"target": "sgm.modules.diffusionmodules.guiders.LinearCFG",
+                                                     "params": {"scale": 7.5, "scale_min": 4.0}}}},
+        ae_dtype="bf16", diffusion_dtype="fp16", scale_factor=0.13025)
+    with torch.device("meta"):
+        model = SUPIRModel(**copy.deepcopy(cfg))
+    ours = {k: list(v.shape) for k, v in model.state_dict().items()}
+    man = manifest("full")
+    assert {k: v for k, v in ours.items() if k != "denoiser.sigmas"} == man
+    assert model.model.dtype == torch.float16 and model.ae_dtype == torch.bfloat16
+    with pytest.raises(RuntimeError):
+        SUPIRModel(**dict(copy.deepcopy(cfg), ae_dtype="fp16"))
+
+
+def test_synth_weights_are_deterministic_and_bf16_safe():
+    a = synth_param("model.diffusion_model.input_blocks.1.0.in_layers.2.weight", (320, 320, 3, 3))
+    b = synth_param("model.diffusion_model.input_blocks.1.0.in_layers.2.weight", (320, 320, 3, 3))
+    assert torch.equal(a, b) and abs(a.std().item() * (320 * 9) ** 0.5 - 1.7 * 0.577) < 0.02
+    n = synth_param("x.norm1.weight", (640,))
+    assert abs(n.mean().item() - 1.0) < 0.02
+
+
+def test_ops_refuse_cpu_tensors():
+    from supir_amd import ops
+    from supir_amd._lib import SupirHipError
+    with pytest.raises(SupirHipError):
+        ops.gemm(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))

@@ -61,6 +61,8 @@ def test_modules(sd, g):
         "sft.10.cs0.7": lambda: O.zero_sft(sd, D + "project_modules.10", c1280, x1280, hori1280, control_scale=0.7),
         "sft.0": lambda: O.zero_sft(sd, D + "project_modules.0", c320, x320, synth_tensor("hori320", (B, 320, 8, 8))),
         "xattn.7": lambda: O.zero_cross_attn(sd, D + "project_modules.7", c640, x1280),
+        "sft.11.cs0.6": lambda: O.zero_sft(sd, D + "project_modules.11", c1280, x1280, control_scale=0.6),
+        "xattn.7.cs0.6": lambda: O.zero_cross_attn(sd, D + "project_modules.7", c640, x1280, control_scale=0.6),
         "xattn.3": lambda: O.zero_cross_attn(sd, D + "project_modules.3", c320, x640),
     }
     assert set(cases) == set(m)
