@@ -55,6 +55,10 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream);
 
+/* Which tile (0..3 = 128x128, 128x64, 64x128, 64x64) tile=-1 selects for an (M, N, act) problem: lets a profiler name the
+ * kernel instantiation a launch used. Host-only, no GPU access. */
+int supir_gemm_tile_for(int M, int N, int act);
+
 /* 3x3 convolution as implicit GEMM on NHWC bf16.  X:[B][H][W][ldx], W:[Cout][3][3][Cin] bf16, Y:[B][OH][OW][ldy].
  * Replaces nn.Conv2d(k=3) at openaimodel.py:127 (Upsample.conv, upsample=1 folds F.interpolate(nearest,2x) :145)
  *   :196 (Downsample.op, stride 2 pad 1) :263,300 (ResBlock in/out conv, rowbias = emb_layers(emb) :338-355,

@@ -25,6 +25,7 @@ SIGNATURES = {
     "supir_conv3x3_smallcin": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "supir_conv3x3_smallcout": [P, P, P, P, I, I, I, I, I, I, P],
     "supir_pointwise_nchw": [P, P, P, P, I, I, I, L, F, P],
+    "supir_gemm_tile_for": [I, I, I],
 }
 
 _lib = None

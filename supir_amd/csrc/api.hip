@@ -6,6 +6,7 @@ extern "C" {
 
 int supir_abi_version(void) { return 1; }
 const char* supir_target_arch(void) { return "gfx950"; }
+int supir_gemm_tile_for(int M, int N, int act) { return supir_gemm_select_tile(M, N, act, -1); }
 
 int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,

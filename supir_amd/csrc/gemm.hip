@@ -278,21 +278,26 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
 }
 
 // tile choice: biggest tile that still yields >= ~1 wave of workgroups over 256 CUs
-template <bool CONV, bool TRANS>
-static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
-    auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+int supir_gemm_select_tile(int M, int N, int act, int force_tile) {
+    auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     int sel = force_tile;
-    if (a.act == 2) {  // GEGLU needs a 128-wide tile (value+gate fragment pair per wave)
+    if (act == 2) {  // GEGLU needs a 128-wide tile (value+gate fragment pair per wave)
         if (sel != 0 && sel != 2) sel = -1;
         if (sel < 0) sel = (tiles(128, 128) >= 200) ? 0 : 2;
     }
     if (sel < 0) {
         if (tiles(128, 128) >= 240) sel = 0;
-        else if (a.N % 128 != 0 && tiles(128, 64) >= 200) sel = 1;
+        else if (N % 128 != 0 && tiles(128, 64) >= 200) sel = 1;
         else if (tiles(128, 64) >= 240) sel = 1;
         else if (tiles(64, 128) >= 240) sel = 2;
         else sel = 3;
     }
+    return sel;
+}
+
+template <bool CONV, bool TRANS>
+static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
+    const int sel = supir_gemm_select_tile(a.M, a.N, a.act, force_tile);
     switch (sel) {
         case 0: return launch_gemm<128, 128, CONV, TRANS>(a, st);
         case 1: return launch_gemm<128, 64, CONV, TRANS>(a, st);

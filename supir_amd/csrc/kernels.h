@@ -47,6 +47,7 @@ struct GnArgs {
     float cscale;       // ZeroSFT control_scale (1 -> no lerp)
 };
 
+int supir_gemm_select_tile(int M, int N, int act, int force_tile);
 int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile);
 int supir_attn_launch(const AttnArgs& a, hipStream_t st);
 int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, long lds_, long ldp, float scale, hipStream_t st);

@@ -16,21 +16,54 @@ BF16 = torch.bfloat16
 _TRACE = None
 
 
-def start_trace():
-    global _TRACE
-    _TRACE = []
-    return _TRACE
-
-
 def stop_trace():
-    global _TRACE
-    t, _TRACE = _TRACE, None
+    global _TRACE, _TIMED
+    t, _TRACE, _TIMED = _TRACE, None, False
     return t
 
 
-def _rec(kernel, flops, bytes_, **shape):
+_TIMED = False
+
+
+def start_trace(timed=False):  # noqa: F811
+    """Record every kernel launch (class, algorithmic FLOPs / bytes, shape).  timed=True additionally brackets each launch
+    with HIP events on the launch stream (bench.py's live per-kernel durations)."""
+    global _TRACE, _TIMED
+    _TRACE, _TIMED = [], bool(timed)
+    return _TRACE
+
+
+def _ev():
+    if _TRACE is None or not _TIMED:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _rec(kernel, flops, bytes_, ev=None, **shape):
     if _TRACE is not None:
-        _TRACE.append(dict(kernel=kernel, flops=float(flops), bytes=float(bytes_), **shape))
+        r = dict(kernel=kernel, flops=float(flops), bytes=float(bytes_), **shape)
+        if ev is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            r["_ev"] = (ev, e1)
+        _TRACE.append(r)
+
+
+def finish_timing(trace):
+    """After a synchronize: replace the event pairs by `us` (microseconds)."""
+    for r in trace:
+        ev = r.pop("_ev", None)
+        if ev is not None:
+            r["us"] = ev[0].elapsed_time(ev[1]) * 1e3
+    return trace
+
+
+def gemm_tile_name(M, N, act=0, conv=False, trans=False):
+    t = _lib.load().supir_gemm_tile_for(M, N, act)
+    bm, bn = [(128, 128), (128, 64), (64, 128), (64, 64)][t]
+    return f"gemm_bf16_kernel<{bm},{bn},{'conv' if conv else 'plain'}{',T' if trans else ''}>"
 
 
 # --------------------------------------------------------------------------------------------- helpers
@@ -100,10 +133,11 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         assert rowbias.dtype == BF16 and rowbias.stride(-1) == 1 and rowbias.shape[-1] == N
         ld_rb = rowbias.stride(0)
     om = 0 if out.dtype == BF16 else 1
+    ev = _ev()
     rc = lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, ldc, _p(bias), _p(rowbias), ld_rb,
                              rows_per_batch, _p(residual), ldr, act, om, alpha, tile, _stream())
     _lib.check(rc, "supir_gemm_bf16")
-    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), M=M, N=N, K=K)
+    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act)
     return out
 
 
@@ -117,10 +151,11 @@ def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
     if out is None:
         out = torch.zeros(B, N, Tpad, dtype=BF16, device=a.device) if Tpad != T else \
             torch.empty(B, N, Tpad, dtype=BF16, device=a.device)
+    ev = _ev()
     rc = lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, Tpad, _p(bias), 0, 0, T, 0, 0, 0, 2,
                              1.0, tile, _stream())
     _lib.check(rc, "supir_gemm_bf16(T)")
-    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), M=M, N=N, K=K)
+    _rec("gemm_t", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev, M=M, N=N, K=K, act=0)
     return out
 
 
@@ -153,12 +188,14 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
         assert rowbias.dtype == BF16 and rowbias.shape == (B, Cout) and rowbias.stride(-1) == 1
         ld_rb = rowbias.stride(0)
     om = 0 if out.dtype == BF16 else 1
+    ev = _ev()
     rc = lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cin, ldx, Cout, ldy, OH, OW, stride,
                                 pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb, _p(residual), ldr,
                                 act, om, alpha, tile, _stream())
     _lib.check(rc, "supir_conv3x3_bf16")
     M = B * OH * OW
-    _rec("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout), M=M, N=Cout, K=9 * Cin)
+    _rec("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout), ev, M=M, N=Cout, K=9 * Cin,
+         act=act)
     return out
 
 
@@ -173,10 +210,11 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None):
     assert q.shape[0] == B and q.stride(0) == Tq * ldq and k.stride(0) == Tk * ldk
     if out is None:
         out = torch.empty(B, Tq, H * 64, dtype=BF16, device=q.device)
+    ev = _ev()
     rc = lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
                                   out.stride(-2), 0.125, _stream())
     _lib.check(rc, "supir_flash_attn_d64")
-    _rec("attn", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * H * 64 * (2 * Tq + 2 * Tk), B=B, H=H, Tq=Tq, Tk=Tk)
+    _rec("attn", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * H * 64 * (2 * Tq + 2 * Tk), ev, B=B, H=H, Tq=Tq, Tk=Tk)
     return out
 
 
@@ -187,9 +225,10 @@ def softmax_rows(s, scale, out=None):
     assert s.dtype == torch.float32 and s.stride(1) == 1
     if out is None:
         out = torch.empty(rows, T, dtype=BF16, device=s.device)
+    ev = _ev()
     rc = lib.supir_softmax_rows(s.data_ptr(), out.data_ptr(), rows, T, s.stride(0), out.stride(0), scale, _stream())
     _lib.check(rc, "supir_softmax_rows")
-    _rec("softmax", 0, 6.0 * rows * T)
+    _rec("softmax", 0, 6.0 * rows * T, ev)
     return out
 
 
@@ -218,12 +257,13 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
         _, Cm2, ldm2 = _rows_ld(mod_b)
         assert Cm == C and Cm2 == C and ldm == ldm2
     ws = _gn_workspace(B, x.device)
+    ev = _ev()
     rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
                                   beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
                                   out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _stream())
     _lib.check(rc, "supir_groupnorm_nhwc")
     n = B * HW * C
-    _rec("groupnorm", 0, 2.0 * n * (3 + (2 if mod_g is not None else 0)), B=B, HW=HW, C=C)
+    _rec("groupnorm", 0, 2.0 * n * (2 + (2 if mod_g is not None else 0)), ev, B=B, HW=HW, C=C)
     return out
 
 
@@ -234,10 +274,11 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     if out is None:
         out = torch.empty(*x.shape, dtype=BF16, device=x.device)
     _, _, ldy = _rows_ld(out)
+    ev = _ev()
     rc = lib.supir_layernorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, ldx, ldy, eps,
                              _stream())
     _lib.check(rc, "supir_layernorm")
-    _rec("layernorm", 0, 4.0 * rows * C, rows=rows, C=C)
+    _rec("layernorm", 0, 4.0 * rows * C, ev, rows=rows, C=C)
     return out
 
 
@@ -256,10 +297,11 @@ def conv3x3_smallcin(x_nchw, w, bias, add=None, out=None):
     ld_add = 0
     if add is not None:
         _, _, ld_add = _rows_ld(add)
+    ev = _ev()
     rc = lib.supir_conv3x3_smallcin(x_nchw.data_ptr(), w.data_ptr(), _p(bias), _p(add), out.data_ptr(), B, Cin, H, W, Cout,
                                     ld_add, ldo, _stream())
     _lib.check(rc, "supir_conv3x3_smallcin")
-    _rec("conv_smallcin", 2.0 * B * H * W * Cout * 9 * Cin, B * H * W * (4.0 * Cin + 2.0 * Cout))
+    _rec("conv_smallcin", 2.0 * B * H * W * Cout * 9 * Cin, B * H * W * (4.0 * Cin + 2.0 * Cout), ev)
     return out
 
 
@@ -273,10 +315,11 @@ def conv3x3_smallcout(x, w9, bias, out=None):
     assert w9.shape == (9, Cout, Cin) and w9.dtype == BF16 and w9.is_contiguous()
     if out is None:
         out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    ev = _ev()
     rc = lib.supir_conv3x3_smallcout(x.data_ptr(), w9.data_ptr(), _p(bias), out.data_ptr(), B, Cin, H, W, Cout, ldx,
                                      _stream())
     _lib.check(rc, "supir_conv3x3_smallcout")
-    _rec("conv_smallcout", 2.0 * B * H * W * Cout * 9 * Cin, B * H * W * (2.0 * Cin + 4.0 * Cout))
+    _rec("conv_smallcout", 2.0 * B * H * W * Cout * 9 * Cin, B * H * W * (2.0 * Cin + 4.0 * Cout), ev)
     return out
 
 

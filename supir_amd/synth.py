@@ -27,12 +27,16 @@ def _hash_uniform(numel, seed, device):
 
 _ZERO_INIT_MARKERS = (".out_layers.3.", ".proj_out.", ".zero_mul.", ".zero_add.", ".zero_conv.", ".out.2.",
                       "input_hint_block.0.")
+# output projections of the other residual branches (attention to_out, feed-forward net.2): not zero-initialised by the
+# reference, but given the same modest gain so that a 70-block-deep random network is not chaotic in bf16 (with O(1)
+# branches the ATen-autocast bf16 path itself lands 23 % away from fp32 at full depth -- useless as a parity bar).
+_BRANCH_OUT_MARKERS = (".to_out.0.", ".ff.net.2.")
 
 
 def _is_zero_init(key):
     """Parameters the reference zero-initialises (openaimodel.py:299-307,947-953; attention.py:606-611;
     SUPIR_v0.py:82-87,481-483).  VAE keys (first_stage_model.*) are never zero-initialised."""
-    return (not key.startswith("first_stage_model.")) and any(m in key for m in _ZERO_INIT_MARKERS)
+    return (not key.startswith("first_stage_model.")) and any(m in key for m in _ZERO_INIT_MARKERS + _BRANCH_OUT_MARKERS)
 
 
 def synth_param(key, shape, device="cpu", seed=0):
@@ -46,7 +50,7 @@ def synth_param(key, shape, device="cpu", seed=0):
         last = key.rsplit(".", 2)
         name = last[-2] if len(last) >= 2 else ""
         if name in ("to_q", "to_k", "q", "k"):
-            gain = 3.0  # peaky softmax: makes attention a real test
+            gain = 2.2  # logits std ~2: a non-uniform softmax, so attention is a real test
         elif _is_zero_init(key):
             gain = 0.4  # the reference zero-initialises these (zero_module): trained residual branches stay modest
         v = v * torch.tensor(gain / math.sqrt(fan_in), dtype=torch.float32, device=device)
