@@ -52,23 +52,10 @@ def build_model(device, rank, world):
     t_fill = time.time() - t0
     t_bcast = 0.0
     if world > 1:
-        # ONE weight broadcast rank0 -> all over RCCL/xGMI, coalesced into ~1 GiB buckets; nothing else is communicated
+        # ONE weight broadcast rank0 -> all over RCCL/xGMI, coalesced into 2^28-element buckets; nothing else is communicated
+        from supir_amd.parallel import broadcast_module_
         t0 = time.time()
-        tensors = [t for k, t in sd.items() if t.is_floating_point() and k != "denoiser.sigmas"]
-        bucket, size = [], 0
-        for t in tensors + [None]:
-            if t is None or size + t.numel() > (1 << 28):
-                if bucket:
-                    flat = torch.cat([b.reshape(-1) for b in bucket])
-                    dist.broadcast(flat, src=0)
-                    o = 0
-                    for b in bucket:
-                        b.copy_(flat[o:o + b.numel()].view_as(b))
-                        o += b.numel()
-                bucket, size = [], 0
-            if t is not None:
-                bucket.append(t)
-                size += t.numel()
+        broadcast_module_(model, src=0)
         torch.cuda.synchronize()
         t_bcast = time.time() - t0
     return model, t_fill, t_bcast

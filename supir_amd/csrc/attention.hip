@@ -178,7 +178,7 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
     if ((a.ldq | a.ldk | a.ldvt) % 8 != 0 || a.ldo % 4 != 0) return SUPIR_ERR_SHAPE;
     if (a.ldvt < ((a.Tk + 63) / 64) * 64) return SUPIR_ERR_SHAPE;
     const int nqb = (a.Tq + 127) / 128;
-    hipLaunchKernelGGL(attn_d64_kernel, dim3(nqb * a.H * a.B), dim3(256), 0, st, a);
+    SUPIR_LAUNCH(attn_d64_kernel, dim3(nqb * a.H * a.B), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
 }
 
@@ -223,6 +223,6 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, long lds_, long ldp, float scale,
                               hipStream_t st) {
     if (rows <= 0 || T <= 0 || T % 4 != 0 || lds_ % 4 != 0 || ldp % 4 != 0) return SUPIR_ERR_SHAPE;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, S, P, T, lds_, ldp, scale);
+    SUPIR_LAUNCH(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, S, P, T, lds_, ldp, scale);
     return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
 }

@@ -16,6 +16,14 @@ typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 
 #include "../../include/supir_hip.h"  // error codes shared with the C ABI
 
+// hipGetLastError() is per-thread sticky state shared with every other HIP user in the process (PyTorch): clear whatever
+// is pending before our launch so that the status we report afterwards is the status of OUR launch only.
+#define SUPIR_LAUNCH(...)            \
+    do {                             \
+        (void)hipGetLastError();     \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 // round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
 __device__ __forceinline__ u16 f2bf(float f) {
     uint32_t u = __float_as_uint(f);

@@ -89,7 +89,7 @@ int supir_conv3x3_smallcin_launch(const float* x, const float* w, const float* b
     const long total = (long)B * H * W * (Cout / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(conv3x3_smallcin_kernel, dim3((unsigned)blocks), dim3(256), smem, st, x, w, bias, add, out, B, Cin,
+    SUPIR_LAUNCH(conv3x3_smallcin_kernel, dim3((unsigned)blocks), dim3(256), smem, st, x, w, bias, add, out, B, Cin,
                        H, W, Cout, ld_add, ldo);
     return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
 }
@@ -175,7 +175,7 @@ int supir_conv3x3_smallcout_launch(const bf16_t* x, const bf16_t* w, const float
                 return SUPIR_ERR_HIP;                                                                              \
             attr = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL(conv3x3_smallcout_kernel<CO>, dim3((unsigned)blocks), dim3(256), smem, st, x, w, bias,  \
+        SUPIR_LAUNCH(conv3x3_smallcout_kernel<CO>, dim3((unsigned)blocks), dim3(256), smem, st, x, w, bias,  \
                            out, B, Cin, H, W, ldx);                                                                \
     }
     switch (Cout) {
@@ -210,7 +210,7 @@ int supir_pointwise_nchw_launch(const float* x, const float* w, const float* bia
     if (B <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || Cout > 8 || HW <= 0) return SUPIR_ERR_SHAPE;
     long blocks = ((long)B * HW + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pointwise_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, out, B, Cin, Cout, HW,
+    SUPIR_LAUNCH(pointwise_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, out, B, Cin, Cout, HW,
                        in_scale);
     return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
 }

@@ -273,7 +273,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
             return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, st, a);
+    SUPIR_LAUNCH(kern, dim3(tiles), dim3(256), smem, st, a);
     return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
 }
 

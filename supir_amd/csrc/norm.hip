@@ -158,7 +158,7 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
         const int cv = a.C / 8, cvb = cv < 256 ? cv : 256, TY = 256 / cvb;
         const size_t smem_stats = (size_t)TY * a.C * 2 * sizeof(float);
         if (smem_stats > 64 * 1024) return SUPIR_ERR_SHAPE;
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), smem_stats, st, a);
+        SUPIR_LAUNCH(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), smem_stats, st, a);
     }
     // apply: ~64 KB of bf16 per workgroup iteration, at least 2 waves of workgroups when there is enough work
     long rows_target = (long)(64 * 1024) / (2L * a.C);
@@ -168,7 +168,7 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
     const int rpc = (a.HW + nca - 1) / nca;
     nca = (a.HW + rpc - 1) / rpc;
     const size_t smem = (size_t)a.C * 2 * sizeof(float);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nca, a.B), dim3(256), smem, st, a, nca, rpc);
+    SUPIR_LAUNCH(gn_apply_kernel, dim3(nca, a.B), dim3(256), smem, st, a, nca, rpc);
     return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
 }
 
@@ -238,11 +238,11 @@ int supir_layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const
     const int nv = (C / 8 + 63) / 64;
     const dim3 grid((rows + 3) / 4), block(256);
     switch (nv) {
-        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
-        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
-        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
-        case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
-        default: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        case 1: SUPIR_LAUNCH(layernorm_kernel<1>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        case 2: SUPIR_LAUNCH(layernorm_kernel<2>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        case 3: SUPIR_LAUNCH(layernorm_kernel<3>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        case 4: SUPIR_LAUNCH(layernorm_kernel<4>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
+        default: SUPIR_LAUNCH(layernorm_kernel<8>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
     }
     return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
 }

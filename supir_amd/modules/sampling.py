@@ -75,11 +75,16 @@ class DiscreteDenoiserWithControl(nn.Module):
         self.register_buffer("sigmas", sigmas)
         self.quantize_c_noise = quantize_c_noise
 
+    def _table(self, like):
+        if self.sigmas.device != like.device:  # built under a device context / before .to(): follow the data
+            self.sigmas = self.sigmas.to(like.device)
+        return self.sigmas
+
     def sigma_to_idx(self, sigma):
-        return (sigma - self.sigmas[:, None]).abs().argmin(dim=0).view(sigma.shape)
+        return (sigma - self._table(sigma)[:, None]).abs().argmin(dim=0).view(sigma.shape)
 
     def idx_to_sigma(self, idx):
-        return self.sigmas[idx]
+        return self._table(idx)[idx]
 
     def w(self, sigma):
         return self.weighting(sigma)

@@ -1,0 +1,64 @@
+"""Multi-GPU: one process per GPU, independent images sharded across ranks, ONE weight broadcast, no collective inside a
+sample (the path shards at image granularity; the reference has no distributed code at all).
+
+backend "nccl" is RCCL on ROCm (xGMI inside a node); the same code runs over gloo on CPU for the tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",)):
+    """Broadcast every floating parameter/buffer of `module` from rank `src`, coalesced into buckets (few large
+    collectives: xGMI rings are per-link bound, so size matters more than count). Returns the number of buckets sent."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    tensors = [t for k, t in module.state_dict().items() if t.is_floating_point() and not any(k.endswith(s) for s in skip)]
+    groups = {}
+    for t in tensors:
+        groups.setdefault((t.dtype, t.device), []).append(t)
+    sent = 0
+    for (_, _), ts in groups.items():
+        bucket, size = [], 0
+        for t in ts + [None]:
+            if t is None or (bucket and size + t.numel() > bucket_elems):
+                flat = torch.cat([b.reshape(-1) for b in bucket])
+                dist.broadcast(flat, src=src)
+                o = 0
+                with torch.no_grad():
+                    for b in bucket:
+                        b.copy_(flat[o:o + b.numel()].view_as(b))
+                        o += b.numel()
+                sent += 1
+                bucket, size = [], 0
+            if t is not None:
+                bucket.append(t)
+                size += t.numel()
+    return sent
+
+
+def shard_items(n_items, rank=None, world=None):
+    """Image i -> rank i % world (round robin, independent units, zero exchange)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    return list(range(rank, n_items, world))
+
+
+def max_over_ranks(seconds, device="cpu"):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_images(local, n_items, device="cpu"):
+    """Optional result gather: {index: [3,H,W] tensor} from every rank -> list on rank 0 (12 MB per 1024^2 image)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [local[i] for i in range(n_items)]
+    objs = [None] * dist.get_world_size()
+    dist.all_gather_object(objs, {k: v.cpu() for k, v in local.items()})
+    merged = {}
+    for o in objs:
+        merged.update(o)
+    return [merged[i] for i in range(n_items)]
