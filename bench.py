@@ -99,33 +99,41 @@ def kernel_profile(model, latent, device):
     return agg, sum(r["us"] for r in tr)
 
 
-def cpu_baseline(model, latent=64):
+def cpu_baseline(model, device, latent=32, max_threads=32):
     """Oracle (fp32 PyTorch restatement of the reference path, kind 'port') timed on the host cores: ONE CFG-doubled
-    UNet+control call at 512x512 (latent 64), full-depth weights copied from the GPU; bounded sample (~10-30 s)."""
+    UNet+control call at 256x256 (latent 32), full-depth weights copied from the GPU.  Bounded sample: a few seconds of CPU
+    work (a first attempt with all 256 host threads at 512x512 took 508 s -- OpenMP oversubscription -- so the thread
+    count is capped and reported)."""
     from oracle import supir_oracle as O
+    from supir_amd import ops
     from supir_amd.synth import synth_tensor
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    sd = {}
-    for pfx, mod in (("model.diffusion_model.", model.model.diffusion_model), ("model.control_model.", model.model.control_model)):
-        for k, v in mod.state_dict().items():
-            sd[pfx + k] = v.detach().float().cpu()
+    threads = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(threads)
     B = 2
     x = synth_tensor("bench.x", (B, 4, latent, latent))
     cond = {"crossattn": synth_tensor("bench.ctx", (B, 77, 2048)), "vector": synth_tensor("bench.y", (B, 2816)),
             "control": synth_tensor("bench.lq", (B, 4, latent, latent))}
     t = torch.full((B,), 500, dtype=torch.int64)
+    # algorithmic FLOPs of this sample: counted from the HIP path's own launch trace at the same shape
+    model.model.enable_graph(False)
+    with torch.no_grad():
+        tr = ops.start_trace()
+        model.model(x.to(device), t.to(device), {k: v.to(device) for k, v in cond.items()}, 1.0)
+        tflop = sum(r["flops"] for r in ops.stop_trace()) / 1e12
+    sd = {}
+    for pfx, mod in (("model.diffusion_model.", model.model.diffusion_model), ("model.control_model.", model.model.control_model)):
+        for k, v in mod.state_dict().items():
+            sd[pfx + k] = v.detach().float().cpu()
     with torch.no_grad():
         t0 = time.time()
         O.control_wrapper(sd, x, t, cond, 1.0)
         dt = time.time() - t0
-    tf = UNET_STEP_TFLOP[latent]
-    s_per_image_1024 = dt * (IMAGE_TFLOP_1024 / tf)  # same TFLOP/s sustained over one 1024^2 50-step image
-    return {"value": 1.0 / s_per_image_1024, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 CFG-doubled UNet+control call at 512x512 (latent {latent}, B=2, fp32, full-depth weights) = "
-                      f"{dt:.2f} s = {tf / dt:.3f} TFLOP/s on {cores} host threads; extrapolated to the {IMAGE_TFLOP_1024} "
-                      f"TFLOP of one 1024x1024 50-step image",
-            "seconds_per_unet_step_512": dt}
+    s_per_image_1024 = dt * (IMAGE_TFLOP_1024 / tflop)  # same TFLOP/s sustained over one 1024^2 50-step image
+    return {"value": 1.0 / s_per_image_1024, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 CFG-doubled UNet+control call at {latent * 8}x{latent * 8} (latent {latent}, B=2, fp32, full-depth "
+                      f"weights, {tflop:.3f} TFLOP) = {dt:.2f} s = {tflop / dt:.3f} TFLOP/s on {threads} host threads "
+                      f"(of {os.cpu_count()}); extrapolated by FLOPs to the {IMAGE_TFLOP_1024} TFLOP of one 1024x1024 50-step image",
+            "seconds_sample": dt}
 
 
 def main():
@@ -233,7 +241,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(model)
+            cpu = cpu_baseline(model, device)
         except Exception as e:  # e.g. host RAM too small for the fp32 weights
             cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
 

@@ -44,6 +44,10 @@ int supir_abi_version(void);
 /* Static string naming the compiled target ("gfx950"). Host pointer. */
 const char* supir_target_arch(void);
 
+/* Diagnostics for SUPIR_ERR_HIP: the hipError_t of the last failed launch on this thread, and its text. Host only. */
+int supir_last_hip_error(void);
+const char* supir_hip_error_string(int code);
+
 /* C = alpha * act(A . W^T + bias + rowbias[batch]) + residual          A:[M][lda] bf16, W:[N][K] bf16 (K contiguous)
  * Replaces every nn.Linear / 1x1 nn.Conv2d on the path:
  *   sgm/modules/attention.py:87 (GEGLU.proj) :100,106 (FeedForward) :213-219 (to_q/k/v/out) :587,611 (proj_in/out)

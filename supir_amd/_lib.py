@@ -6,6 +6,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
+# torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  It MUST be in the process before our library is
+# dlopen'ed, otherwise the loader resolves our DT_NEEDED to the system runtime and the process ends up with kernels
+# registered in one HIP runtime and streams created by another (every launch then fails).
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsupir_hip.so")
 
@@ -53,6 +58,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.supir_last_hip_error.restype = c_int
+    lib.supir_last_hip_error.argtypes = []
+    lib.supir_hip_error_string.restype = c_char_p
+    lib.supir_hip_error_string.argtypes = [c_int]
     if lib.supir_abi_version() != 1:
         raise SupirHipError("libsupir_hip.so ABI version mismatch")
     _lib = lib
@@ -61,4 +70,8 @@ def load():
 
 def check(rc, name):
     if rc != 0:
-        raise SupirHipError(f"{name} failed: {_ERR.get(rc, rc)}")
+        detail = ""
+        if rc == -3 and _lib is not None:
+            code = _lib.supir_last_hip_error()
+            detail = f" [hipError {code}: {_lib.supir_hip_error_string(code).decode()}]"
+        raise SupirHipError(f"{name} failed: {_ERR.get(rc, rc)}{detail}")

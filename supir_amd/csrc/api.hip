@@ -2,7 +2,17 @@
 #include "kernels.h"
 #include "../../include/supir_hip.h"
 
+static thread_local int g_last_hip_error = 0;
+int supir_note_hip_status(hipError_t e) {
+    if (e == hipSuccess) return SUPIR_OK;
+    g_last_hip_error = (int)e;
+    return SUPIR_ERR_HIP;
+}
+
 extern "C" {
+
+int supir_last_hip_error(void) { return g_last_hip_error; }
+const char* supir_hip_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
 int supir_abi_version(void) { return 1; }
 const char* supir_target_arch(void) { return "gfx950"; }

@@ -179,7 +179,7 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
     if (a.ldvt < ((a.Tk + 63) / 64) * 64) return SUPIR_ERR_SHAPE;
     const int nqb = (a.Tq + 127) / 128;
     SUPIR_LAUNCH(attn_d64_kernel, dim3(nqb * a.H * a.B), dim3(256), 0, st, a);
-    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+    return SUPIR_LAUNCH_STATUS();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -224,5 +224,5 @@ int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, long l
                               hipStream_t st) {
     if (rows <= 0 || T <= 0 || T % 4 != 0 || lds_ % 4 != 0 || ldp % 4 != 0) return SUPIR_ERR_SHAPE;
     SUPIR_LAUNCH(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, S, P, T, lds_, ldp, scale);
-    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+    return SUPIR_LAUNCH_STATUS();
 }

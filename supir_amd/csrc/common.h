@@ -24,6 +24,10 @@ typedef u16 u16x8 __attribute__((ext_vector_type(8)));
         hipLaunchKernelGGL(__VA_ARGS__); \
     } while (0)
 
+// status of the launch just issued: SUPIR_OK or SUPIR_ERR_HIP (the hipError_t is kept for supir_last_hip_error())
+int supir_note_hip_status(hipError_t e);
+#define SUPIR_LAUNCH_STATUS() supir_note_hip_status(hipGetLastError())
+
 // round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
 __device__ __forceinline__ u16 f2bf(float f) {
     uint32_t u = __float_as_uint(f);

@@ -81,9 +81,8 @@ int supir_conv3x3_smallcin_launch(const float* x, const float* w, const float* b
     if (smem > 160 * 1024) return SUPIR_ERR_SHAPE;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv3x3_smallcin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return SUPIR_ERR_HIP;
+        if (supir_note_hip_status(hipFuncSetAttribute((const void*)conv3x3_smallcin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024)) != SUPIR_OK) return SUPIR_ERR_HIP;
         attr = true;
     }
     const long total = (long)B * H * W * (Cout / 8);
@@ -91,7 +90,7 @@ int supir_conv3x3_smallcin_launch(const float* x, const float* w, const float* b
     if (blocks > 2048) blocks = 2048;
     SUPIR_LAUNCH(conv3x3_smallcin_kernel, dim3((unsigned)blocks), dim3(256), smem, st, x, w, bias, add, out, B, Cin,
                        H, W, Cout, ld_add, ldo);
-    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+    return SUPIR_LAUNCH_STATUS();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -185,7 +184,7 @@ int supir_conv3x3_smallcout_launch(const bf16_t* x, const bf16_t* w, const float
         default: return SUPIR_ERR_SHAPE;
     }
 #undef SC_LAUNCH
-    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+    return SUPIR_LAUNCH_STATUS();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -212,5 +211,5 @@ int supir_pointwise_nchw_launch(const float* x, const float* w, const float* bia
     if (blocks > 2048) blocks = 2048;
     SUPIR_LAUNCH(pointwise_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, out, B, Cin, Cout, HW,
                        in_scale);
-    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+    return SUPIR_LAUNCH_STATUS();
 }

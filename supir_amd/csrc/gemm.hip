@@ -269,12 +269,11 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     auto kern = gemm_bf16_kernel<BM, BN, CONV, TRANS>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return SUPIR_ERR_HIP;
+        if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
         attr_set = true;
     }
     SUPIR_LAUNCH(kern, dim3(tiles), dim3(256), smem, st, a);
-    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+    return SUPIR_LAUNCH_STATUS();
 }
 
 // tile choice: biggest tile that still yields >= ~1 wave of workgroups over 256 CUs

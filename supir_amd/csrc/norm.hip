@@ -169,7 +169,7 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
     nca = (a.HW + rpc - 1) / rpc;
     const size_t smem = (size_t)a.C * 2 * sizeof(float);
     SUPIR_LAUNCH(gn_apply_kernel, dim3(nca, a.B), dim3(256), smem, st, a, nca, rpc);
-    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+    return SUPIR_LAUNCH_STATUS();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -244,5 +244,5 @@ int supir_layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const
         case 4: SUPIR_LAUNCH(layernorm_kernel<4>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
         default: SUPIR_LAUNCH(layernorm_kernel<8>, grid, block, 0, st, x, y, gamma, beta, rows, C, ldx, ldy, eps); break;
     }
-    return hipGetLastError() == hipSuccess ? SUPIR_OK : SUPIR_ERR_HIP;
+    return SUPIR_LAUNCH_STATUS();
 }

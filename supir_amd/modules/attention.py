@@ -49,8 +49,11 @@ class CrossAttention(nn.Module):
             return c[4], c[5]
         ctx = tokens_bf16(context)
         B, Tk, _ = ctx.shape
-        k = ops.gemm(ctx, wk)
-        vt = ops.gemm_t(ctx, wv, None, B, Tk, _pad64(Tk))
+        k_old = vt_old = None
+        if c is not None and c[2] is wk and c[3] is wv and c[4].shape[:2] == (B, Tk) and c[4].device == ctx.device:
+            k_old, vt_old = c[4], c[5]   # same shape: refresh IN PLACE so a captured hipGraph keeps reading these buffers
+        k = ops.gemm(ctx, wk, out=k_old)
+        vt = ops.gemm_t(ctx, wv, None, B, Tk, _pad64(Tk), out=vt_old)
         object.__setattr__(self, "_kv_cache", (context, context._version, wk, wv, k, vt))
         return k, vt
 

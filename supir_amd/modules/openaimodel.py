@@ -206,13 +206,7 @@ class UNetModel(nn.Module):
         te = timestep_embedding(timesteps, self.model_channels).to(BF16)
         l0, l2 = self.time_embed[0], self.time_embed[2]
         emb = ops.gemm(ops.gemm(te, l0.w(), l0.b32(), act=1), l2.w(), l2.b32(), out_dtype=torch.float32)
-        c = self._label_cache
-        if c is None or c[0] is not y or c[1] != y._version:
-            m0, m2 = self.label_emb[0][0], self.label_emb[0][2]
-            lab = ops.gemm(ops.gemm(y.to(BF16).contiguous(), m0.w(), m0.b32(), act=1), m2.w(), m2.b32(),
-                           out_dtype=torch.float32)
-            object.__setattr__(self, "_label_cache", (y, y._version, lab))
-        emb = emb + self._label_cache[2]
+        emb = emb + self._label(y)
         blocks = self._res_blocks()
         srcs = [p for b in blocks for p in (b.emb_layers[1].weight, b.emb_layers[1].bias)]
         w_all, b_all, offs = self._emb_w.get(srcs, lambda: (
@@ -225,6 +219,26 @@ class UNetModel(nn.Module):
             proj[id(b)] = proj_all[:, o:o + n]
             o += n
         return EmbBundle(emb.to(BF16), proj)
+
+    def _label(self, y):
+        """label_emb(y): constant over the sampling loop -> cached on tensor identity/version, refreshed in place."""
+        c = self._label_cache
+        if c is None or c[0] is not y or c[1] != y._version:
+            m0, m2 = self.label_emb[0][0], self.label_emb[0][2]
+            old = c[2] if (c is not None and c[2].shape[0] == y.shape[0] and c[2].device == y.device) else None
+            lab = ops.gemm(ops.gemm(y.to(BF16).contiguous(), m0.w(), m0.b32(), act=1), m2.w(), m2.b32(),
+                           out_dtype=torch.float32, out=old)
+            object.__setattr__(self, "_label_cache", (y, y._version, lab))
+        return self._label_cache[2]
+
+    def refresh_static_conditioning(self, context, y):
+        """Recompute every step-independent quantity (text K / V^T of all cross-attention layers, label embedding) for a
+        new conditioning, into the SAME buffers: what a captured hipGraph needs before it can be replayed."""
+        from .attention import BasicTransformerBlock
+        for m in self.modules():
+            if isinstance(m, BasicTransformerBlock) and not m.attn2.is_self:
+                m.attn2._context_kv(context)
+        self._label(y)
 
     def _conv_in(self, x, add=None):
         c = self.input_blocks[0][0]

@@ -40,14 +40,14 @@ class ControlWrapper(nn.Module):
 
     def _forward_graph(self, x, t, c, control_scale):
         ctx, vec, ctl = c["crossattn"], c["vector"], c["control"]
-        key = (tuple(x.shape), float(control_scale), id(ctx), ctx._version, id(vec), vec._version)
+        key = (tuple(x.shape), float(control_scale), tuple(ctx.shape), tuple(vec.shape))
         g = self._graphs.get(key)
         if g is None:
             if len(self._graphs) >= 4:
                 self._graphs.clear()
             sx, st, sc = x.clone(), t.clone(), ctl.clone()
             cond = {"crossattn": ctx, "vector": vec, "control": sc}
-            # warm-up on a side stream: fills the weight / text-KV caches outside the capture
+            # warm-up on a side stream: fills the weight / text-KV / label caches OUTSIDE the capture
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -57,9 +57,14 @@ class ControlWrapper(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self._forward_eager(sx, st, cond, control_scale)
-            g = (graph, sx, st, sc, out, ctx, vec)  # keep ctx/vec alive: the key uses their identity
+            g = [graph, sx, st, sc, out, ctx, ctx._version, vec, vec._version]
             self._graphs[key] = g
-        graph, sx, st, sc, out, _, _ = g
+        graph, sx, st, sc, out = g[:5]
+        if g[5] is not ctx or g[6] != ctx._version or g[7] is not vec or g[8] != vec._version:
+            # new prompt / vector with the same shapes: refresh the static conditioning in place, keep the graph
+            self.control_model.refresh_static_conditioning(ctx, vec)
+            self.diffusion_model.refresh_static_conditioning(ctx, vec)
+            g[5:9] = [ctx, ctx._version, vec, vec._version]
         sx.copy_(x)
         st.copy_(t)
         sc.copy_(ctl)

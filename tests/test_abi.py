@@ -21,7 +21,7 @@ def _header_functions():
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     fns = _header_functions()
-    assert len(fns) >= 12
+    assert len(fns) >= 14
     for name in fns:
         assert hasattr(lib, name), f"{name} declared in supir_hip.h but not exported"
     assert lib.supir_abi_version() == 1
@@ -33,7 +33,8 @@ def test_ctypes_signatures_match_header():
     for name, argtypes in _lib.SIGNATURES.items():
         assert name in fns, name
         assert len(argtypes) == fns[name], (name, len(argtypes), fns[name])
-    assert set(fns) - set(_lib.SIGNATURES) == {"supir_abi_version", "supir_target_arch"}
+    assert set(fns) - set(_lib.SIGNATURES) == {"supir_abi_version", "supir_target_arch", "supir_last_hip_error",
+                                                 "supir_hip_error_string"}
 
 
 def test_bad_arguments_return_error_codes_without_a_gpu():

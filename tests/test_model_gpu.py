@@ -209,3 +209,24 @@ def test_full_depth_wrapper_vs_oracle_on_device():
     e = rel_l2(out, ref)
     print(f"full-depth wrapper: HIP bf16 vs fp32 oracle {e:.3e}; ATen-autocast bf16 floor {floor:.3e}; eps std {ref.std().item():.3f}")
     assert e <= max(2e-2, 1.5 * floor)
+
+
+def test_graph_survives_new_prompt_without_recapture(wrap):
+    """A new context / vector tensor of the same shape must refresh the text K/V^T and label caches in place and replay the
+    SAME captured graph (no re-capture per image)."""
+    x, t, cond = _wrapper_inputs()
+    cond2 = dict(cond, crossattn=T("context2", (B, 77, 2048)), vector=T("vector2", (B, 2816)))
+    with torch.no_grad():
+        e1 = wrap(x, t, cond, 1.0).clone()
+        e2 = wrap(x, t, cond2, 1.0).clone()
+        wrap.enable_graph(True)
+        try:
+            g1 = wrap(x, t, cond, 1.0).clone()
+            n_graphs = len(wrap._graphs)
+            g2 = wrap(x, t, cond2, 1.0).clone()
+            g1b = wrap(x, t, cond, 1.0).clone()
+            assert len(wrap._graphs) == n_graphs == 1
+        finally:
+            wrap.enable_graph(False)
+    assert torch.equal(g1, e1) and torch.equal(g2, e2) and torch.equal(g1b, e1)
+    assert not torch.equal(e1, e2)
