@@ -90,7 +90,8 @@ def kernel_profile(model, latent, device):
     for r in tr:
         k = r["kernel"]
         if k in ("gemm", "gemm_t", "conv3x3"):
-            k = ops.gemm_tile_name(r["M"], r["N"], r.get("act", 0), conv=(k == "conv3x3"), trans=(k == "gemm_t"))
+            k = ops.gemm_tile_name(r["M"], r["N"], r.get("act", 0), conv=(k == "conv3x3"), trans=(k == "gemm_t"),
+                                   tile=r.get("tile", -1))
         a = agg.setdefault(k, dict(launches=0, us=0.0, flops=0.0, bytes=0.0))
         a["launches"] += 1
         a["us"] += r["us"]

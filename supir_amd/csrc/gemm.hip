@@ -22,6 +22,10 @@
 //  * XCD-aware workgroup -> tile mapping (8 private L2s).
 #include "kernels.h"
 
+#ifndef SUPIR_DEFAULT_STAGES_CODE
+#define SUPIR_DEFAULT_STAGES_CODE 1  /* 2-deep ring: measured best (deeper rings cost a resident workgroup per CU) */
+#endif
+
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
 
@@ -30,7 +34,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, bool CONV, bool TRANS>
+template <int BM, int BN, int S, bool CONV, bool TRANS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -118,18 +122,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     const int a_row_off = (wm * (BM / 2) + l31) * 128;
     const int b_row_off = (wn * (BN / 2) + l31) * 128;
 
+    // S-deep LDS ring, ONE barrier per K step: loads for tile kt+S-1 are issued right after the barrier of step kt (into
+    // the buffer step kt-1 just finished reading) and stay in flight across the next S-2 barriers (counted vmcnt).
+    // With M = 2048 the grid is only 1-2 workgroups per CU, so latency hiding has to come from this queue depth.
     const int nk = p.K >> 6;
-    stage(0);
+    {
+        const int pre = nk < S - 1 ? nk : S - 1;
+        for (int s = 0; s < pre; ++s) stage(s);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            stage(buf ^ 1);
-            wait_vmcnt<LOADS>();  // tile kt landed (tile kt+1 may still be in flight)
+        const int rem = nk - 1 - kt;
+        const int inflight = rem < S - 2 ? rem : S - 2;  // younger tiles allowed to stay outstanding
+        if constexpr (S >= 4) {
+            if (inflight >= 2) wait_vmcnt<2 * LOADS>();
+            else if (inflight == 1) wait_vmcnt<LOADS>();
+            else wait_vmcnt<0>();
+        } else if constexpr (S == 3) {
+            if (inflight >= 1) wait_vmcnt<LOADS>();
+            else wait_vmcnt<0>();
         } else {
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (kt + S - 1 < nk) stage((kt + S - 1) % S);
+        const int buf = kt % S;
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + A_BYTES;
 #pragma unroll
@@ -151,8 +168,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everyone done reading buf before it is restaged
-        asm volatile("" ::: "memory");
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -262,11 +277,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN, bool CONV, bool TRANS>
+template <int BM, int BN, int S, bool CONV, bool TRANS>
 static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    constexpr int smem = 2 * (BM + BN) * 128;
-    auto kern = gemm_bf16_kernel<BM, BN, CONV, TRANS>;
+    constexpr int smem = S * (BM + BN) * 128;
+    auto kern = gemm_bf16_kernel<BM, BN, S, CONV, TRANS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
@@ -294,15 +309,28 @@ int supir_gemm_select_tile(int M, int N, int act, int force_tile) {
     return sel;
 }
 
+// `force_tile`: -1 auto; otherwise bits 0-1 = tile (128x128, 128x64, 64x128, 64x64), bits 2-3 = LDS ring depth override
+// (0 auto, 1 -> 2 stages, 2 -> 3, 3 -> 4) -- the override exists for tools/bench_kernels.py's sweeps.
 template <bool CONV, bool TRANS>
 static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
-    const int sel = supir_gemm_select_tile(a.M, a.N, a.act, force_tile);
-    switch (sel) {
-        case 0: return launch_gemm<128, 128, CONV, TRANS>(a, st);
-        case 1: return launch_gemm<128, 64, CONV, TRANS>(a, st);
-        case 2: return launch_gemm<64, 128, CONV, TRANS>(a, st);
-        default: return launch_gemm<64, 64, CONV, TRANS>(a, st);
+    const int sel = supir_gemm_select_tile(a.M, a.N, a.act, force_tile < 0 ? -1 : (force_tile & 3));
+    int stages = force_tile < 0 ? 0 : ((force_tile >> 2) & 3);
+    if (stages == 0) stages = SUPIR_DEFAULT_STAGES_CODE;
+    stages += 1;
+    if ((a.K >> 6) < 3 && stages > 2) stages = 2;
+#define SUPIR_GEMM_CASE(BM_, BN_)                                                  \
+    switch (stages) {                                                              \
+        case 2: return launch_gemm<BM_, BN_, 2, CONV, TRANS>(a, st);               \
+        case 3: return launch_gemm<BM_, BN_, 3, CONV, TRANS>(a, st);               \
+        default: return launch_gemm<BM_, BN_, 4, CONV, TRANS>(a, st);              \
     }
+    switch (sel) {
+        case 0: SUPIR_GEMM_CASE(128, 128)
+        case 1: SUPIR_GEMM_CASE(128, 64)
+        case 2: SUPIR_GEMM_CASE(64, 128)
+        default: SUPIR_GEMM_CASE(64, 64)
+    }
+#undef SUPIR_GEMM_CASE
 }
 
 int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile) {

@@ -132,8 +132,8 @@ class LightGLVUNet(UNetModel):
         for i in cross_attn_insert_idx:
             self.project_modules.insert(i, ZeroCrossAttn(cond_output_channels[i], concat_channels[i]))
 
-    def forward(self, x, timesteps=None, context=None, y=None, control=None, control_scale=1, **kwargs):
-        """SUPIR_v0.py:600-666. Skip concat replaced by ZeroSFT; ZeroCrossAttn before the Upsample of 3-child blocks."""
+    def encode(self, x, timesteps=None, context=None, y=None):
+        """Encoder + middle block: independent of the control branch (it can run concurrently with GLVControl)."""
         emb = self._embed(timesteps, y)
         hs = []
         h = self._conv_in(x)
@@ -141,9 +141,16 @@ class LightGLVUNet(UNetModel):
         for module in list(self.input_blocks)[1:]:
             h = module(h, emb, context)
             hs.append(h)
+        h = self.middle_block(h, emb, context)
+        return emb, hs, h
+
+    def forward(self, x, timesteps=None, context=None, y=None, control=None, control_scale=1, encoded=None, **kwargs):
+        """SUPIR_v0.py:600-666. Skip concat replaced by ZeroSFT; ZeroCrossAttn before the Upsample of 3-child blocks.
+        `encoded` = a precomputed encode() result."""
+        emb, hs, h = encoded if encoded is not None else self.encode(x, timesteps, context, y)
+        hs = list(hs)
         adapter_idx = len(self.project_modules) - 1
         control_idx = len(control) - 1
-        h = self.middle_block(h, emb, context)
         h = self.project_modules[adapter_idx](control[control_idx], h, control_scale=control_scale)
         adapter_idx -= 1
         control_idx -= 1

@@ -19,17 +19,40 @@ class ControlWrapper(nn.Module):
         self.dtype = dtype
         self._graph_on = False
         self._graphs = {}
+        self.overlap_branches = True   # GLVControl || UNet encoder on two HIP streams
+        self._side = None
+        self._warm = False
 
     def load_control_model(self, control_model):
         self.control_model = control_model
 
     # ------------------------------------------------------------------ eager
     def _forward_eager(self, x, t, c, control_scale, **kwargs):
-        control = self.control_model(x=c.get("control", None), timesteps=t, xt=x,
-                                     control_vector=c.get("control_vector", None), mask_x=c.get("mask_x", None),
-                                     context=c.get("crossattn", None), y=c.get("vector", None))
-        out = self.diffusion_model(x, timesteps=t, context=c.get("crossattn", None), y=c.get("vector", None),
-                                   control=control, control_scale=control_scale, **kwargs)
+        ctx, vec = c.get("crossattn", None), c.get("vector", None)
+        ckw = dict(x=c.get("control", None), timesteps=t, xt=x, control_vector=c.get("control_vector", None),
+                   mask_x=c.get("mask_x", None), context=ctx, y=vec)
+        if self.overlap_branches and self._warm and x.is_cuda and not kwargs:
+            # The control branch and the UNet encoder+middle are independent until the first ZeroSFT: run them on two
+            # streams.  Each alone launches grids of only 160-640 workgroups (M = 2048 tokens at 32x32), i.e. 1-2 per CU
+            # at 25-40 % MFMA utilisation; co-scheduled they fill each other's idle CUs / MFMA slots.
+            main = torch.cuda.current_stream()
+            if self._side is None or self._side.device != x.device:
+                self._side = torch.cuda.Stream(device=x.device)
+            side = self._side
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                control = self.control_model(**ckw)
+            enc = self.diffusion_model.encode(x, timesteps=t, context=ctx, y=vec)
+            main.wait_stream(side)
+            for h in control:
+                h.record_stream(main)
+            out = self.diffusion_model(x, timesteps=t, context=ctx, y=vec, control=control, control_scale=control_scale,
+                                       encoded=enc)
+        else:
+            control = self.control_model(**ckw)
+            out = self.diffusion_model(x, timesteps=t, context=ctx, y=vec, control=control, control_scale=control_scale,
+                                       **kwargs)
+            self._warm = True   # weight / context caches are now built (they are filled on the calling stream)
         return out.float()
 
     # ------------------------------------------------------------------ hipGraph replay

@@ -60,8 +60,8 @@ def finish_timing(trace):
     return trace
 
 
-def gemm_tile_name(M, N, act=0, conv=False, trans=False):
-    t = _lib.load().supir_gemm_tile_for(M, N, act)
+def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
+    t = (tile & 3) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     bm, bn = [(128, 128), (128, 64), (64, 128), (64, 64)][t]
     return f"gemm_bf16_kernel<{bm},{bn},{'conv' if conv else 'plain'}{',T' if trans else ''}>"
 
@@ -102,12 +102,45 @@ _WS = {}
 
 
 def _gn_workspace(B, device):
-    key = (B, device)
+    key = (B, device, torch.cuda.current_stream().cuda_stream)  # per stream: GroupNorms may run concurrently
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(B * 1024 * 64, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
+
+
+# --------------------------------------------------------------------------------------------- tile autotuning
+# The GEMM kernel has four tile shapes; which one wins depends on how the (M, N) grid quantises onto 256 CUs and on K.
+# "Measure, don't guess": the first time a problem shape is seen (outside graph capture) every candidate is timed with HIP
+# events on the launch stream and the winner is cached for the life of the process.  All tiles accumulate K in the same
+# order, so the choice never changes a result bit.
+import os as _os
+
+_TUNE = {}
+AUTOTUNE = _os.environ.get("SUPIR_AUTOTUNE", "1") != "0"
+
+
+def _autotune(key, candidates, launch):
+    best = _TUNE.get(key)
+    if best is not None:
+        return best
+    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return -1
+    times = []
+    for t in candidates:
+        for _ in range(2):
+            launch(t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            launch(t)
+        e1.record()
+        e1.synchronize()
+        times.append((e0.elapsed_time(e1), t))
+    best = min(times)[1]
+    _TUNE[key] = best
+    return best
 
 
 # --------------------------------------------------------------------------------------------- GEMM family
@@ -133,11 +166,21 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         assert rowbias.dtype == BF16 and rowbias.stride(-1) == 1 and rowbias.shape[-1] == N
         ld_rb = rowbias.stride(0)
     om = 0 if out.dtype == BF16 else 1
+
+    def launch(t):
+        return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, ldc, _p(bias), _p(rowbias), ld_rb,
+                                   rows_per_batch, _p(residual), ldr, act, om, alpha, t, _stream())
+
+    if tile == -1:
+        key = ("gemm", M, N, K, act, om)
+        if residual is not None and residual.data_ptr() == out.data_ptr():
+            tile = _TUNE.get(key, -1)   # in-place accumulate: re-launching would change the data, only reuse a known winner
+        else:
+            tile = _autotune(key, (0, 2) if act == 2 else (0, 1, 2, 3), launch)
     ev = _ev()
-    rc = lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, ldc, _p(bias), _p(rowbias), ld_rb,
-                             rows_per_batch, _p(residual), ldr, act, om, alpha, tile, _stream())
+    rc = launch(tile)
     _lib.check(rc, "supir_gemm_bf16")
-    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act)
+    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act, tile=tile)
     return out
 
 
@@ -188,14 +231,20 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
         assert rowbias.dtype == BF16 and rowbias.shape == (B, Cout) and rowbias.stride(-1) == 1
         ld_rb = rowbias.stride(0)
     om = 0 if out.dtype == BF16 else 1
+
+    def launch(t):
+        return lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cin, ldx, Cout, ldy, OH, OW, stride,
+                                      pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb, _p(residual), ldr,
+                                      act, om, alpha, t, _stream())
+
+    if tile == -1:
+        tile = _autotune(("conv", B, H, W, Cin, Cout, stride, bool(upsample)), (0, 1, 2, 3), launch)
     ev = _ev()
-    rc = lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cin, ldx, Cout, ldy, OH, OW, stride,
-                                pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb, _p(residual), ldr,
-                                act, om, alpha, tile, _stream())
+    rc = launch(tile)
     _lib.check(rc, "supir_conv3x3_bf16")
     M = B * OH * OW
     _rec("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout), ev, M=M, N=Cout, K=9 * Cin,
-         act=act)
+         act=act, tile=tile)
     return out
 
 

@@ -230,3 +230,18 @@ def test_graph_survives_new_prompt_without_recapture(wrap):
             wrap.enable_graph(False)
     assert torch.equal(g1, e1) and torch.equal(g2, e2) and torch.equal(g1b, e1)
     assert not torch.equal(e1, e2)
+
+
+def test_two_stream_overlap_is_bitwise_equal_to_serial(wrap):
+    x, t, cond = _wrapper_inputs()
+    with torch.no_grad():
+        wrap.overlap_branches = False
+        a = wrap(x, t, cond, 1.0).clone()
+        wrap.overlap_branches = True
+        b = wrap(x, t, cond, 1.0).clone()
+        c = wrap(x * 0.9, t, cond, 1.0).clone()
+        wrap.overlap_branches = False
+        c_ref = wrap(x * 0.9, t, cond, 1.0).clone()
+        wrap.overlap_branches = True
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(c, c_ref)

@@ -33,10 +33,11 @@ for (M, N, K, cnt) in [(2048, 1280, 1280, 560), (2048, 10240, 1280, 90), (2048, 
     a = torch.randn(M, K, device=dev).to(BF)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
     b = torch.randn(N, device=dev)
-    for tile in ([-1, 0, 1, 2, 3] if M * N <= 2048 * 1280 else [-1, 0, 1]):
-        t = timeit(lambda: ops.gemm(a, w, b, tile=tile))
-        res.append(dict(op="gemm", M=M, N=N, K=K, tile=tile, us=t * 1e6, tflops=2.0 * M * N * K / t / 1e12, count=cnt))
-        print(res[-1], flush=True)
+    for tile in ([0, 1, 2, 3] if M * N <= 2048 * 1280 else [0, 1]):
+        for st in (1, 2, 3):
+            t = timeit(lambda: ops.gemm(a, w, b, tile=tile | (st << 2)))
+            res.append(dict(op="gemm", M=M, N=N, K=K, tile=tile, stages=st + 1, us=t * 1e6, tflops=2.0 * M * N * K / t / 1e12, count=cnt))
+            print(res[-1], flush=True)
     # torch (hipBLASLt) reference speed for context only
     t = timeit(lambda: torch.nn.functional.linear(a, w))
     print(dict(op="torch.linear", M=M, N=N, K=K, us=t * 1e6, tflops=2.0 * M * N * K / t / 1e12), flush=True)
@@ -46,11 +47,12 @@ for (B, H, W, Cin, Cout, cnt) in [(2, 32, 32, 1280, 1280, 17), (2, 64, 64, 640, 
     x = torch.randn(B, H, W, Cin, device=dev).to(BF)
     w = (torch.randn(Cout, 3, 3, Cin, device=dev) * (9 * Cin) ** -0.5).to(BF)
     b = torch.randn(Cout, device=dev)
-    for tile in [-1, 0, 1]:
-        t = timeit(lambda: ops.conv3x3(x, w, b, tile=tile), iters=10)
-        fl = 2.0 * B * H * W * Cout * 9 * Cin
-        res.append(dict(op="conv3x3", B=B, H=H, W=W, Cin=Cin, Cout=Cout, tile=tile, us=t * 1e6, tflops=fl / t / 1e12, count=cnt))
-        print(res[-1], flush=True)
+    for tile in [0, 1]:
+        for st in (1, 2, 3):
+            t = timeit(lambda: ops.conv3x3(x, w, b, tile=tile | (st << 2)), iters=10)
+            fl = 2.0 * B * H * W * Cout * 9 * Cin
+            res.append(dict(op="conv3x3", B=B, H=H, W=W, Cin=Cin, Cout=Cout, tile=tile, stages=st + 1, us=t * 1e6, tflops=fl / t / 1e12, count=cnt))
+            print(res[-1], flush=True)
 
 for (B, H, Tq, Tk, cnt) in [(2, 20, 1024, 1024, 91), (2, 10, 4096, 4096, 15), (2, 20, 1024, 77, 90), (2, 10, 4096, 77, 14)]:
     C = H * 64

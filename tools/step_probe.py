@@ -38,8 +38,10 @@ with torch.no_grad():
     for k, (n, f, b) in agg.items():
         print(f"  {k:16s} launches {n:5d}  TFLOP {f / 1e12:8.3f}  GB {b / 1e9:8.3f}")
     print("  total launches", len(tr), "TFLOP", sum(r["flops"] for r in tr) / 1e12)
-    for mode in ("eager", "graph"):
-        wrap.enable_graph(mode == "graph")
+    for mode in ("eager-serial", "graph-serial", "eager-overlap", "graph-overlap"):
+        wrap.overlap_branches = mode.endswith("overlap")
+        wrap.enable_graph(False)
+        wrap.enable_graph(mode.startswith("graph"))
         for _ in range(2):
             wrap(x, t, cond, 1.0)
         torch.cuda.synchronize()
