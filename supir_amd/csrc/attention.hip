@@ -14,7 +14,8 @@
 // by global_load_lds (double buffered, counted vmcnt) and shared by the 4 waves.
 // MFMA 32x32x16 with swapped operands: S^T = K.Q^T puts one query row per lane (softmax needs one shfl_xor 32),
 // and P feeds the PV MFMA straight from those registers: the key order inside each 16-wide k block is
-// permuted identically on the Vt side, so no cross-lane exchange is needed.
+// arranged (K rows read with bits 2/3 of the row index swapped) so that it is one 16-byte chunk of a Vt row: no
+// cross-lane exchange, conflict-free ds_read_b128 on both operands.
 #include "kernels.h"
 
 
@@ -73,6 +74,12 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnArgs p) {
     float m_run = -INFINITY, l_run = 0.f;
     const int sw = (l31 >> 1) & 7;
     const int row_off = l31 * 128;
+    // K fragment rows are read PERMUTED: MFMA row i of S^T holds key swap_bits(2,3)(i).  With that, the 8 P values a lane
+    // owns per 16-key block (rows 4*half + (r&3) + 8*(r>>2)) are the 8 CONSECUTIVE keys 16*kb + 8*half + 0..7, i.e. exactly
+    // one 16-byte chunk of a V^T row: the PV operand is a conflict-free ds_read_b128 and no lane exchange is needed.
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int krow_off = krow * 128;
+    const int ksw = (krow >> 1) & 7;
 
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
@@ -96,17 +103,17 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnArgs p) {
             for (int r = 0; r < 16; ++r) s[kf][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kfrag = *(const bf16x8*)(sK + kf * 4096 + row_off + (((2 * ks + half) ^ sw) * 16));
+                const bf16x8 kfrag = *(const bf16x8*)(sK + kf * 4096 + krow_off + (((2 * ks + half) ^ ksw) * 16));
                 s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], s[kf], 0, 0, 0);
             }
         }
-        // lane holds query l31, keys t*64 + kf*32 + (r&3) + 8*(r>>2) + 4*half
+        // lane holds query l31, keys t*64 + kf*32 + 16*(r>>3) + 8*half + (r&7)
         if (t == nt - 1 && (p.Tk & 63)) {
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + kf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int key = t * 64 + kf * 32 + 16 * (r >> 3) + 8 * half + (r & 7);
                     if (key >= p.Tk) s[kf][r] = -INFINITY;
                 }
         }
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnArgs p) {
         m_run = m_new;
         const float mb = m_new * p.scale_log2e;
         float psum = 0.f;
-        bf16x8 pf[4];  // pf[kf*2+kb]: keys kf*32 + 16*kb + {4h..4h+3, 8+4h..8+4h+3}
+        bf16x8 pf[4];  // pf[kf*2+kb]: keys kf*32 + 16*kb + 8*half + 0..7
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
@@ -142,13 +149,8 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnArgs p) {
             const char* vrow = sV + df * 4096 + row_off;
 #pragma unroll
             for (int kb4 = 0; kb4 < 4; ++kb4) {
-                // 16 keys kbase..kbase+15 = logical chunks 2*kb4, 2*kb4+1 of the row; this lane needs
-                // bytes [8*half, 8*half+8) of each chunk
-                const bf16x4 lo = *(const bf16x4*)(vrow + (((2 * kb4) ^ sw) * 16) + 8 * half);
-                const bf16x4 hi = *(const bf16x4*)(vrow + (((2 * kb4 + 1) ^ sw) * 16) + 8 * half);
-                bf16x8 vf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                // 16 keys 16*kb4 .. +15 = logical chunks 2*kb4, 2*kb4+1 of the V^T row; lane half h takes chunk 2*kb4+h
+                const bf16x8 vf = *(const bf16x8*)(vrow + (((2 * kb4 + half) ^ sw) * 16));
                 o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb4], o[df], 0, 0, 0);
             }
         }

@@ -81,16 +81,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchun
     float* sA = (float*)smem_raw;  // [C] scale
     float* sB = sA + p.C;          // [C] shift
     __shared__ float s_mean[32], s_rstd[32];
+    __shared__ double s_part[4][64];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cv = p.C >> 3, cpg = p.C >> 5;
+    {
+        // all 256 threads reduce the per-chunk partials (fixed order -> reproducible): value v = tid&63, chunks sub, sub+4, ...
+        const int v = tid & 63, sub = tid >> 6;
+        double a = 0.0;
+        for (int k = sub; k < p.nchunk; k += 4) a += (double)p.partial[((size_t)b * p.nchunk + k) * 64 + v];
+        s_part[sub][v] = a;
+    }
+    __syncthreads();
     if (tid < 32) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < p.nchunk; ++k) {
-            const float* pp = p.partial + ((size_t)b * p.nchunk + k) * 64 + 2 * tid;
-            s += (double)pp[0];
-            q += (double)pp[1];
-        }
+        const double s = s_part[0][2 * tid] + s_part[1][2 * tid] + s_part[2][2 * tid] + s_part[3][2 * tid];
+        const double q = s_part[0][2 * tid + 1] + s_part[1][2 * tid + 1] + s_part[2][2 * tid + 1] + s_part[3][2 * tid + 1];
         const double n = (double)p.HW * (double)cpg;
         const double mean = s / n;
         double var = q / n - mean * mean;
@@ -152,6 +157,7 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
     if (a.mod_g && (!a.mod_b || a.ldm % 8 != 0)) return SUPIR_ERR_ARG;
     a.nchunk = a.HW / 64;
     if (a.nchunk < 1) a.nchunk = 1;
+    if (a.nchunk > 128 && (long)a.HW * a.C <= (8L << 20)) a.nchunk = 128;  // UNet-sized maps: fewer partials to re-reduce
     if (a.nchunk > 1024) a.nchunk = 1024;   // workspace contract: B * 1024 * 64 floats
     a.rows_per_chunk = (a.HW + a.nchunk - 1) / a.nchunk;
     {
@@ -161,7 +167,7 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
         SUPIR_LAUNCH(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), smem_stats, st, a);
     }
     // apply: ~64 KB of bf16 per workgroup iteration, at least 2 waves of workgroups when there is enough work
-    long rows_target = (long)(64 * 1024) / (2L * a.C);
+    long rows_target = (long)(32 * 1024) / (2L * a.C);
     if (rows_target < 8) rows_target = 8;
     int nca = (int)((a.HW + rows_target - 1) / rows_target);
     if (nca > 2048) nca = 2048;

@@ -119,6 +119,17 @@ import os as _os
 
 _TUNE = {}
 AUTOTUNE = _os.environ.get("SUPIR_AUTOTUNE", "1") != "0"
+_TUNE_FILE = _os.environ.get("SUPIR_TUNE_FILE")   # optional: persist / preload winners (profiling runs without re-tuning)
+if _TUNE_FILE and _os.path.exists(_TUNE_FILE):
+    import json as _json
+    _TUNE.update({tuple(k): v for k, v in _json.load(open(_TUNE_FILE))})
+
+
+def save_tuning(path=None):
+    import json as _json
+    path = path or _TUNE_FILE
+    if path:
+        _json.dump([[list(k), v] for k, v in _TUNE.items()], open(path, "w"))
 
 
 def _autotune(key, candidates, launch):
