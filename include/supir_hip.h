@@ -54,12 +54,13 @@ const char* supir_hip_error_string(int code);
  *   sgm/modules/diffusionmodules/openaimodel.py:289 (emb_layers) :317 (skip_connection) :666-695 (time/label embed)
  *   SUPIR/modules/SUPIR_v0.py:48,87 (zero_conv)   sgm/modules/diffusionmodules/model.py:124 (nin_shortcut) :164-175 (q,k,v,proj_out)
  * K % 64 == 0, N % 4 == 0. bias fp32 [N]. rowbias bf16 [nbatch][ld_rowbias] (row m uses batch m / rows_per_batch).
- * residual bf16 [M][ldr]. tile: -1 auto, 0..3 force (128x128, 128x64, 64x128, 64x64). */
+ * residual bf16 [M][ldr]. tile: -1 auto; 0..6 force a tile of the table in csrc/gemm.hip (128x128, 128x64, 64x128, 64x64,
+ * 256x128/8 waves, 256x256/8 waves, 256x128/4 waves); bits 3-4 optionally force the LDS ring depth (profiling sweeps). */
 int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream);
 
-/* Which tile (0..3 = 128x128, 128x64, 64x128, 64x64) tile=-1 selects for an (M, N, act) problem: lets a profiler name the
+/* Which tile (index into the table of csrc/gemm.hip) tile=-1 selects for an (M, N, act) problem: lets a profiler name the
  * kernel instantiation a launch used. Host-only, no GPU access. */
 int supir_gemm_tile_for(int M, int N, int act);
 

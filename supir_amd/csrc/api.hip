@@ -22,7 +22,7 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 15) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 31) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
@@ -41,7 +41,7 @@ int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int 
                        float alpha, int tile, void* stream) {
     if (!X || !W || !Y) return SUPIR_ERR_ARG;
     if (B <= 0 || H <= 0 || Wd <= 0 || OH <= 0 || OW <= 0) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || tile > 15) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || tile > 31) return SUPIR_ERR_ARG;
     if (stride != 1 && stride != 2) return SUPIR_ERR_SHAPE;
     if (upsample && stride != 1) return SUPIR_ERR_SHAPE;
     if (ldy % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)) return SUPIR_ERR_SHAPE;

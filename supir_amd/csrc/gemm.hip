@@ -22,6 +22,9 @@
 //  * XCD-aware workgroup -> tile mapping (8 private L2s).
 #include "kernels.h"
 
+#ifndef SUPIR_GEMM_PRELOAD
+#define SUPIR_GEMM_PRELOAD 0
+#endif
 #ifndef SUPIR_DEFAULT_STAGES_CODE
 #define SUPIR_DEFAULT_STAGES_CODE 1  /* 2-deep ring: measured best (deeper rings cost a resident workgroup per CU) */
 #endif
@@ -34,20 +37,27 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int S, bool CONV, bool TRANS>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
+template <int BM, int BN, int WM, int WN, int S, bool CONV, bool TRANS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 64 * WM * WN;          // threads: WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile
+    constexpr int RPL = NT / 8;               // tile rows staged per load instruction of the workgroup
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32, LOADS = A_LOADS + B_LOADS;
-    constexpr int MI = BM / 64, NI = BN / 64;
+    constexpr int A_LOADS = BM / RPL, B_LOADS = BN / RPL, LOADS = A_LOADS + B_LOADS;
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tile_n = id / tiles_m, tile_m = id - tile_n * tiles_m;  // neighbours share the W panel
+    // neighbours (same XCD, same L2) share the W panel (order 0) or the A panel (order 1): the host picks the order that
+    // minimises L2 fills, i.e. keeps the BIGGER operand from being re-fetched by every XCD
+    int tile_m, tile_n;
+    if (p.order == 0) { tile_n = id / tiles_m; tile_m = id - tile_n * tiles_m; }
+    else { tile_m = id / tiles_n; tile_n = id - tile_m * tiles_n; }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- loader state: slot s = j*256 + tid -> row j*32 + (tid>>3), physical chunk tid&7 ----
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     int a_iy0[A_LOADS], a_ix0[A_LOADS];  // conv: oy*stride - pad_t, ox*stride - pad_l
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
-        int m = m0 + j * 32 + lrow;
+        int m = m0 + j * RPL + lrow;
         m = m < p.M ? m : p.M - 1;
         if constexpr (CONV) {
             const int b = m / p.rows_per_batch;
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     const bf16_t* b_ptr[B_LOADS];
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j) {
-        int n = n0 + j * 32 + lrow;
+        int n = n0 + j * RPL + lrow;
         n = n < p.N ? n : p.N - 1;
         b_ptr[j] = p.Wt + (size_t)n * p.K + lchunk * 8;
     }
@@ -95,10 +105,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
             } else {
                 src = a_ptr[j] + ld_k0;
             }
-            glds16(src, sA + (j * 256 + wave * 64) * 16);
+            glds16(src, sA + (j * NT + wave * 64) * 16);
         }
 #pragma unroll
-        for (int j = 0; j < B_LOADS; ++j) glds16(b_ptr[j] + ld_k0, sB + (j * 256 + wave * 64) * 16);
+        for (int j = 0; j < B_LOADS; ++j) glds16(b_ptr[j] + ld_k0, sB + (j * NT + wave * 64) * 16);
         ld_k0 += 64;
         if constexpr (CONV) {
             ld_cin0 += 64;
@@ -119,8 +129,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
 
     // fragment read offsets: row = base32 + l31, logical chunk 2*ks+half, physical chunk ^ ((row>>1)&7)
     const int sw = (l31 >> 1) & 7;
-    const int a_row_off = (wm * (BM / 2) + l31) * 128;
-    const int b_row_off = (wn * (BN / 2) + l31) * 128;
+    const int a_row_off = (wm * WTM + l31) * 128;
+    const int b_row_off = (wn * WTN + l31) * 128;
 
     // S-deep LDS ring, ONE barrier per K step: loads for tile kt+S-1 are issued right after the barrier of step kt (into
     // the buffer step kt-1 just finished reading) and stay in flight across the next S-2 barriers (counted vmcnt).
@@ -149,6 +159,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
         const int buf = kt % S;
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + A_BYTES;
+#if SUPIR_GEMM_PRELOAD
+        // phase-separated K step: pull the whole 64-deep fragment set into registers first (16 ds_read_b128 for a 64x64
+        // wave tile), then issue the MFMAs back to back at raised priority.  With two workgroups resident per CU the
+        // co-resident wave's LDS phase overlaps this wave's matrix phase instead of interleaving with it.
+        bf16x8 af[4][MI], bfr[4][NI];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = ((2 * ks + half) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[ks][i] = *(const bf16x8*)(sA + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[ks][j] = *(const bf16x8*)(sB + b_row_off + j * 32 * 128 + coff);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr (TRANS)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int coff = ((2 * ks + half) ^ sw) * 16;
@@ -168,6 +207,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -178,12 +218,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+                const int n = n0 + wn * WTN + j * 32 + l31;
                 if (n >= p.N) continue;
                 const float bz = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const int m = m0 + wm * (BM / 2) + i * 32 + 8 * rg + 4 * half;
+                    const int m = m0 + wm * WTM + i * 32 + 8 * rg + 4 * half;
                     if (m >= p.M) continue;
                     const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
                     if (m + 3 < p.M && t + 3 < p.rows_per_batch && ((t | p.ldc) & 3) == 0) {
@@ -209,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
         // D[i = channel][j = token]: lane owns token l31, channels (r&3)+8*(r>>2)+4*half -> 4 consecutive channels
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 32 + l31;
+            const int m = m0 + wm * WTM + i * 32 + l31;
             if (m >= p.M) continue;
             const int bidx = p.rowbias ? m / p.rows_per_batch : 0;
             if (p.act == 2) {
@@ -217,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
                 if constexpr (NI == 2) {
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
-                        const int nl = wn * 64 + 8 * rg + 4 * half;  // column inside the 128-wide tile
+                        const int nl = wn * 64 + 8 * rg + 4 * half;  // column inside the tile (each wave owns 64 columns)
                         const int nv = n0 + nl, ng = n0 + nl + 32;   // interleaved weight rows
                         if (ng >= p.N) continue;
                         f32x4 bv = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
@@ -239,7 +279,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const int n = n0 + wn * (BN / 2) + j * 32 + 8 * rg + 4 * half;
+                    const int n = n0 + wn * WTN + j * 32 + 8 * rg + 4 * half;
                     if (n >= p.N) continue;
                     f32x4 v;
 #pragma unroll
@@ -277,28 +317,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int S, bool CONV, bool TRANS>
+template <int BM, int BN, int WM, int WN, int S, bool CONV, bool TRANS>
 static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     constexpr int smem = S * (BM + BN) * 128;
-    auto kern = gemm_bf16_kernel<BM, BN, S, CONV, TRANS>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, S, CONV, TRANS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    SUPIR_LAUNCH(kern, dim3(tiles), dim3(256), smem, st, a);
+    SUPIR_LAUNCH(kern, dim3(tiles), dim3(64 * WM * WN), smem, st, a);
     return SUPIR_LAUNCH_STATUS();
 }
 
-// tile choice: biggest tile that still yields >= ~1 wave of workgroups over 256 CUs
+// Tile table (index -> block tile, wave grid, per-wave tile):
+//   0: 128x128 2x2 (64x64)   1: 128x64 2x2 (64x32)   2: 64x128 2x2 (32x64)   3: 64x64 2x2 (32x32)
+//   4: 256x128 4x2 (64x64, 512 threads)   5: 256x256 2x4 (128x64, 512 threads)   6: 256x128 2x2 (128x64)
+// Heuristic default: biggest of tiles 0-3 that still yields >= ~1 wave of workgroups over 256 CUs; the Python layer
+// autotunes over the whole table per problem shape.
 int supir_gemm_select_tile(int M, int N, int act, int force_tile) {
     auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     int sel = force_tile;
-    if (act == 2) {  // GEGLU needs a 128-wide tile (value+gate fragment pair per wave)
-        if (sel != 0 && sel != 2) sel = -1;
-        if (sel < 0) sel = (tiles(128, 128) >= 200) ? 0 : 2;
-    }
+    if (act == 2 && (sel == 1 || sel == 3)) sel = -1;  // GEGLU needs 64 columns per wave (value + gate fragment pair)
+    if (sel < 0 && act == 2) sel = (tiles(128, 128) >= 200) ? 0 : 2;
     if (sel < 0) {
         if (tiles(128, 128) >= 240) sel = 0;
         else if (N % 128 != 0 && tiles(128, 64) >= 200) sel = 1;
@@ -309,31 +351,43 @@ int supir_gemm_select_tile(int M, int N, int act, int force_tile) {
     return sel;
 }
 
-// `force_tile`: -1 auto; otherwise bits 0-1 = tile (128x128, 128x64, 64x128, 64x64), bits 2-3 = LDS ring depth override
-// (0 auto, 1 -> 2 stages, 2 -> 3, 3 -> 4) -- the override exists for tools/bench_kernels.py's sweeps.
+// `force_tile`: -1 auto; otherwise bits 0-2 = tile index (table above), bits 3-4 = LDS ring depth override
+// (0 default, 1 -> 2 stages, 2 -> 3, 3 -> 4) -- the override exists for tools/bench_kernels.py's sweeps.
 template <bool CONV, bool TRANS>
 static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
-    const int sel = supir_gemm_select_tile(a.M, a.N, a.act, force_tile < 0 ? -1 : (force_tile & 3));
-    int stages = force_tile < 0 ? 0 : ((force_tile >> 2) & 3);
+    const int sel = supir_gemm_select_tile(a.M, a.N, a.act, force_tile < 0 ? -1 : (force_tile & 7));
+    int stages = force_tile < 0 ? 0 : ((force_tile >> 3) & 3);
     if (stages == 0) stages = SUPIR_DEFAULT_STAGES_CODE;
     stages += 1;
     if ((a.K >> 6) < 3 && stages > 2) stages = 2;
-#define SUPIR_GEMM_CASE(BM_, BN_)                                                  \
+#define SUPIR_GEMM_CASE(BM_, BN_, WM_, WN_)                                        \
     switch (stages) {                                                              \
-        case 2: return launch_gemm<BM_, BN_, 2, CONV, TRANS>(a, st);               \
-        case 3: return launch_gemm<BM_, BN_, 3, CONV, TRANS>(a, st);               \
-        default: return launch_gemm<BM_, BN_, 4, CONV, TRANS>(a, st);              \
+        case 2: return launch_gemm<BM_, BN_, WM_, WN_, 2, CONV, TRANS>(a, st);     \
+        default: return launch_gemm<BM_, BN_, WM_, WN_, 3, CONV, TRANS>(a, st);    \
     }
     switch (sel) {
-        case 0: SUPIR_GEMM_CASE(128, 128)
-        case 1: SUPIR_GEMM_CASE(128, 64)
-        case 2: SUPIR_GEMM_CASE(64, 128)
-        default: SUPIR_GEMM_CASE(64, 64)
+        case 0: SUPIR_GEMM_CASE(128, 128, 2, 2)
+        case 1: SUPIR_GEMM_CASE(128, 64, 2, 2)
+        case 2: SUPIR_GEMM_CASE(64, 128, 2, 2)
+        case 3: SUPIR_GEMM_CASE(64, 64, 2, 2)
+        case 4: return launch_gemm<256, 128, 4, 2, 2, CONV, TRANS>(a, st);
+        case 5: return launch_gemm<256, 256, 2, 4, 2, CONV, TRANS>(a, st);
+        default: return launch_gemm<256, 128, 2, 2, 2, CONV, TRANS>(a, st);
     }
 #undef SUPIR_GEMM_CASE
 }
 
-int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile) {
+int supir_gemm_launch(const GemmArgs& a_in, bool conv, hipStream_t st, int force_tile) {
+    GemmArgs a = a_in;
+    {
+        // bytes each operand costs in L2 fills under the two orders (8 XCDs, each with a private L2)
+        const double a_bytes = conv ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin : 2.0 * (double)a.M * a.K;
+        const double w_bytes = 2.0 * (double)a.N * a.K;
+        const int tm = (a.M + 127) / 128, tn = (a.N + 127) / 128;
+        const double cost_m_fast = a_bytes * (tn < 8 ? tn : 8) + w_bytes;
+        const double cost_n_fast = w_bytes * (tm < 8 ? tm : 8) + a_bytes;
+        a.order = cost_n_fast < cost_m_fast ? 1 : 0;
+    }
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return SUPIR_ERR_ARG;
     if (a.K % 64 != 0 || a.N % 4 != 0 || a.lda % 8 != 0) return SUPIR_ERR_SHAPE;
     if (conv && (a.Cin % 64 != 0 || a.K != 9 * a.Cin)) return SUPIR_ERR_SHAPE;

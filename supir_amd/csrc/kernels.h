@@ -16,6 +16,7 @@ struct GemmArgs {
     int act;                // 0 none, 1 SiLU, 2 GEGLU (value/gate interleaved per 32 columns)
     int out_mode;           // 0 bf16 [M][ldc], 1 fp32 [M][ldc], 2 bf16 transposed [batch][N][ldc]
     float alpha;            // result = alpha * act(acc + bias + rowbias) + residual
+    int order;              // tile order inside an XCD's id range: 0 = tile_m fastest (W panel shared), 1 = tile_n fastest
 };
 
 struct AttnArgs {

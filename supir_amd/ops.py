@@ -61,9 +61,9 @@ def finish_timing(trace):
 
 
 def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
-    t = (tile & 3) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
-    bm, bn = [(128, 128), (128, 64), (64, 128), (64, 64)][t]
-    return f"gemm_bf16_kernel<{bm},{bn},{'conv' if conv else 'plain'}{',T' if trans else ''}>"
+    t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
+    name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2"][t]
+    return f"gemm_bf16_kernel<{name},{'conv' if conv else 'plain'}{',T' if trans else ''}>"
 
 
 # --------------------------------------------------------------------------------------------- helpers
@@ -187,7 +187,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         if residual is not None and residual.data_ptr() == out.data_ptr():
             tile = _TUNE.get(key, -1)   # in-place accumulate: re-launching would change the data, only reuse a known winner
         else:
-            tile = _autotune(key, (0, 2) if act == 2 else (0, 1, 2, 3), launch)
+            tile = _autotune(key, (0, 2, 4, 5, 6) if act == 2 else (0, 1, 2, 3, 4, 5, 6), launch)
     ev = _ev()
     rc = launch(tile)
     _lib.check(rc, "supir_gemm_bf16")
@@ -249,7 +249,7 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
                                       act, om, alpha, t, _stream())
 
     if tile == -1:
-        tile = _autotune(("conv", B, H, W, Cin, Cout, stride, bool(upsample)), (0, 1, 2, 3), launch)
+        tile = _autotune(("conv", B, H, W, Cin, Cout, stride, bool(upsample)), (0, 1, 2, 3, 4, 5, 6), launch)
     ev = _ev()
     rc = launch(tile)
     _lib.check(rc, "supir_conv3x3_bf16")

@@ -45,7 +45,7 @@ GEMM_SHAPES = [
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_gemm_plain(M, N, K, tile):
     if tile >= 0 and M * N > 2048 * 1280:
         pytest.skip("forced tiles only on small/medium shapes")
@@ -84,25 +84,27 @@ def test_gemm_epilogues():
 
 
 @pytest.mark.parametrize("M,K,N2", [(2048, 1280, 10240), (8192, 640, 5120), (96, 320, 2560)])
-def test_gemm_geglu(M, K, N2):
+@pytest.mark.parametrize("tile", [-1, 0, 2, 4, 5, 6])
+def test_gemm_geglu(M, K, N2, tile):
     """GEGLU epilogue (reference: sgm/modules/attention.py:89-91: first half value, second half gate, erf GELU)."""
     from supir_amd.weights import interleave_geglu
     a = rnd(M, K).to(BF)
     w = rnd(N2, K, scale=K ** -0.5, seed=1).to(BF)
     bias = rnd(N2, seed=2)
     wi, bi = interleave_geglu(w, bias)
-    out = ops.gemm(a, wi, bi, act=2)
+    out = ops.gemm(a, wi, bi, act=2, tile=tile)
     y = a.float() @ w.float().T + bias
     v, g = y.chunk(2, dim=-1)
     check(out, v * F.gelu(g), name="geglu")
 
 
 @pytest.mark.parametrize("B,T,N,K", [(2, 1024, 1280, 1280), (2, 77, 640, 2048), (2, 16, 640, 640), (1, 4096, 640, 640)])
-def test_gemm_transposed(B, T, N, K):
+@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 6])
+def test_gemm_transposed(B, T, N, K, tile):
     a = rnd(B * T, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
     Tp = (T + 63) // 64 * 64
-    out = ops.gemm_t(a, w, None, B, T, Tp)
+    out = ops.gemm_t(a, w, None, B, T, Tp, tile=tile)
     ref = (a.float() @ w.float().T).view(B, T, N).permute(0, 2, 1)
     check(out[:, :, :T], ref, name="gemm_t")
     if Tp != T:
@@ -125,13 +127,14 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv3x3(case):
+@pytest.mark.parametrize("tile", [-1, 4, 5, 6])
+def test_conv3x3(case, tile):
     B, H, W, Cin, Cout, stride, pad, up, out_hw = case
     x = rnd(B, H, W, Cin).to(BF)
     w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
     bias = rnd(Cout, seed=2)
     wk = w.permute(0, 2, 3, 1).contiguous()
-    out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw)
+    out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile)
     xr = x.float().permute(0, 3, 1, 2)
     if up:
         xr = F.interpolate(xr, scale_factor=2, mode="nearest")

@@ -8,13 +8,13 @@ dev = "cuda"
 which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
 torch.manual_seed(0)
 if which == "gemm":
-    for (M, N, K, tile) in [(2048, 1280, 1280, 3 | (1 << 2)), (2048, 1280, 1280, 1 | (1 << 2)), (2048, 10240, 1280, 0 | (1 << 2)),
-                            (8192, 640, 2560, 0 | (1 << 2))]:
+    for (M, N, K, tile) in [(2048, 1280, 1280, 3), (2048, 1280, 1280, 1), (2048, 10240, 1280, 0),
+                            (8192, 640, 2560, 0)]:
         a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
         for _ in range(3):
             ops.gemm(a, w, None, tile=tile)
 elif which == "conv":
-    for (B, H, W, Cin, Cout, tile) in [(2, 32, 32, 1280, 1280, 1 | (1 << 2)), (2, 64, 64, 640, 640, 0 | (1 << 2)), (2, 128, 128, 320, 320, 0 | (1 << 2))]:
+    for (B, H, W, Cin, Cout, tile) in [(2, 32, 32, 1280, 1280, 1), (2, 64, 64, 640, 640, 0), (2, 128, 128, 320, 320, 0)]:
         x = torch.randn(B, H, W, Cin, device=dev).to(BF); w = (torch.randn(Cout, 3, 3, Cin, device=dev) * (9 * Cin) ** -0.5).to(BF)
         for _ in range(3):
             ops.conv3x3(x, w, None, tile=tile)

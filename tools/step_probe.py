@@ -14,15 +14,16 @@ from tests.helpers import build_unet, synth_tensor
 
 dev = "cuda"
 lat = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 t0 = time.time()
 wrap = build_unet(device=dev)
 torch.cuda.synchronize()
 print("build+fill s", time.time() - t0, "mem GB", torch.cuda.memory_allocated() / 1e9, flush=True)
-B = 2
+B = BATCH
 x = synth_tensor("x", (B, 4, lat, lat)).to(dev)
 cond = {"crossattn": synth_tensor("ctx", (B, 77, 2048)).to(dev), "vector": synth_tensor("y", (B, 2816)).to(dev),
         "control": synth_tensor("lq", (B, 4, lat, lat)).to(dev)}
-t = torch.tensor([500, 500], dtype=torch.int64, device=dev)
+t = torch.full((B,), 500, dtype=torch.int64, device=dev)
 with torch.no_grad():
     for _ in range(2):
         out = wrap(x, t, cond, 1.0)
@@ -38,7 +39,7 @@ with torch.no_grad():
     for k, (n, f, b) in agg.items():
         print(f"  {k:16s} launches {n:5d}  TFLOP {f / 1e12:8.3f}  GB {b / 1e9:8.3f}")
     print("  total launches", len(tr), "TFLOP", sum(r["flops"] for r in tr) / 1e12)
-    for mode in ("eager-serial", "graph-serial", "eager-overlap", "graph-overlap"):
+    for mode in ("graph-serial", "graph-overlap"):
         wrap.overlap_branches = mode.endswith("overlap")
         wrap.enable_graph(False)
         wrap.enable_graph(mode.startswith("graph"))
