@@ -231,6 +231,36 @@ def main():
             torch.randn_like = orig
         gold["sliding_windows_24_40_16_8"] = S._sliding_windows(24, 40, 16, 8)
 
+        # DPM++ 2M restore sampler (config 5). k_diffusion is not installed: the reference class is run with the published
+        # Karras schedule (supir_amd.modules.sampling.get_sigmas_karras) and a scripted noise sampler injected, so the
+        # solver arithmetic is pinned while the schedule / Brownian-tree noise stream stay parity-unpinned.
+        from supir_amd.modules.sampling import get_sigmas_karras as karras
+        S.get_sigmas_karras = lambda n, smin, smax, device="cpu": karras(n, float(smin), float(smax), device=device)
+
+        class ScriptedNoise:
+            def __init__(self, x, smin, smax):
+                self.i = 0
+                self.shape = tuple(x.shape)
+
+            def __call__(self, s, s_next):
+                self.i += 1
+                return synth_tensor(f"dpm.eps{self.i}.{self.shape[-1]}", self.shape)
+
+        S.BrownianTreeNoiseSampler = ScriptedNoise
+        for steps in (8, 4):
+            dsm = S.RestoreDPMPP2MSampler(num_steps=steps, s_noise=1.003, eta=1.0, **sampler_cfg)
+            denoiser = lambda inp, sigma, cc, cs: den(fake_net, inp, sigma, cc, cs)
+            gold[f"sampler_dpmpp_{steps}"] = dsm(denoiser, x0.clone(), cond=dict(c), uc=dict(uc), control_scale=0.9).clone()
+        S.torch.tensor = lambda *a, **k: orig_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+        try:
+            tdsm = S.TiledRestoreDPMPP2MSampler(tile_size=16, tile_stride=8, num_steps=4, s_noise=1.003, eta=1.0, **sampler_cfg)
+        finally:
+            S.torch.tensor = orig_tensor
+        denoiser = lambda inp, sigma, cc, cs: den(fake_net, inp, sigma, cc, cs)
+        # fresh dicts: the reference's tiled samplers overwrite cond['control'] / uc['control'] per tile
+        gold["sampler_dpmpp_tiled_4"] = tdsm(denoiser, synth_tensor("noised_big", big), cond=dict(cb, control=lqb),
+                                             uc=dict(ucb, control=lqb), control_scale=1.0).clone()
+
         # -------------------------------------------------------------- VAE (64x64 px)
         img = synth_tensor("img", (1, 3, 64, 64), scale=0.5)
         h = denc(img)

@@ -293,3 +293,146 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
             x_next /= count
             x = x_next
         return x
+
+
+# ----------------------------------------------------------------------------------------------- DPM++ 2M restore sampler
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0, device="cpu"):
+    """Karras et al. (2022) schedule as published / as in k-diffusion 0.1.1.post1 `get_sigmas_karras` (third-party, not in
+    the reference tree: requirements.txt:41): n sigmas from sigma_max to sigma_min on a rho-warped ramp, then 0."""
+    ramp = torch.linspace(0, 1, n, device=device)
+    min_inv_rho = float(sigma_min) ** (1 / rho)
+    max_inv_rho = float(sigma_max) ** (1 / rho)
+    sig = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
+    return torch.cat([sig, sig.new_zeros([1])])
+
+
+class IntervalNoiseSampler:
+    """Stand-in for k_diffusion's BrownianTreeNoiseSampler (needs torchsde, not available): the sampler queries
+    consecutive, non-overlapping sigma intervals, on which normalised Brownian increments are i.i.d. N(0, 1) -- so a
+    fresh torch.randn per call has the same distribution.  What is NOT reproduced is the tree's seed->noise mapping:
+    the noise STREAM of config 5 is parity-unpinned."""
+
+    def __init__(self, x, sigma_min=None, sigma_max=None, seed=None):
+        self.shape, self.device, self.dtype = x.shape, x.device, x.dtype
+        self.gen = None
+        if seed is not None:
+            self.gen = torch.Generator(device=x.device).manual_seed(seed)
+
+    def __call__(self, sigma, sigma_next):
+        return torch.randn(self.shape, device=self.device, dtype=self.dtype, generator=self.gen)
+
+
+def _neg_log(s):
+    return s.log().neg()
+
+
+class RestoreDPMPP2MSampler(BaseDiffusionSampler):
+    """sampling.py:422-515 (RestoreDPMPP2MSampler over DPMPP2MSampler :291-362): DPM-Solver++(2M) SDE with Karras sigmas
+    between the DDPM schedule's end points; used by options/SUPIR_v0_Juggernautv9_lightning.yaml (8 / 4 steps)."""
+
+    def __init__(self, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, restore_cfg=4.0,
+                 restore_cfg_s_tmin=0.05, eta=1.0, noise_sampler_cls=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.s_noise, self.eta = s_noise, eta
+        self.noise_sampler_cls = noise_sampler_cls or IntervalNoiseSampler
+
+    def denoise(self, x, denoiser, sigma, cond, uc, control_scale=1.0, cond_cat=None):
+        if cond_cat is None:
+            cond_cat = self.guider.prepare_cond(cond, uc)
+        twice = not isinstance(self.guider, IdentityGuider)
+        xin = torch.cat([x] * 2) if twice else x
+        sin = torch.cat([sigma] * 2) if twice else sigma
+        return self.guider(denoiser(xin, sin, cond_cat, control_scale), sigma)
+
+    def get_variables(self, sigma, next_sigma, previous_sigma=None):
+        t, t_next = _neg_log(sigma), _neg_log(next_sigma)
+        h = t_next - t
+        if previous_sigma is not None:
+            return h, (t - _neg_log(previous_sigma)) / h, t, t_next
+        return h, None, t, t_next
+
+    def get_mult(self, h, r, t, t_next, previous_sigma):
+        eta_h = self.eta * h
+        mult1 = t_next.neg().exp() / t.neg().exp() * (-eta_h).exp()
+        mult2 = (-h - eta_h).expm1()
+        if previous_sigma is not None:
+            return mult1, mult2, 1 + 1 / (2 * r), 1 / (2 * r)
+        return mult1, mult2
+
+    def sampler_step(self, old_denoised, previous_sigma, sigma, next_sigma, denoiser, x, cond, uc=None, eps_noise=None,
+                     control_scale=1.0, cond_cat=None, last=False):
+        denoised = self.denoise(x, denoiser, sigma, cond, uc, control_scale=control_scale, cond_cat=cond_cat)
+        h, r, t, t_next = self.get_variables(sigma, next_sigma, previous_sigma)
+        eta_h = self.eta * h
+        mult = [append_dims(m, x.ndim) for m in self.get_mult(h, r, t, t_next, previous_sigma)]
+        x_standard = mult[0] * x - mult[1] * denoised
+        if old_denoised is None or last:
+            return x_standard, denoised
+        denoised_d = mult[2] * denoised - mult[3] * old_denoised
+        x = mult[0] * x - mult[1] * denoised_d          # next_sigma > 0 here (the `last` step returned above)
+        if self.eta:
+            # the reference multiplies [B,4,H,W] by the [B] vector next_sigma (sampling.py:482: only valid for B = 1);
+            # append_dims is the same thing for B = 1 and the intended broadcast for B > 1
+            x = x + eps_noise * append_dims(next_sigma * (-2 * eta_h).expm1().neg().sqrt(), x.ndim) * self.s_noise
+        return x, denoised
+
+    def _karras(self, x, cond, uc, num_steps):
+        x, s_in, sigmas, num_sigmas, cond, uc, sf = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        n = self.num_steps if num_steps is None else num_steps
+        smin, smax = sf[-2], sf[0]
+        sig_host = get_sigmas_karras(n, smin, smax, device="cpu")
+        return x, s_in, sig_host.to(x.device), num_sigmas, cond, uc, [float(v) for v in sig_host], smin, smax
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, control_scale=1.0, **kwargs):
+        x, s_in, sigmas, num_sigmas, cond, uc, sf, smin, smax = self._karras(x, cond, uc, num_steps)
+        cond_cat = self.guider.prepare_cond(cond, uc)
+        noise_sampler = self.noise_sampler_cls(x, smin, smax)
+        old = None
+        for i in range(num_sigmas - 1):
+            eps = noise_sampler(s_in * sigmas[i], s_in * sigmas[i + 1]) if (i > 0 and sf[i + 1] > 1e-14) else None
+            x, old = self.sampler_step(old, None if i == 0 else s_in * sigmas[i - 1], s_in * sigmas[i], s_in * sigmas[i + 1],
+                                       denoiser, x, cond, uc=uc, eps_noise=eps, control_scale=control_scale,
+                                       cond_cat=cond_cat, last=sf[i + 1] < 1e-14)
+        return x
+
+
+class TiledRestoreDPMPP2MSampler(RestoreDPMPP2MSampler):
+    """sampling.py:663-730: tile loop + Gaussian blend around the DPM++ step (x and old_denoised are both blended)."""
+
+    def __init__(self, tile_size=128, tile_stride=64, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tile_size, self.tile_stride = tile_size, tile_stride
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, control_scale=1.0, **kwargs):
+        use_local_prompt = isinstance(cond, list)
+        b, _, h, w = x.shape
+        tiles = _sliding_windows(h, w, self.tile_size, self.tile_stride)
+        tile_weights = gaussian_weights(self.tile_size, self.tile_size, 1, device=x.device).repeat(b, 1, 1, 1)
+        lq = cond[0]["control"] if use_local_prompt else cond["control"]
+        x, s_in, sigmas, num_sigmas, cond, uc, sf, smin, smax = self._karras(x, cond, uc, num_steps)
+        uc = dict(uc)
+        conds = [dict(cj) for cj in cond] if use_local_prompt else [dict(cond)]
+        static = [self.guider.prepare_cond({k: v for k, v in cj.items() if k != "control"},
+                                           {k: v for k, v in uc.items() if k != "control"}) for cj in conds]
+        noise_sampler = self.noise_sampler_cls(x, smin, smax)
+        old = None
+        for i in range(num_sigmas - 1):
+            eps = noise_sampler(s_in * sigmas[i], s_in * sigmas[i + 1]) if (i > 0 and sf[i + 1] > 1e-14) else torch.zeros_like(x)
+            x_next, old_next, count = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+            for j, (hi, he, wi, we) in enumerate(tiles):
+                cj = conds[j] if use_local_prompt else conds[0]
+                ctl = lq[:, :, hi:he, wi:we]
+                cj["control"] = ctl
+                uc["control"] = ctl
+                cat = dict(static[j if use_local_prompt else 0])
+                cat["control"] = torch.cat((ctl, ctl), 0) if not isinstance(self.guider, IdentityGuider) else ctl
+                _x, _old = self.sampler_step(None if old is None else old[:, :, hi:he, wi:we],
+                                             None if i == 0 else s_in * sigmas[i - 1], s_in * sigmas[i], s_in * sigmas[i + 1],
+                                             denoiser, x[:, :, hi:he, wi:we], cj, uc=uc, eps_noise=eps[:, :, hi:he, wi:we],
+                                             control_scale=control_scale, cond_cat=cat, last=sf[i + 1] < 1e-14)
+                x_next[:, :, hi:he, wi:we] += _x * tile_weights
+                old_next[:, :, hi:he, wi:we] += _old * tile_weights
+                count[:, :, hi:he, wi:we] += tile_weights
+            old = old_next / count
+            x = x_next / count
+        return x

@@ -27,6 +27,8 @@ TARGET_MAP = {
     "sgm.modules.diffusionmodules.sampling_utils.NoDynamicThresholding": "supir_amd.modules.sampling.NoDynamicThresholding",
     "sgm.modules.diffusionmodules.sampling.RestoreEDMSampler": "supir_amd.modules.sampling.RestoreEDMSampler",
     "sgm.modules.diffusionmodules.sampling.TiledRestoreEDMSampler": "supir_amd.modules.sampling.TiledRestoreEDMSampler",
+    "sgm.modules.diffusionmodules.sampling.RestoreDPMPP2MSampler": "supir_amd.modules.sampling.RestoreDPMPP2MSampler",
+    "sgm.modules.diffusionmodules.sampling.TiledRestoreDPMPP2MSampler": "supir_amd.modules.sampling.TiledRestoreDPMPP2MSampler",
     "sgm.modules.diffusionmodules.openaimodel.UNetModel": "supir_amd.modules.openaimodel.UNetModel",
     "sgm.modules.diffusionmodules.openaimodel.ResBlock": "supir_amd.modules.openaimodel.ResBlock",
     "sgm.modules.attention.SpatialTransformer": "supir_amd.modules.attention.SpatialTransformer",

@@ -166,3 +166,44 @@ def test_ops_refuse_cpu_tensors():
     from supir_amd._lib import SupirHipError
     with pytest.raises(SupirHipError):
         ops.gemm(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))
+
+
+class _ScriptedNoise:
+    def __init__(self, x, smin=None, smax=None):
+        self.i, self.shape = 0, tuple(x.shape)
+
+    def __call__(self, s, s_next):
+        self.i += 1
+        return synth_tensor(f"dpm.eps{self.i}.{self.shape[-1]}", self.shape)
+
+
+@pytest.mark.parametrize("steps", [8, 4])
+def test_restore_dpmpp2m_sampler_vs_reference(g, steps):
+    """Solver arithmetic of RestoreDPMPP2MSampler (sampling.py:422-515) vs the reference class run with the same (published)
+    Karras schedule and the same scripted noise.  The schedule itself and the Brownian-tree noise stream come from the
+    third-party k-diffusion package that is not in the reference tree: parity unpinned for those two."""
+    c, uc = _io()
+    den = S.DiscreteDenoiserWithControl()
+    smp = S.RestoreDPMPP2MSampler(num_steps=steps, s_noise=1.003, eta=1.0, device="cpu", guider_config=S.LinearCFG(1.0, 4.0),
+                                  noise_sampler_cls=_ScriptedNoise)
+    out = smp(lambda i, s, cc, cs: den(_fake_net, i, s, cc, cs), synth_tensor("noised_z", (1, 4, 16, 16)).clone(), cond=c, uc=uc,
+              control_scale=0.9)
+    assert rel_l2(out, g[f"sampler_dpmpp_{steps}"]) <= 5e-5
+
+
+def test_tiled_dpmpp2m_sampler_vs_reference(g):
+    c, uc = _io()
+    big = (1, 4, 24, 40)
+    lqb = synth_tensor("lq_big", big)
+    c, uc = dict(c, control=lqb), dict(uc, control=lqb)
+    den = S.DiscreteDenoiserWithControl()
+    smp = S.TiledRestoreDPMPP2MSampler(tile_size=16, tile_stride=8, num_steps=4, s_noise=1.003, eta=1.0, device="cpu",
+                                       guider_config=S.LinearCFG(1.0, 4.0), noise_sampler_cls=_ScriptedNoise)
+    out = smp(lambda i, s, cc, cs: den(_fake_net, i, s, cc, cs), synth_tensor("noised_big", big), cond=c, uc=uc, control_scale=1.0)
+    assert rel_l2(out, g["sampler_dpmpp_tiled_4"]) <= 5e-5
+
+
+def test_karras_schedule_properties():
+    s = S.get_sigmas_karras(8, 0.0292, 14.6146)
+    assert s.shape == (9,) and s[-1] == 0 and abs(s[0].item() - 14.6146) < 1e-4 and abs(s[-2].item() - 0.0292) < 1e-5
+    assert torch.all(s[:-1][1:] < s[:-1][:-1])
