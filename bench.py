@@ -144,6 +144,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--edm-steps", type=int, default=50)
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--images-per-gpu", type=int, default=1,
+                    help="images batched into one batchify_sample call per rank (test.py runs 1; >1 raises M of every GEMM)")
+    ap.add_argument("--extra-batch", type=int, default=4,
+                    help="after the timed region also report throughput with this many images per call (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -166,9 +170,16 @@ def main():
     model, t_fill, t_bcast = build_model(device, rank, world)
     model.model.enable_graph(not args.no_graph)
     P = args.res
-    x = (synth_tensor(f"bench.img{rank}", (1, 3, P, P), scale=0.5).clamp(-1, 1)).to(device)
-    c = {"crossattn": synth_tensor("bench.c", (1, 77, 2048)).to(device), "vector": synth_tensor("bench.v", (1, 2816)).to(device)}
-    uc = {"crossattn": synth_tensor("bench.uc", (1, 77, 2048)).to(device), "vector": synth_tensor("bench.uv", (1, 2816)).to(device)}
+    def make_inputs(n):
+        xs = (synth_tensor(f"bench.img{rank}.{n}", (n, 3, P, P), scale=0.5).clamp(-1, 1)).to(device)
+        cc = {"crossattn": synth_tensor("bench.c", (1, 77, 2048)).to(device).repeat(n, 1, 1).contiguous(),
+              "vector": synth_tensor("bench.v", (1, 2816)).to(device).repeat(n, 1).contiguous()}
+        uu = {"crossattn": synth_tensor("bench.uc", (1, 77, 2048)).to(device).repeat(n, 1, 1).contiguous(),
+              "vector": synth_tensor("bench.uv", (1, 2816)).to(device).repeat(n, 1).contiguous()}
+        return xs, cc, uu
+
+    ipg = args.images_per_gpu
+    x, c, uc = make_inputs(ipg)
 
     def sync():
         if world > 1:
@@ -239,6 +250,19 @@ def main():
                 pass
         model.model.enable_graph(not args.no_graph)
 
+    if rank == 0 and world == 1 and args.extra_batch > 1 and args.extra_batch != ipg:
+        # supplementary: same workload with several images per call (raises M of every GEMM from 2048.. to n*2048..)
+        nb = args.extra_batch
+        xb, cb, ub = make_inputs(nb)
+        one_image(model, xb, (cb, ub), 4321, args.edm_steps)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        one_image(model, xb, (cb, ub), 4322, args.edm_steps)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        extra["batched"] = {"images_per_call": nb, "images_per_s": nb / tb, "s_per_call": tb}
+        del xb
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -247,7 +271,7 @@ def main():
             cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
 
     if rank == 0:
-        n_img = args.steps * world
+        n_img = args.steps * world * ipg
         line = {
             "metric": "1024px 50-step EDM denoise images/sec", "value": n_img / dt, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -255,10 +279,11 @@ def main():
             "config": {"workload": f"configs[1]: 1xMI355X {P}x{P}, {args.edm_steps} EDM steps (RestoreEDMSampler, s_churn 5, "
                                    f"linear CFG 1.0->4.0), bf16 MFMA UNet+GLVControl+VAE, SUPIR-v0 config, 1 image per GPU per step, "
                                    f"random-init weights", "edm_steps": args.edm_steps, "resolution": P,
-                       "images_per_gpu_per_step": 1, "hip_graph": not args.no_graph},
+                       "images_per_gpu_per_step": ipg, "hip_graph": not args.no_graph,
+                       "two_stream_overlap": bool(model.model.overlap_branches)},
             "roofline": roofline, "cpu_baseline": cpu,
             "output_finite": finite, "weight_fill_s": round(t_fill, 2), "weight_broadcast_s": round(t_bcast, 2),
-            "end_to_end_tflops_per_gpu": IMAGE_TFLOP_1024 * args.steps / dt if P == 1024 and args.edm_steps == 50 else None,
+            "end_to_end_tflops_per_gpu": IMAGE_TFLOP_1024 * args.steps * ipg / dt if P == 1024 and args.edm_steps == 50 else None,
             "kernel_breakdown_unet_step": breakdown,
         }
         line.update(extra)

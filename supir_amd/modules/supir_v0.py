@@ -38,15 +38,20 @@ class ZeroSFT(nn.Module):
             torch.cat([Wt.conv3x3_w(self.zero_mul.weight), Wt.conv3x3_w(self.zero_add.weight)], 0).contiguous(),
             torch.cat([Wt.f32(self.zero_mul.bias), Wt.f32(self.zero_add.bias)], 0).contiguous()))
 
-    def forward(self, c, h, h_ori=None, control_scale=1):
+    def control_side(self, c):
+        """gamma|beta maps: depend on the control feature only, so they can be produced ahead of the decoder (side stream)."""
+        ch = to_nhwc(c)
+        m = self.mlp_shared[0]
+        actv = ops.conv3x3(ch, m.w(), m.b32(), act=1)
+        wgb, bgb = self._w_gamma_beta()
+        return ops.conv3x3(actv, wgb, bgb)                                               # [B,H,W,2*Ccat]
+
+    def forward(self, c, h, h_ori=None, control_scale=1, pre=None):
         assert self.mask is False
         ch, hh = to_nhwc(c), to_nhwc(h)
         B, H, W, Cs = hh.shape
         hz = ops.gemm(ch, self.zero_conv.w(), self.zero_conv.b32(), residual=hh)        # h + zero_conv(c)
-        m = self.mlp_shared[0]
-        actv = ops.conv3x3(ch, m.w(), m.b32(), act=1)
-        wgb, bgb = self._w_gamma_beta()
-        gb = ops.conv3x3(actv, wgb, bgb)                                                 # [B,H,W,2*Ccat]
+        gb = pre if pre is not None else self.control_side(c)
         n = self.param_free_norm
         Ccat = n.num_channels
         cs = float(control_scale)
@@ -71,20 +76,25 @@ class ZeroCrossAttn(nn.Module):
         self.norm2 = GroupNorm32(context_dim)
         self.mask = mask
 
-    def forward(self, context, x, control_scale=1):
-        """x + attn(GN(x), GN(context)) * control_scale (SUPIR_v0.py:138-152). The control feature changes every step,
-        so its K / V^T are projected here (no cross-step cache)."""
-        assert self.mask is False
-        xh, chh = to_nhwc(x), to_nhwc(context)
-        B, H, W, C = xh.shape
-        Cc = chh.shape[-1]
-        xn = ops.groupnorm(xh, self.norm1.g32(), self.norm1.b32(), self.norm1.eps).view(B, H * W, C)
+    def control_side(self, context):
+        """K and V^T of the (group-normalised) control feature: independent of the decoder state."""
+        chh = to_nhwc(context)
+        B, Cc = chh.shape[0], chh.shape[-1]
         cn = ops.groupnorm(chh, self.norm2.g32(), self.norm2.b32(), self.norm2.eps).view(B, -1, Cc)
+        a, Tk = self.attn, cn.shape[1]
+        return ops.gemm(cn, a.to_k.w()), ops.gemm_t(cn, a.to_v.w(), None, B, Tk, (Tk + 63) // 64 * 64)
+
+    def forward(self, context, x, control_scale=1, pre=None):
+        """x + attn(GN(x), GN(context)) * control_scale (SUPIR_v0.py:138-152). The control feature changes every step,
+        so its K / V^T are projected every step (no cross-step cache)."""
+        assert self.mask is False
+        xh = to_nhwc(x)
+        B, H, W, C = xh.shape
+        xn = ops.groupnorm(xh, self.norm1.g32(), self.norm1.b32(), self.norm1.eps).view(B, H * W, C)
+        k, vt = pre if pre is not None else self.control_side(context)
         a = self.attn
-        T, Tk = H * W, cn.shape[1]
+        T, Tk = H * W, k.shape[1]
         q = ops.gemm(xn, a.to_q.w())
-        k = ops.gemm(cn, a.to_k.w())
-        vt = ops.gemm_t(cn, a.to_v.w(), None, B, Tk, (Tk + 63) // 64 * 64)
         o = ops.flash_attn(q, k, vt, B, a.heads, T, Tk)
         out = ops.gemm(o, a.to_out[0].w(), a.to_out[0].b32(), residual=xh.view(B, T, C), alpha=float(control_scale))
         return to_nchw(out.view(B, H, W, C))
@@ -144,19 +154,45 @@ class LightGLVUNet(UNetModel):
         h = self.middle_block(h, emb, context)
         return emb, hs, h
 
-    def forward(self, x, timesteps=None, context=None, y=None, control=None, control_scale=1, encoded=None, **kwargs):
+    def adapter_control_sides(self, control, on_done=None):
+        """Control-side half of every adapter (ZeroSFT gamma|beta maps, ZeroCrossAttn K / V^T) in the order the decoder
+        consumes them.  `on_done(idx, tensors)` is called after each one (ControlWrapper records a stream event there)."""
+        pre = {}
+        adapter_idx, control_idx = len(self.project_modules) - 1, len(control) - 1
+        pre[adapter_idx] = self.project_modules[adapter_idx].control_side(control[control_idx])
+        if on_done:
+            on_done(adapter_idx, pre[adapter_idx])
+        adapter_idx -= 1
+        control_idx -= 1
+        for module in self.output_blocks:
+            pre[adapter_idx] = self.project_modules[adapter_idx].control_side(control[control_idx])
+            if on_done:
+                on_done(adapter_idx, pre[adapter_idx])
+            adapter_idx -= 1
+            if len(module) == 3:
+                pre[adapter_idx] = self.project_modules[adapter_idx].control_side(control[control_idx])
+                if on_done:
+                    on_done(adapter_idx, pre[adapter_idx])
+                adapter_idx -= 1
+            control_idx -= 1
+        return pre
+
+    def forward(self, x, timesteps=None, context=None, y=None, control=None, control_scale=1, encoded=None,
+                adapter_pre=None, **kwargs):
         """SUPIR_v0.py:600-666. Skip concat replaced by ZeroSFT; ZeroCrossAttn before the Upsample of 3-child blocks.
         `encoded` = a precomputed encode() result."""
         emb, hs, h = encoded if encoded is not None else self.encode(x, timesteps, context, y)
         hs = list(hs)
         adapter_idx = len(self.project_modules) - 1
         control_idx = len(control) - 1
-        h = self.project_modules[adapter_idx](control[control_idx], h, control_scale=control_scale)
+        pre = adapter_pre if adapter_pre is not None else (lambda i: None)
+        h = self.project_modules[adapter_idx](control[control_idx], h, control_scale=control_scale, pre=pre(adapter_idx))
         adapter_idx -= 1
         control_idx -= 1
         for module in self.output_blocks:
             _h = hs.pop()
-            h = self.project_modules[adapter_idx](control[control_idx], _h, h, control_scale=control_scale)
+            h = self.project_modules[adapter_idx](control[control_idx], _h, h, control_scale=control_scale,
+                                                  pre=pre(adapter_idx))
             adapter_idx -= 1
             if len(module) == 3:
                 assert isinstance(module[2], Upsample)
@@ -167,7 +203,8 @@ class LightGLVUNet(UNetModel):
                         h = layer(h, context)
                     else:
                         h = layer(h)
-                h = self.project_modules[adapter_idx](control[control_idx], h, control_scale=control_scale)
+                h = self.project_modules[adapter_idx](control[control_idx], h, control_scale=control_scale,
+                                                      pre=pre(adapter_idx))
                 adapter_idx -= 1
                 h = module[2](h)
             else:

@@ -40,14 +40,34 @@ class ControlWrapper(nn.Module):
                 self._side = torch.cuda.Stream(device=x.device)
             side = self._side
             side.wait_stream(main)
+            ready = {}
             with torch.cuda.stream(side):
                 control = self.control_model(**ckw)
+                ev_control = torch.cuda.Event()
+                ev_control.record(side)
+
+                def on_done(idx, tensors):
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    ready[idx] = (tensors, ev)
+
+                # control-side halves of the adapters keep the side stream busy while the main stream runs the decoder
+                self.diffusion_model.adapter_control_sides(control, on_done)
             enc = self.diffusion_model.encode(x, timesteps=t, context=ctx, y=vec)
-            main.wait_stream(side)
+            main.wait_event(ev_control)
             for h in control:
                 h.record_stream(main)
+
+            def pre(idx):
+                tensors, ev = ready[idx]
+                main.wait_event(ev)
+                for tt in (tensors if isinstance(tensors, tuple) else (tensors,)):
+                    tt.record_stream(main)
+                return tensors
+
             out = self.diffusion_model(x, timesteps=t, context=ctx, y=vec, control=control, control_scale=control_scale,
-                                       encoded=enc)
+                                       encoded=enc, adapter_pre=pre)
+            side.wait_stream(main)   # join: nothing of this step is still running on the side stream afterwards
         else:
             control = self.control_model(**ckw)
             out = self.diffusion_model(x, timesteps=t, context=ctx, y=vec, control=control, control_scale=control_scale,
