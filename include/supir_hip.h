@@ -84,21 +84,30 @@ int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, 
                          int ldk, int ldvt, int ldo, float scale, void* stream);
 
 /* P[r][:] = softmax(S[r][:] * scale): fp32 scores -> bf16 probabilities (VAE mid-block single-head attention,
- * sgm/modules/diffusionmodules/model.py:177-192, 228-256; the score matrix itself comes from supir_gemm_bf16). */
-int supir_softmax_rows(const float* S, void* P, int rows, int T, long ld_s, long ld_p, float scale, void* stream);
+ * sgm/modules/diffusionmodules/model.py:177-192, 228-256; the score matrix itself comes from supir_gemm_bf16).
+ * Columns [T, Tpad) (K padding of the following P.V GEMM) are written as zeros. */
+int supir_softmax_rows(const float* S, void* P, int rows, int T, int Tpad, long ld_s, long ld_p, float scale,
+                       void* stream);
 
 /* GroupNorm(32 groups) over NHWC bf16 with fp32 statistics, optional SiLU, optional channel concat of two sources
  * (channels [0,C1) from x1, [C1,C) from x2), optional ZeroSFT modulation out = GN(x)*(mod_g+1)+mod_b and
  * control_scale lerp against the raw concat (x1raw / x2raw = the tensors before zero_conv; NULL -> x1 / x2 themselves;
  * with the same leading dimensions ld1 / ld2).
- * workspace: B*1024*64 floats.
+ * workspace: B*1024*64 floats.  given_mean_var: NULL (use this tensor's statistics) or externally pooled ones.
  * Replaces GroupNorm32 (sgm/modules/diffusionmodules/util.py:258-276), Normalize (attention.py:122-125,
  * model.py:48-51), nonlinearity/SiLU (model.py:44-46, openaimodel.py:261,296) and ZeroSFT.forward's tail
  * (SUPIR/modules/SUPIR_v0.py:110-113). */
 int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, const void* x2raw, int B, int HW, int C, int C1, int ld1,
                          int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
                          const void* mod_b, int ldm, float control_scale, void* out, int ldo, float* workspace,
-                         size_t workspace_bytes, void* stream);
+                         size_t workspace_bytes, const float* given_mean_var, void* stream);
+
+/* Statistics half of GroupNorm alone: sums_out[b][g] = (sum, sum of squares) over group g of batch b, fp32 [B][32][2].
+ * With given_mean_var ([B][32][2] = mean, biased variance) supir_groupnorm_nhwc skips its own statistics pass and
+ * normalises with the supplied ones.  Together they are the tiled VAE's cross-tile GroupNorm
+ * (SUPIR/utils/tilevae.py:511-553 get_var_mean / custom_group_norm, :599-648 GroupNormParam). */
+int supir_groupnorm_stats(const void* x1, const void* x2, int B, int HW, int C, int C1, int ld1, int ld2, float* sums_out,
+                          float* workspace, size_t workspace_bytes, void* stream);
 
 /* LayerNorm over the last dim of token-major bf16 [rows][ld]; gamma/beta fp32 [C]. (attention.py:437-439,465-486) */
 int supir_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, int ldx, int ldy,

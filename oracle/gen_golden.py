@@ -277,6 +277,34 @@ def main():
         gold["vae_z_stage1"] = (post.mean + post.std * pn) * 0.13025
         print("  vae x_stage1 std", xs1.std().item())
 
+        # -------------------------------------------------------------- tiled VAE (the reference's VAEHook, CPU)
+        import types
+        xf = types.ModuleType("xformers")
+        xf.ops = types.ModuleType("xformers.ops")
+
+        def _mea(q, k, v, attn_bias=None, op=None):     # [B*H, T, D] -> SDPA (what xformers computes)
+            return torch.nn.functional.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+
+        xf.ops.memory_efficient_attention = _mea
+        sys.modules["xformers"], sys.modules["xformers.ops"] = xf, xf.ops
+        from SUPIR.utils import devices as ref_devices
+        ref_devices.device = torch.device("cpu")
+        ref_devices.get_optimal_device = lambda: torch.device("cpu")
+        from SUPIR.utils import tilevae as TV
+        TV.xformers = xf
+        TV.devices.device = torch.device("cpu")
+        for net in (denc, dec):
+            net.original_forward = net.forward
+            net.mid.attn_1.attention_op = None   # attribute of MemoryEfficientAttnBlock (attn_type vanilla-xformers)
+        with R.quiet():
+            img_t = synth_tensor("img_tiled", (1, 3, 192, 160), scale=0.5)
+            gold["tiled_enc_192x160_t64"] = TV.VAEHook(denc, 64, is_decoder=False, fast_decoder=False, fast_encoder=False,
+                                                       color_fix=False, to_gpu=False)(img_t).clone()
+            z_t = synth_tensor("z_tiled", (1, 4, 40, 32), scale=1.0)
+            gold["tiled_dec_40x32_t8"] = TV.VAEHook(dec, 8, is_decoder=True, fast_decoder=False, fast_encoder=False,
+                                                    color_fix=False, to_gpu=False)(z_t).clone()
+        print("  tiled enc", tuple(gold["tiled_enc_192x160_t64"].shape), "tiled dec", tuple(gold["tiled_dec_40x32_t8"].shape))
+
         # colour fix
         sys.modules["torchvision.transforms"].ToTensor = lambda: None
         from SUPIR.utils.colorfix import wavelet_reconstruction

@@ -509,3 +509,124 @@ def wavelet_reconstruction(content, style):
     ch, _ = decomp(content)
     _, sl = decomp(style)
     return ch + sl
+
+
+# ----------------------------------------------------------------------------------------------- tiled VAE
+def _best_tile(lowerbound, upperbound):
+    """VAEHook.get_best_tile_size (SUPIR/utils/tilevae.py:702-715)."""
+    divider = 32
+    while divider >= 2:
+        rem = lowerbound % divider
+        if rem == 0:
+            return lowerbound
+        cand = lowerbound - rem + divider
+        if cand <= upperbound:
+            return cand
+        divider //= 2
+    return lowerbound
+
+
+def vae_split_tiles(h, w, tile_size, pad, is_decoder):
+    """VAEHook.split_tiles (tilevae.py:717-774); bbox = [x1, x2, y1, y2]."""
+    nh = max(math.ceil((h - 2 * pad) / tile_size), 1)
+    nw = max(math.ceil((w - 2 * pad) / tile_size), 1)
+    rth = _best_tile(math.ceil((h - 2 * pad) / nh), tile_size)
+    rtw = _best_tile(math.ceil((w - 2 * pad) / nw), tile_size)
+    in_b, out_b = [], []
+    for i in range(nh):
+        for j in range(nw):
+            ib = [pad + j * rtw, min(pad + (j + 1) * rtw, w), pad + i * rth, min(pad + (i + 1) * rth, h)]
+            ob = [ib[0] if ib[0] > pad else 0, ib[1] if ib[1] < w - pad else w,
+                  ib[2] if ib[2] > pad else 0, ib[3] if ib[3] < h - pad else h]
+            out_b.append([x * 8 if is_decoder else x // 8 for x in ob])
+            in_b.append([max(0, ib[0] - pad), min(w, ib[1] + pad), max(0, ib[2] - pad), min(h, ib[3] + pad)])
+    return in_b, out_b
+
+
+def _pooled_gn(sd, p, tiles, silu):
+    """GroupNormParam.add_tile / summary + custom_group_norm (tilevae.py:599-648, 524-553): pixel-weighted mean of the
+    per-tile biased variances and means per (batch, group); eps 1e-6."""
+    vs, ms, px = [], [], []
+    for t in tiles:
+        b, c = t.shape[:2]
+        r = t.reshape(1, b * 32, c // 32, *t.shape[2:])
+        v, m = torch.var_mean(r, dim=[0, 2, 3, 4], unbiased=False)
+        vs.append(v)
+        ms.append(m)
+        px.append(t.shape[2] * t.shape[3])
+    w = torch.tensor(px, dtype=torch.float32, device=tiles[0].device) / max(px)
+    w = (w / w.sum()).unsqueeze(1)
+    var = (torch.vstack(vs) * w).sum(0)
+    mean = (torch.vstack(ms) * w).sum(0)
+    out = []
+    for t in tiles:
+        b, c = t.shape[:2]
+        r = t.reshape(1, b * 32, c // 32, *t.shape[2:])
+        o = F.batch_norm(r, mean, var, training=False, momentum=0, eps=1e-6).reshape(t.shape)
+        o = o * sd[p + ".weight"].view(1, -1, 1, 1) + sd[p + ".bias"].view(1, -1, 1, 1)
+        out.append(F.silu(o) if silu else o)
+    return out
+
+
+def _tiled_resblock(sd, p, tiles):
+    res = [_conv(sd, p + ".nin_shortcut", t, padding=0) for t in tiles] if (p + ".nin_shortcut.weight") in sd else tiles
+    h = [_conv(sd, p + ".conv1", t) for t in _pooled_gn(sd, p + ".norm1", tiles, True)]
+    h = [_conv(sd, p + ".conv2", t) for t in _pooled_gn(sd, p + ".norm2", h, True)]
+    return [a + b for a, b in zip(h, res)]
+
+
+def _tiled_attn(sd, p, tiles):
+    out = []
+    for t, n in zip(tiles, _pooled_gn(sd, p + ".norm", tiles, False)):
+        q, k, v = (_conv(sd, f"{p}.{m}", n, padding=0) for m in ("q", "k", "v"))
+        b, c, h, w = q.shape
+        q, k, v = (x.reshape(b, c, h * w).permute(0, 2, 1)[:, None] for x in (q, k, v))
+        o = F.scaled_dot_product_attention(q, k, v)[:, 0].permute(0, 2, 1).reshape(b, c, h, w)
+        out.append(t + _conv(sd, p + ".proj_out", o, padding=0))
+    return out
+
+
+def vae_tiled_forward(sd, z, p, tile_size, is_decoder):
+    """VAEHook.__call__ / vae_tile_forward (tilevae.py:688-700, 821-970) with fast modes off, executed layer-major."""
+    pad = 11 if is_decoder else 32
+    H, W = z.shape[2], z.shape[3]
+    if max(H, W) <= pad * 2 + tile_size:
+        return vae_decoder(sd, z, p) if is_decoder else vae_encoder(sd, z, p)
+    in_b, out_b = vae_split_tiles(H, W, tile_size, pad, is_decoder)
+    tiles = [_conv(sd, p + "conv_in", z[:, :, b[2]:b[3], b[0]:b[1]]) for b in in_b]
+    nlev = 0
+    key = "up" if is_decoder else "down"
+    while f"{p}{key}.{nlev}.block.0.norm1.weight" in sd:
+        nlev += 1
+
+    def mid(ts):
+        ts = _tiled_resblock(sd, p + "mid.block_1", ts)
+        ts = _tiled_attn(sd, p + "mid.attn_1", ts)
+        return _tiled_resblock(sd, p + "mid.block_2", ts)
+
+    if is_decoder:
+        tiles = mid(tiles)
+        for lvl in reversed(range(nlev)):
+            blk = 0
+            while f"{p}up.{lvl}.block.{blk}.norm1.weight" in sd:
+                tiles = _tiled_resblock(sd, f"{p}up.{lvl}.block.{blk}", tiles)
+                blk += 1
+            if f"{p}up.{lvl}.upsample.conv.weight" in sd:
+                tiles = [_conv(sd, f"{p}up.{lvl}.upsample.conv", F.interpolate(t, scale_factor=2.0, mode="nearest")) for t in tiles]
+    else:
+        for lvl in range(nlev):
+            blk = 0
+            while f"{p}down.{lvl}.block.{blk}.norm1.weight" in sd:
+                tiles = _tiled_resblock(sd, f"{p}down.{lvl}.block.{blk}", tiles)
+                blk += 1
+            if f"{p}down.{lvl}.downsample.conv.weight" in sd:
+                tiles = [_conv(sd, f"{p}down.{lvl}.downsample.conv", F.pad(t, (0, 1, 0, 1)), stride=2, padding=0) for t in tiles]
+        tiles = mid(tiles)
+    outs = [_conv(sd, p + "conv_out", t) for t in _pooled_gn(sd, p + "norm_out", tiles, True)]
+    oh, ow = (H * 8, W * 8) if is_decoder else (H // 8, W // 8)
+    res = torch.zeros(z.shape[0], outs[0].shape[1], oh, ow, dtype=outs[0].dtype, device=z.device)
+    for o, ib, ob in zip(outs, in_b, out_b):
+        padded = [i * 8 if is_decoder else i // 8 for i in ib]
+        m = [ob[i] - padded[i] for i in range(4)]
+        res[:, :, ob[2]:ob[3], ob[0]:ob[1]] = o[:, :, m[2]:o.size(2) + m[3], m[0]:o.size(3) + m[1]]
+    return res

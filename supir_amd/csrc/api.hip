@@ -66,21 +66,33 @@ int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, 
     return supir_attn_launch(a, (hipStream_t)stream);
 }
 
-int supir_softmax_rows(const float* S, void* P, int rows, int T, long ld_s, long ld_p, float scale, void* stream) {
+int supir_softmax_rows(const float* S, void* P, int rows, int T, int Tpad, long ld_s, long ld_p, float scale,
+                       void* stream) {
     if (!S || !P) return SUPIR_ERR_ARG;
-    return supir_softmax_rows_launch(S, (bf16_t*)P, rows, T, ld_s, ld_p, scale, (hipStream_t)stream);
+    return supir_softmax_rows_launch(S, (bf16_t*)P, rows, T, Tpad, ld_s, ld_p, scale, (hipStream_t)stream);
+}
+
+int supir_groupnorm_stats(const void* x1, const void* x2, int B, int HW, int C, int C1, int ld1, int ld2, float* sums_out,
+                          float* workspace, size_t workspace_bytes, void* stream) {
+    if (!x1 || !sums_out || !workspace) return SUPIR_ERR_ARG;
+    if (C1 <= 0 || C1 > C) return SUPIR_ERR_ARG;
+    if (workspace_bytes < (size_t)B * 1024 * 64 * sizeof(float)) return SUPIR_ERR_ARG;
+    GnArgs a{};
+    a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.partial = workspace;
+    a.B = B; a.HW = HW; a.C = C; a.C1 = C1; a.ld1 = ld1; a.ld2 = ld2;
+    return supir_groupnorm_stats_launch(a, sums_out, (hipStream_t)stream);
 }
 
 int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, const void* x2raw, int B, int HW, int C, int C1, int ld1,
                          int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
                          const void* mod_b, int ldm, float control_scale, void* out, int ldo, float* workspace,
-                         size_t workspace_bytes, void* stream) {
+                         size_t workspace_bytes, const float* given_mean_var, void* stream) {
     if (!x1 || !gamma || !beta || !out || !workspace) return SUPIR_ERR_ARG;
     if (C1 <= 0 || C1 > C) return SUPIR_ERR_ARG;
     if (workspace_bytes < (size_t)B * 1024 * 64 * sizeof(float)) return SUPIR_ERR_ARG;
     GnArgs a{};
     a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.x1raw = (const bf16_t*)x1raw; a.x2raw = (const bf16_t*)x2raw;
-    a.partial = workspace; a.gamma = gamma; a.beta = beta;
+    a.partial = workspace; a.gamma = gamma; a.beta = beta; a.given = given_mean_var;
     a.mod_g = (const bf16_t*)mod_g; a.mod_b = (const bf16_t*)mod_b; a.out = (bf16_t*)out;
     a.B = B; a.HW = HW; a.C = C; a.C1 = C1; a.ld1 = ld1; a.ld2 = ld2; a.ldm = ldm; a.ldo = ldo;
     a.act = act; a.eps = eps; a.cscale = control_scale;

@@ -189,7 +189,8 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
 // sgm/modules/diffusionmodules/model.py:177-192, 228-256). With 288 GB of HBM the [T][T] score matrix is simply
 // materialised in fp32 by the GEMM kernel (out_mode 1); this kernel turns each fp32 row into bf16 probabilities.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
-                                                            int T, long lds_, long ldp, float scale) {
+                                                            int T, int Tpad, long lds_, long ldp, float scale) {
+    // columns [0, T) are the keys; [T, Tpad) is K-padding of the following P.V GEMM and is written as exact zeros
     __shared__ float red[8];
     const float* s = S + (size_t)blockIdx.x * lds_;
     bf16_t* pr = P + (size_t)blockIdx.x * ldp;
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     float mx = -INFINITY;
     for (int i = tid * 4; i < T; i += 1024) {
         const f32x4 v = *(const f32x4*)(s + i);
-        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (i + e < T) mx = fmaxf(mx, v[e]);
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -207,24 +210,26 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int i = tid * 4; i < T; i += 1024) {
         const f32x4 v = *(const f32x4*)(s + i);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sum += __expf((v[e] - mx) * scale);
+        for (int e = 0; e < 4; ++e)
+            if (i + e < T) sum += __expf((v[e] - mx) * scale);
     }
     sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-    for (int i = tid * 4; i < T; i += 1024) {
+    for (int i = tid * 4; i < Tpad; i += 1024) {
         const f32x4 v = *(const f32x4*)(s + i);
         u16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(__expf((v[e] - mx) * scale) * inv);
+        for (int e = 0; e < 4; ++e) o[e] = (i + e < T) ? f2bf(__expf((v[e] - mx) * scale) * inv) : (u16)0;
         *(u16x4*)(pr + i) = o;
     }
 }
 
-int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, long lds_, long ldp, float scale,
+int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, int Tpad, long lds_, long ldp, float scale,
                               hipStream_t st) {
-    if (rows <= 0 || T <= 0 || T % 4 != 0 || lds_ % 4 != 0 || ldp % 4 != 0) return SUPIR_ERR_SHAPE;
-    SUPIR_LAUNCH(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, S, P, T, lds_, ldp, scale);
+    if (rows <= 0 || T <= 0 || Tpad < T || Tpad % 4 != 0 || lds_ % 4 != 0 || ldp % 4 != 0 || lds_ < Tpad || ldp < Tpad)
+        return SUPIR_ERR_SHAPE;
+    SUPIR_LAUNCH(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, S, P, T, Tpad, lds_, ldp, scale);
     return SUPIR_LAUNCH_STATUS();
 }

@@ -35,6 +35,7 @@ struct GnArgs {
     const bf16_t* x1raw;  // ZeroSFT lerp only: raw counterpart of x1 (null -> x1 itself)
     const bf16_t* x2raw;  // ZeroSFT lerp only: un-projected skip (h before + zero_conv(c)); null -> x2 itself
     float* partial;     // [B][nchunk][32][2]  (sum, sumsq)
+    const float* given; // optional [B][32][2] (mean, var): normalise with these instead of this tensor's own statistics
     const float* gamma; // [C]
     const float* beta;  // [C]
     const bf16_t* mod_g;  // [B][HW][ldm] ZeroSFT gamma map or null
@@ -51,8 +52,10 @@ struct GnArgs {
 int supir_gemm_select_tile(int M, int N, int act, int force_tile);
 int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile);
 int supir_attn_launch(const AttnArgs& a, hipStream_t st);
-int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, long lds_, long ldp, float scale, hipStream_t st);
+int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, int Tpad, long lds_, long ldp, float scale,
+                              hipStream_t st);
 int supir_groupnorm_launch(GnArgs a, hipStream_t st);
+int supir_groupnorm_stats_launch(GnArgs a, float* sums_out, hipStream_t st);
 int supir_layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int rows, int C, int ldx,
                            int ldy, float eps, hipStream_t st);
 int supir_conv3x3_smallcin_launch(const float* x, const float* w, const float* bias, const bf16_t* add, bf16_t* out, int B,

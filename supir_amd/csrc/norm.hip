@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchun
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cv = p.C >> 3, cpg = p.C >> 5;
-    {
+    if (!p.given) {
         // all 256 threads reduce the per-chunk partials (fixed order -> reproducible): value v = tid&63, chunks sub, sub+4, ...
         const int v = tid & 63, sub = tid >> 6;
         double a = 0.0;
@@ -93,7 +93,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchun
         s_part[sub][v] = a;
     }
     __syncthreads();
-    if (tid < 32) {
+    if (p.given) {
+        // externally pooled statistics (tiled VAE: SUPIR/utils/tilevae.py:524-553 custom_group_norm)
+        if (tid < 32) {
+            s_mean[tid] = p.given[((size_t)b * 32 + tid) * 2];
+            s_rstd[tid] = rsqrtf(p.given[((size_t)b * 32 + tid) * 2 + 1] + p.eps);
+        }
+    } else if (tid < 32) {
         const double s = s_part[0][2 * tid] + s_part[1][2 * tid] + s_part[2][2 * tid] + s_part[3][2 * tid];
         const double q = s_part[0][2 * tid + 1] + s_part[1][2 * tid + 1] + s_part[2][2 * tid + 1] + s_part[3][2 * tid + 1];
         const double n = (double)p.HW * (double)cpg;
@@ -160,7 +166,7 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
     if (a.nchunk > 128 && (long)a.HW * a.C <= (8L << 20)) a.nchunk = 128;  // UNet-sized maps: fewer partials to re-reduce
     if (a.nchunk > 1024) a.nchunk = 1024;   // workspace contract: B * 1024 * 64 floats
     a.rows_per_chunk = (a.HW + a.nchunk - 1) / a.nchunk;
-    {
+    if (!a.given) {
         const int cv = a.C / 8, cvb = cv < 256 ? cv : 256, TY = 256 / cvb;
         const size_t smem_stats = (size_t)TY * a.C * 2 * sizeof(float);
         if (smem_stats > 64 * 1024) return SUPIR_ERR_SHAPE;
@@ -175,6 +181,30 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
     nca = (a.HW + rpc - 1) / rpc;
     const size_t smem = (size_t)a.C * 2 * sizeof(float);
     SUPIR_LAUNCH(gn_apply_kernel, dim3(nca, a.B), dim3(256), smem, st, a, nca, rpc);
+    return SUPIR_LAUNCH_STATUS();
+}
+
+// per-(batch, group) sum / sum of squares of one tensor: [B][32][2] fp32 (chunk partials reduced in fp64, fixed order)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums,
+                                                         int nchunk) {
+    const int b = blockIdx.x, v = threadIdx.x;
+    double a = 0.0;
+    for (int k = 0; k < nchunk; ++k) a += (double)partial[((size_t)b * nchunk + k) * 64 + v];
+    sums[(size_t)b * 64 + v] = (float)a;
+}
+
+int supir_groupnorm_stats_launch(GnArgs a, float* sums_out, hipStream_t st) {
+    if (a.B <= 0 || a.HW <= 0 || a.C <= 0 || a.C % 32 != 0 || a.C1 % 8 != 0 || a.ld1 % 8 != 0) return SUPIR_ERR_SHAPE;
+    if (a.C1 < a.C && (!a.x2 || a.ld2 % 8 != 0)) return SUPIR_ERR_ARG;
+    a.nchunk = a.HW / 64;
+    if (a.nchunk < 1) a.nchunk = 1;
+    if (a.nchunk > 1024) a.nchunk = 1024;
+    a.rows_per_chunk = (a.HW + a.nchunk - 1) / a.nchunk;
+    const int cv = a.C / 8, cvb = cv < 256 ? cv : 256, TY = 256 / cvb;
+    const size_t smem_stats = (size_t)TY * a.C * 2 * sizeof(float);
+    if (smem_stats > 64 * 1024) return SUPIR_ERR_SHAPE;
+    SUPIR_LAUNCH(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), smem_stats, st, a);
+    SUPIR_LAUNCH(gn_finalize_kernel, dim3(a.B), dim3(64), 0, st, a.partial, sums_out, a.nchunk);
     return SUPIR_LAUNCH_STATUS();
 }
 

@@ -135,6 +135,16 @@ class SUPIRModel(nn.Module):
             return samples, dict(z=_z, x_stage1=x_stage1, z_stage1=z_stage1, samples=_samples)
         return samples
 
+    def init_tile_vae(self, encoder_tile_size=512, decoder_tile_size=64):
+        """SUPIR_model.py:138-150: route the three VAE nets through the tiled forward (test.py --use_tile_vae)."""
+        from ..utils.tilevae import VAEHook
+        fs = self.first_stage_model
+        for net, size, dec in ((fs.denoise_encoder, encoder_tile_size, False), (fs.encoder, encoder_tile_size, False),
+                               (fs.decoder, decoder_tile_size, True)):
+            net.original_forward = net.forward
+            net.forward = VAEHook(net, size, is_decoder=dec, fast_decoder=False, fast_encoder=False, color_fix=False,
+                                  to_gpu=True)
+
     def prepare_condition(self, _z, p, p_p, n_p, N):
         if self.conditioner is None:
             raise RuntimeError("no text conditioner attached (out of scope: SURVEY.md section 2); pass cond=(c, uc) with "

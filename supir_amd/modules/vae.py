@@ -51,21 +51,31 @@ class AttnBlock(nn.Module):
         self.v = Linear(in_channels, in_channels, conv1x1=True)
         self.proj_out = Linear(in_channels, in_channels, conv1x1=True)
 
+    def attend(self, n):
+        """n: normalised tokens [B, T, C] bf16 -> proj_out-less attention output [B, T, C].  Any T: the key axis is padded
+        to a multiple of 64 with zero K rows / zero V^T columns and the softmax masks the padding."""
+        B, T, C = n.shape
+        Tp = (T + 63) // 64 * 64
+        q = ops.gemm(n, self.q.w(), self.q.b32())
+        if Tp == T:
+            k = ops.gemm(n, self.k.w(), self.k.b32())
+        else:
+            k = torch.zeros(B, Tp, C, dtype=BF16, device=n.device)
+            ops.gemm(n, self.k.w(), self.k.b32(), out=k[:, :T])
+        vt = ops.gemm_t(n, self.v.w(), self.v.b32(), B, T, Tp)       # [B, C, Tp], zero padded
+        o = torch.empty(B, T, C, dtype=BF16, device=n.device)
+        for b in range(B):
+            s = ops.gemm(q[b], k[b], out_dtype=torch.float32)       # [T, Tp] fp32 scores
+            p = ops.softmax_rows(s, C ** -0.5, valid=T)
+            ops.gemm(p, vt[b], out=o[b])                            # P [T,Tp] . (V^T [C,Tp])^T
+        return o
+
     def forward(self, x, **kwargs):
         xh = to_nhwc(x)
         B, H, W, C = xh.shape
         T = H * W
-        if T % 64 != 0:
-            raise ValueError("VAE attention needs H*W % 64 == 0 (image sides are multiples of 64 px: SUPIR/util.py:78-79)")
         n = ops.groupnorm(xh, self.norm.g32(), self.norm.b32(), self.norm.eps).view(B, T, C)
-        q = ops.gemm(n, self.q.w(), self.q.b32())
-        k = ops.gemm(n, self.k.w(), self.k.b32())
-        vt = ops.gemm_t(n, self.v.w(), self.v.b32(), B, T, T)       # [B, C, T]
-        o = torch.empty(B, T, C, dtype=BF16, device=xh.device)
-        for b in range(B):
-            s = ops.gemm(q[b], k[b], out_dtype=torch.float32)       # [T, T] fp32 scores
-            p = ops.softmax_rows(s, C ** -0.5)
-            ops.gemm(p, vt[b], out=o[b])                            # P [T,T] . (V^T [C,T])^T
+        o = self.attend(n)
         out = ops.gemm(o, self.proj_out.w(), self.proj_out.b32(), residual=xh.view(B, T, C))
         return to_nchw(out.view(B, H, W, C))
 

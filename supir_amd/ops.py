@@ -278,23 +278,39 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None):
     return out
 
 
-def softmax_rows(s, scale, out=None):
+def softmax_rows(s, scale, out=None, valid=None):
+    """softmax over the first `valid` columns of fp32 scores [rows, Tpad]; remaining columns of the bf16 output are zero."""
     lib = _lib.load()
     _check_dev(s)
-    rows, T = s.shape
+    rows, Tp = s.shape
+    T = Tp if valid is None else valid
     assert s.dtype == torch.float32 and s.stride(1) == 1
     if out is None:
-        out = torch.empty(rows, T, dtype=BF16, device=s.device)
+        out = torch.empty(rows, Tp, dtype=BF16, device=s.device)
     ev = _ev()
-    rc = lib.supir_softmax_rows(s.data_ptr(), out.data_ptr(), rows, T, s.stride(0), out.stride(0), scale, _stream())
+    rc = lib.supir_softmax_rows(s.data_ptr(), out.data_ptr(), rows, T, Tp, s.stride(0), out.stride(0), scale, _stream())
     _lib.check(rc, "supir_softmax_rows")
     _rec("softmax", 0, 6.0 * rows * T, ev)
     return out
 
 
 # --------------------------------------------------------------------------------------------- norms
+def groupnorm_stats(x):
+    """(sum, sum of squares) per (batch, group) of a channels-last tensor: fp32 [B, 32, 2]."""
+    lib = _lib.load()
+    _check_dev(x)
+    B = x.shape[0]
+    HW = int(math.prod(x.shape[1:-1]))
+    _, C, ld = _rows_ld(x)
+    ws = _gn_workspace(B, x.device)
+    out = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
+    rc = lib.supir_groupnorm_stats(x.data_ptr(), 0, B, HW, C, C, ld, 0, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
+    _lib.check(rc, "supir_groupnorm_stats")
+    return out
+
+
 def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=None, control_scale=1.0, x1raw=None,
-              x2raw=None, out=None):
+              x2raw=None, out=None, given=None):
     """GroupNorm(32) over channels-last x (optionally the channel concat [x | x2]); see supir_groupnorm_nhwc."""
     lib = _lib.load()
     _check_dev(x, gamma, beta)
@@ -320,7 +336,7 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
     ev = _ev()
     rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
                                   beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
-                                  out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _stream())
+                                  out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _p(given), _stream())
     _lib.check(rc, "supir_groupnorm_nhwc")
     n = B * HW * C
     _rec("groupnorm", 0, 2.0 * n * (2 + (2 if mod_g is not None else 0)), ev, B=B, HW=HW, C=C)

@@ -294,3 +294,49 @@ def test_errors_are_loud():
         ops.gemm(a, w)
     with pytest.raises(SupirHipError):
         ops.gemm(a.cpu(), w.cpu())
+
+
+def test_softmax_rows_padded():
+    rows, T, Tp = 50, 7396 // 4, 1856  # T = 1849 (not a multiple of 4), padded to a multiple of 64
+    s = rnd(rows, Tp, scale=3.0)
+    out = ops.softmax_rows(s, 512 ** -0.5, valid=T)
+    ref = torch.zeros_like(s)
+    ref[:, :T] = torch.softmax(s[:, :T] * 512 ** -0.5, dim=-1)
+    check(out, ref, name="softmax-padded")
+    assert out[:, T:].abs().max().item() == 0.0
+
+
+def test_groupnorm_stats_and_given():
+    """Statistics-only pass and normalisation with externally supplied (pooled) statistics: the tiled-VAE GroupNorm
+    (SUPIR/utils/tilevae.py:511-553)."""
+    B, H, W, C = 2, 13, 9, 256
+    x = (rnd(B, H, W, C) * 1.3 + 0.4).to(BF)
+    gamma = rnd(C, seed=1) * 0.2 + 1.0
+    beta = rnd(C, seed=2) * 0.2
+    st = ops.groupnorm_stats(x)
+    xf = x.float().reshape(B, H * W, 32, C // 32)
+    check(st[..., 0], xf.sum(dim=(1, 3)), rel=1e-5, name="gn-sum")
+    check(st[..., 1], (xf * xf).sum(dim=(1, 3)), rel=1e-5, name="gn-sumsq")
+    mean = rnd(B, 32, seed=5) * 0.1 + 0.4
+    var = rnd(B, 32, seed=6).abs() + 0.5
+    given = torch.stack([mean, var], -1).contiguous()
+    out = ops.groupnorm(x, gamma, beta, 1e-6, silu=True, given=given)
+    r = x.float().reshape(B, H, W, 32, C // 32)
+    r = (r - mean.view(B, 1, 1, 32, 1)) / (var.view(B, 1, 1, 32, 1) + 1e-6).sqrt()
+    ref = F.silu(r.reshape(B, H, W, C) * gamma + beta)
+    check(out, ref, name="gn-given")
+
+
+def test_vae_attention_any_token_count():
+    from tests.helpers import build_vae
+    vae = build_vae(DEV)
+    att = vae.decoder.mid.attn_1
+    x = rnd(1, 512, 9, 7)  # 63 tokens
+    with torch.no_grad():
+        out = att(x)
+        n = F.group_norm(x.to(BF).float(), 32, att.norm.weight, att.norm.bias, 1e-6)
+        q, k, v = (F.conv2d(n, getattr(att, m).weight, getattr(att, m).bias) for m in "qkv")
+        q, k, v = (t.reshape(1, 512, 63).permute(0, 2, 1)[:, None] for t in (q, k, v))
+        o = F.scaled_dot_product_attention(q, k, v)[:, 0].permute(0, 2, 1).reshape(1, 512, 9, 7)
+        ref = x.to(BF).float() + F.conv2d(o, att.proj_out.weight, att.proj_out.bias)
+    check(out, ref, rel=1.5e-2, name="vae-attn-63")

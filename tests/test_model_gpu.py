@@ -245,3 +245,19 @@ def test_two_stream_overlap_is_bitwise_equal_to_serial(wrap):
         wrap.overlap_branches = True
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(c, c_ref)
+
+
+def test_tiled_vae_vs_reference_golden(g):
+    """Native tiled VAE (all tiles resident, layer-major, pooled GroupNorm kernels) vs the reference's VAEHook output."""
+    from supir_amd.utils.tilevae import VAEHook
+    vae = build_vae(DEV)
+    for net in (vae.denoise_encoder, vae.decoder):
+        net.original_forward = net.forward
+    with torch.no_grad():
+        enc = VAEHook(vae.denoise_encoder, 64, is_decoder=False)(T("img_tiled", (1, 3, 192, 160), scale=0.5))
+        dec = VAEHook(vae.decoder, 8, is_decoder=True)(T("z_tiled", (1, 4, 40, 32)))
+        tiny = VAEHook(vae.decoder, 64, is_decoder=True)(g["vae_z"].to(DEV) / 0.13025)   # falls through to the untiled net
+    e_e, e_d = rel_l2(enc, g["tiled_enc_192x160_t64"]), rel_l2(dec, g["tiled_dec_40x32_t8"])
+    print(f"tiled vae: encoder {e_e:.3e}, decoder {e_d:.3e}")
+    assert tuple(enc.shape) == (1, 8, 24, 20) and tuple(dec.shape) == (1, 3, 320, 256) and tuple(tiny.shape) == (1, 3, 64, 64)
+    assert e_e <= 2.5e-2 and e_d <= 2.5e-2

@@ -158,3 +158,18 @@ def test_vae(sd, g):
 def test_wavelet(g):
     out = O.wavelet_reconstruction(synth_tensor("wa", (1, 3, 64, 64)), synth_tensor("wb", (1, 3, 64, 64)))
     assert rel_l2(out, g["wavelet"]) <= 1e-6
+
+
+def test_tiled_vae(sd, g):
+    """oracle tiled VAE (layer-major restatement) vs the reference's VAEHook task-queue execution."""
+    with torch.no_grad():
+        enc = O.vae_tiled_forward(sd, synth_tensor("img_tiled", (1, 3, 192, 160), scale=0.5),
+                                  "first_stage_model.denoise_encoder.", 64, False)
+        assert rel_l2(enc, g["tiled_enc_192x160_t64"]) <= 5e-5
+        dec = O.vae_tiled_forward(sd, synth_tensor("z_tiled", (1, 4, 40, 32)), "first_stage_model.decoder.", 8, True)
+        assert rel_l2(dec, g["tiled_dec_40x32_t8"]) <= 5e-5
+        # tiling changes the result (pooled statistics, tile-local attention): must be checked against the TILED reference
+        full = O.vae_decoder(sd, synth_tensor("z_tiled", (1, 4, 40, 32)), "first_stage_model.decoder.")
+        assert rel_l2(dec, full) > 1e-3
+    assert O.vae_split_tiles(512, 512, 64, 11, True)[0][:2] == [[0, 86, 0, 86], [64, 150, 0, 86]]
+    assert len(O.vae_split_tiles(4096, 4096, 512, 32, False)[0]) == 64
