@@ -35,6 +35,7 @@ TARGET_MAP = {
     "sgm.modules.attention.BasicTransformerBlock": "supir_amd.modules.attention.BasicTransformerBlock",
     "sgm.modules.attention.CrossAttention": "supir_amd.modules.attention.CrossAttention",
     "sgm.modules.attention.MemoryEfficientCrossAttention": "supir_amd.modules.attention.MemoryEfficientCrossAttention",
+    "SUPIR.utils.tilevae.VAEHook": "supir_amd.utils.tilevae.VAEHook",
     "sgm.modules.diffusionmodules.model.Encoder": "supir_amd.modules.vae.Encoder",
     "sgm.modules.diffusionmodules.model.Decoder": "supir_amd.modules.vae.Decoder",
     "sgm.models.autoencoder.AutoencoderKL": "supir_amd.modules.vae.AutoencoderKL",
@@ -74,18 +75,27 @@ def install():
         for i in range(1, len(parts) + 1):
             name = ".".join(parts[:i])
             if name not in sys.modules:
-                m = types.ModuleType(name)
-                m.__path__ = []  # mark as package so sub-imports resolve through sys.modules
-                sys.modules[name] = m
-                if i > 1:
-                    setattr(sys.modules[".".join(parts[:i - 1])], parts[i - 1], m)
+                try:  # a reference checkout on sys.path: patch its real module instead of shadowing it
+                    importlib.import_module(name)
+                except Exception:
+                    m = types.ModuleType(name)
+                    m.__path__ = []  # mark as package so sub-imports resolve through sys.modules
+                    sys.modules[name] = m
+                    if i > 1:
+                        setattr(sys.modules[".".join(parts[:i - 1])], parts[i - 1], m)
         setattr(sys.modules[mod_name], cls_name, obj)
         done.append(ref_path)
     util = sys.modules.get("sgm.util")
     if util is None:
-        util = types.ModuleType("sgm.util")
-        sys.modules["sgm.util"] = util
-        setattr(sys.modules["sgm"], "util", util)
-    util.instantiate_from_config = instantiate_from_config
+        try:
+            util = importlib.import_module("sgm.util")
+        except Exception:
+            util = types.ModuleType("sgm.util")
+            sys.modules["sgm.util"] = util
+            setattr(sys.modules["sgm"], "util", util)
+    # the reference resolves `target:` strings through sgm.util.get_obj_from_str (sgm/util.py:178-185): route it through
+    # TARGET_MAP so that modules which imported the function by name before install() are covered too
     util.get_obj_from_str = get_obj_from_str
+    if not hasattr(util, "instantiate_from_config") or getattr(util.instantiate_from_config, "__module__", "") != __name__:
+        util.instantiate_from_config = instantiate_from_config
     return done

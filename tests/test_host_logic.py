@@ -207,3 +207,24 @@ def test_karras_schedule_properties():
     s = S.get_sigmas_karras(8, 0.0292, 14.6146)
     assert s.shape == (9,) and s[-1] == 0 and abs(s[0].item() - 14.6146) < 1e-4 and abs(s[-2].item() - 0.0292) < 1e-5
     assert torch.all(s[:-1][1:] < s[:-1][:-1])
+
+
+def test_tiled_vae_tiling_matches_oracle_and_reference_counts():
+    from oracle import supir_oracle as O
+    from supir_amd.utils import tilevae as TV
+    for (h, w, ts, dec) in [(512, 512, 64, True), (4096, 4096, 512, False), (40, 32, 8, True), (192, 160, 64, False),
+                            (1024, 768, 512, False), (128, 128, 64, True)]:
+        pad = 11 if dec else 32
+        assert TV.split_tiles(h, w, ts, pad, dec) == O.vae_split_tiles(h, w, ts, pad, dec)
+    # config 3: 4096^2 -> 8x8 encoder tiles of 512 px, 8x8 decoder tiles of 64 latent px
+    assert len(TV.split_tiles(4096, 4096, 512, 32, False)[0]) == 64 and len(TV.split_tiles(512, 512, 64, 11, True)[0]) == 64
+
+
+def test_plugin_install_registers_reference_paths():
+    import importlib
+    import sys
+    done = plugin.install()
+    assert "SUPIR.modules.SUPIR_v0.LightGLVUNet" in done
+    from supir_amd.modules.supir_v0 import LightGLVUNet
+    assert importlib.import_module("SUPIR.modules.SUPIR_v0").LightGLVUNet is LightGLVUNet
+    assert sys.modules["sgm.util"].get_obj_from_str("sgm.modules.diffusionmodules.sampling.RestoreEDMSampler") is S.RestoreEDMSampler
