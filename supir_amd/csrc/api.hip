@@ -35,6 +35,32 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
     return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
 }
 
+int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                       const void* residual, int ldr, int act, int out_mode, int rows_per_batch, float alpha, int tile,
+                       float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
+                       const float* ln_colsum, float ln_eps, void* stream) {
+    if (!A || !W || !C) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 31) return SUPIR_ERR_ARG;
+    if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
+    if (ln_stats && (!ln_colsum || ln_slots <= 0 || ln_ld < ln_slots)) return SUPIR_ERR_ARG;
+    if (rowstats_out && (out_mode != 0 || act == 2 || rs_ld <= 0)) return SUPIR_ERR_ARG;
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
+    a.bias = bias; a.res = (const bf16_t*)residual;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr;
+    a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+    a.act = act; a.out_mode = out_mode; a.alpha = alpha;
+    a.rowstats_out = rowstats_out; a.rs_ld = rs_ld;
+    a.ln_stats = ln_stats; a.ln_ld = ln_ld; a.ln_slots = ln_slots; a.ln_colsum = ln_colsum; a.ln_eps = ln_eps;
+    if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0))) return SUPIR_ERR_SHAPE;
+    if (rowstats_out) {  // the slot index is tile_n * waves_n + wave_n: the caller's rs_ld must cover the tile actually used
+        const int sel = supir_gemm_select_tile(M, N, act, tile < 0 ? -1 : (tile & 7));
+        const int bn = (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128), wn = sel == 5 ? 4 : 2;
+        if (((N + bn - 1) / bn) * wn > rs_ld) return SUPIR_ERR_ARG;
+    }
+    return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
+}
+
 int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int Wd, int Cin, int ldx, int Cout,
                        int ldy, int OH, int OW, int stride, int pad_t, int pad_l, int upsample, const float* bias,
                        const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,

@@ -211,6 +211,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
     }
 
     // ------------------------------------------------------------------ epilogue
+    // LayerNorm folding: per-row mean / rstd of the A operand, reduced from the producer GEMM's per-wave-column partial
+    // sums (fixed order: reproducible).  Lane l31 of fragment row-block i owns row m0 + wm*WTM + i*32 + l31.
+    float ln_mean[MI], ln_rstd[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        ln_mean[i] = 0.f;
+        ln_rstd[i] = 1.f;
+    }
+    if (p.ln_stats) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            int m = m0 + wm * WTM + i * 32 + l31;
+            m = m < p.M ? m : p.M - 1;
+            const float* st = p.ln_stats + (size_t)m * p.ln_ld * 2;
+            float sm = 0.f, sq = 0.f;
+            for (int sl = 0; sl < p.ln_slots; ++sl) {
+                sm += st[2 * sl];
+                sq += st[2 * sl + 1];
+            }
+            const float inv = 1.0f / (float)p.K;
+            const float mean = sm * inv;
+            float var = sq * inv - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            ln_mean[i] = mean;
+            ln_rstd[i] = rsqrtf(var + p.ln_eps);
+        }
+    }
     if constexpr (TRANS) {
         // D[i = token][j = channel]: lane owns channel l31, tokens (r&3)+8*(r>>2)+4*half -> 4 consecutive tokens
         bf16_t* Cb = (bf16_t*)p.C;
@@ -219,17 +246,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int n = n0 + wn * WTN + j * 32 + l31;
-                if (n >= p.N) continue;
-                const float bz = p.bias ? p.bias[n] : 0.f;
+                const bool n_ok = n < p.N;
+                const int nc = n_ok ? n : p.N - 1;
+                const float bz = p.bias ? p.bias[nc] : 0.f;
+                const float cs = p.ln_stats ? p.ln_colsum[nc] : 0.f;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
+                    float val[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = acc[i][j][rg * 4 + e];
+                        if (p.ln_stats) {  // stats of token 8*rg + 4*half + e live in the lane with that l31
+                            const int src = 8 * rg + 4 * half + e;
+                            const float mu = __shfl(ln_mean[i], src, 64), rs = __shfl(ln_rstd[i], src, 64);
+                            a = rs * (a - mu * cs);
+                        }
+                        val[e] = p.alpha * (a + bz);
+                    }
                     const int m = m0 + wm * WTM + i * 32 + 8 * rg + 4 * half;
-                    if (m >= p.M) continue;
+                    if (!n_ok || m >= p.M) continue;
                     const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
                     if (m + 3 < p.M && t + 3 < p.rows_per_batch && ((t | p.ldc) & 3) == 0) {
                         u16x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = f2bf(p.alpha * (acc[i][j][rg * 4 + e] + bz));
+                        for (int e = 0; e < 4; ++e) o[e] = f2bf(val[e]);
                         *(u16x4*)(Cb + ((size_t)b * p.N + n) * p.ldc + t) = o;
                     } else {
 #pragma unroll
@@ -237,8 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
                             const int me = m + e;
                             if (me < p.M) {
                                 const int be = me / p.rows_per_batch, te = me - be * p.rows_per_batch;
-                                ((u16*)Cb)[((size_t)be * p.N + n) * p.ldc + te] =
-                                    f2bf(p.alpha * (acc[i][j][rg * 4 + e] + bz));
+                                ((u16*)Cb)[((size_t)be * p.N + n) * p.ldc + te] = f2bf(val[e]);
                             }
                         }
                     }
@@ -250,40 +289,52 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wm * WTM + i * 32 + l31;
-            if (m >= p.M) continue;
-            const int bidx = p.rowbias ? m / p.rows_per_batch : 0;
+            const bool m_ok = m < p.M;
+            const int bidx = (p.rowbias && m_ok) ? m / p.rows_per_batch : 0;
+            const float mu = ln_mean[i], rs = ln_rstd[i];
             if (p.act == 2) {
                 // GEGLU: fragment pair (value, gate) = (j even, j odd) inside the wave's 64 columns
                 if constexpr (NI == 2) {
+                    if (m_ok) {
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int nl = wn * 64 + 8 * rg + 4 * half;  // column inside the tile (each wave owns 64 columns)
-                        const int nv = n0 + nl, ng = n0 + nl + 32;   // interleaved weight rows
-                        if (ng >= p.N) continue;
-                        f32x4 bv = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-                        if (p.bias) { bv = *(const f32x4*)(p.bias + nv); bg = *(const f32x4*)(p.bias + ng); }
-                        u16x4 o;
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int nl = wn * 64 + 8 * rg + 4 * half;  // column inside the tile (each wave owns 64 columns)
+                            const int nv = n0 + nl, ng = n0 + nl + 32;   // interleaved weight rows
+                            if (ng >= p.N) continue;
+                            f32x4 bv = {0, 0, 0, 0}, bg = {0, 0, 0, 0}, cv = {0, 0, 0, 0}, cg = {0, 0, 0, 0};
+                            if (p.bias) { bv = *(const f32x4*)(p.bias + nv); bg = *(const f32x4*)(p.bias + ng); }
+                            if (p.ln_stats) { cv = *(const f32x4*)(p.ln_colsum + nv); cg = *(const f32x4*)(p.ln_colsum + ng); }
+                            u16x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = acc[i][0][rg * 4 + e] + bv[e];
-                            const float g = acc[i][1][rg * 4 + e] + bg[e];
-                            o[e] = f2bf(v * gelu_f(g));
+                            for (int e = 0; e < 4; ++e) {
+                                float v = acc[i][0][rg * 4 + e], g = acc[i][1][rg * 4 + e];
+                                if (p.ln_stats) { v = rs * (v - mu * cv[e]); g = rs * (g - mu * cg[e]); }
+                                v += bv[e];
+                                g += bg[e];
+                                o[e] = f2bf(v * gelu_f(g));
+                            }
+                            const int no = (n0 >> 1) + wn * 32 + 8 * rg + 4 * half;
+                            *(u16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
                         }
-                        const int no = (n0 >> 1) + wn * 32 + 8 * rg + 4 * half;
-                        *(u16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
                     }
                 }
                 continue;
             }
+            float rsum = 0.f, rsq = 0.f;   // row statistics of what this wave writes (for the NEXT LayerNorm)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int n = n0 + wn * WTN + j * 32 + 8 * rg + 4 * half;
-                    if (n >= p.N) continue;
+                    if (n >= p.N || !m_ok) continue;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
+                    if (p.ln_stats) {
+                        const f32x4 cs = *(const f32x4*)(p.ln_colsum + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rs * (v[e] - mu * cs[e]);
+                    }
                     if (p.bias) {
                         const f32x4 bz = *(const f32x4*)(p.bias + n);
                         v += bz;
@@ -309,10 +360,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
                     } else {
                         u16x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = f2bf(v[e]);
+                            const float r = bf2f(o[e]);
+                            rsum += r;
+                            rsq += r * r;
+                        }
                         *(u16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
                     }
                 }
+            if (p.rowstats_out) {
+                rsum += __shfl_xor(rsum, 32, 64);
+                rsq += __shfl_xor(rsq, 32, 64);
+                if (half == 0 && m_ok) {
+                    float* dst = p.rowstats_out + ((size_t)m * p.rs_ld + tile_n * WN + wn) * 2;
+                    dst[0] = rsum;
+                    dst[1] = rsq;
+                }
+            }
         }
     }
 }

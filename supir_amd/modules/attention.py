@@ -14,6 +14,9 @@ from .. import weights as Wt
 from .base import BF16, Linear, Norm, Normalize, Passthrough, Prep, to_nchw, to_nhwc, tokens_bf16
 
 
+FOLD_LAYERNORM = True   # SpatialTransformer runs its blocks through BasicTransformerBlock.forward_fused
+
+
 def _pad64(t):
     return (t + 63) // 64 * 64
 
@@ -125,6 +128,54 @@ class BasicTransformerBlock(nn.Module):
         self.norm1 = Norm(dim, 1e-5)
         self.norm2 = Norm(dim, 1e-5)
         self.norm3 = Norm(dim, 1e-5)
+        object.__setattr__(self, "_fold", Prep())
+
+    # ------------------------------------------------------------------ LayerNorm-folded fast path
+    def _folded(self):
+        """Weights of the four LayerNorm consumers with the norm folded in (W' = gamma (.) W, column sums, b')."""
+        a1, a2, ff = self.attn1, self.attn2, self.ff.net[0]
+        srcs = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias,
+                a1.to_q.weight, a1.to_k.weight, a1.to_v.weight, a2.to_q.weight, ff.proj.weight, ff.proj.bias)
+
+        def build():
+            n1, n2, n3 = self.norm1, self.norm2, self.norm3
+            wqk = torch.cat([a1.to_q.weight.detach().float(), a1.to_k.weight.detach().float()], 0)
+            qk = Wt.fold_layernorm(wqk, None, n1.weight, n1.bias)
+            v = Wt.fold_layernorm(a1.to_v.weight, None, n1.weight, n1.bias)
+            q2 = Wt.fold_layernorm(a2.to_q.weight, None, n2.weight, n2.bias)
+            gw, gc, gb = Wt.fold_layernorm(ff.proj.weight, ff.proj.bias, n3.weight, n3.bias)
+            gwi, gbi = Wt.interleave_geglu(gw, gb)
+            _, gci = Wt.interleave_geglu(gw, gc)
+            return dict(qk=qk, v=v, q2=q2, geglu=(gwi, gci, gbi))
+
+        return self._fold.get(srcs, build)
+
+    def forward_fused(self, x, stats, context):
+        """Token stream x [B,T,C] (updated in place) + the RowStats its producer emitted -> (x, RowStats).
+        No LayerNorm launches: every norm is folded into the GEMM that consumes it (supir_gemm_bf16_ln); each residual
+        GEMM emits the row statistics the next norm needs."""
+        f = self._folded()
+        B, T, C = x.shape
+        H = self.attn1.heads
+        inner = H * 64
+        e1, e2, e3 = self.norm1.eps, self.norm2.eps, self.norm3.eps
+        w, cs, b = f["qk"]
+        qk = ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e1)
+        w, cs, b = f["v"]
+        vt = ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e1, trans=(B, T, _pad64(T)))
+        a = ops.flash_attn(qk[:, :, :inner], qk[:, :, inner:], vt, B, H, T, T)
+        o1 = self.attn1.to_out[0]
+        x, stats = ops.gemm_ln(a, o1.w(), o1.b32(), residual=x, out=x, emit_stats=True)
+        w, cs, b = f["q2"]
+        q = ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e2)
+        k, vt2 = self.attn2._context_kv(context)
+        a = ops.flash_attn(q, k, vt2, B, H, T, k.shape[1])
+        o2 = self.attn2.to_out[0]
+        x, stats = ops.gemm_ln(a, o2.w(), o2.b32(), residual=x, out=x, emit_stats=True)
+        w, cs, b = f["geglu"]
+        g = ops.gemm_ln(x, w, b, act=2, ln=stats, colsum=cs, ln_eps=e3)
+        l2 = self.ff.net[2]
+        return ops.gemm_ln(g, l2.w(), l2.b32(), residual=x, out=x, emit_stats=True)
 
     def forward(self, x, context=None, additional_tokens=None, n_times_crossframe_attn_in_self=0, inplace=False):
         """x [B,T,C] -> x + attn1(LN x) ... (attention.py:465-486). inplace=True updates the token stream in place
@@ -164,8 +215,15 @@ class SpatialTransformer(nn.Module):
         xh = to_nhwc(x)
         B, H, W, C = xh.shape
         n = ops.groupnorm(xh, self.norm.g32(), self.norm.b32(), self.norm.eps)
-        t = ops.gemm(n.view(B, H * W, C), self.proj_in.w(), self.proj_in.b32())
-        for blk in self.transformer_blocks:
-            t = blk(t, context=context, inplace=True)
+        fused = FOLD_LAYERNORM and context is not None and all(
+            (not b.disable_self_attn) and (not b.attn2.is_self) for b in self.transformer_blocks)
+        if fused:
+            t, stats = ops.gemm_ln(n.view(B, H * W, C), self.proj_in.w(), self.proj_in.b32(), emit_stats=True)
+            for blk in self.transformer_blocks:
+                t, stats = blk.forward_fused(t, stats, context)
+        else:
+            t = ops.gemm(n.view(B, H * W, C), self.proj_in.w(), self.proj_in.b32())
+            for blk in self.transformer_blocks:
+                t = blk(t, context=context, inplace=True)
         out = ops.gemm(t, self.proj_out.w(), self.proj_out.b32(), residual=xh.view(B, H * W, C))
         return to_nchw(out.view(B, H, W, C))

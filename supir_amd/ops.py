@@ -195,6 +195,76 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
     return out
 
 
+_TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2)}
+MAX_SLOTS_PER = 32   # rowstats slot granularity: one slot per 32 output columns at the finest (64-wide tile, 2 wave columns)
+
+
+class RowStats:
+    """Per-row (sum, sum of squares) partials a producer GEMM left behind for the LayerNorm folded into its consumers."""
+    __slots__ = ("buf", "slots", "ld")
+
+    def __init__(self, buf, slots, ld):
+        self.buf, self.slots, self.ld = buf, slots, ld
+
+
+def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=-1, emit_stats=False, ln=None, colsum=None,
+            ln_eps=1e-5, trans=None):
+    """GEMM with LayerNorm folding (see supir_gemm_bf16_ln).  ln = RowStats of `a` (consumer side), emit_stats=True makes
+    this call a producer and returns (out, RowStats).  trans=(B, T, Tpad) selects the transposed (V^T) output."""
+    lib = _lib.load()
+    _check_dev(a, w)
+    M, K, lda = _rows_ld(a)
+    N = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous() and w.dtype == BF16 and a.dtype == BF16
+    n_out = N // 2 if act == 2 else N
+    if trans is not None:
+        B, T, Tpad = trans
+        assert M == B * T
+        if out is None:
+            out = torch.zeros(B, N, Tpad, dtype=BF16, device=a.device) if Tpad != T else \
+                torch.empty(B, N, Tpad, dtype=BF16, device=a.device)
+        ldc, om, rpb = Tpad, 2, T
+    else:
+        if out is None:
+            out = torch.empty(*a.shape[:-1], n_out, dtype=BF16, device=a.device)
+        _, _, ldc = _rows_ld(out)
+        om, rpb = 0, 0
+    ldr = 0
+    if residual is not None:
+        _, _, ldr = _rows_ld(residual)
+    stats = None
+    rs_ld = 0
+    if emit_stats:
+        rs_ld = (N + MAX_SLOTS_PER - 1) // MAX_SLOTS_PER
+        stats = torch.empty(M, rs_ld, 2, dtype=torch.float32, device=a.device)
+    ln_p, ln_ld, ln_slots = 0, 0, 0
+    if ln is not None:
+        ln_p, ln_ld, ln_slots = ln.buf.data_ptr(), ln.ld, ln.slots
+        assert colsum is not None and colsum.numel() == N
+
+    def launch(t):
+        return lib.supir_gemm_bf16_ln(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, ldc, _p(bias), _p(residual),
+                                      ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots, _p(colsum), ln_eps,
+                                      _stream())
+
+    if tile == -1:
+        key = ("gemm", M, N, K, act, om)
+        if residual is not None and residual.data_ptr() == out.data_ptr():
+            tile = _TUNE.get(key, -1)
+        else:
+            tile = _autotune(key, (0, 2, 4, 5, 6) if act == 2 else (0, 1, 2, 3, 4, 5, 6), launch)
+    ev = _ev()
+    rc = launch(tile)
+    _lib.check(rc, "supir_gemm_bf16_ln")
+    _rec("gemm_t" if trans is not None else "gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act,
+         tile=tile)
+    if emit_stats:
+        t_used = (tile & 7) if tile >= 0 else lib.supir_gemm_tile_for(M, N, act)
+        bn, wn = _TILE_BN_WN[t_used]
+        return out, RowStats(stats, ((N + bn - 1) // bn) * wn, rs_ld)
+    return out
+
+
 def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
     """Transposed projection: out[b][n][t] = (a[b*T+t] @ w[n]) (+bias); out is [B, N, Tpad] (zero padded)."""
     lib = _lib.load()

@@ -41,3 +41,16 @@ def interleave_geglu(w, b):
     if b is not None:
         bi = torch.stack([b[:n].reshape(n // 32, 32), b[n:].reshape(n // 32, 32)], dim=1).reshape(n2).contiguous()
     return wi, bi
+
+
+def fold_layernorm(w, bias, gamma, beta):
+    """LayerNorm folded into the following Linear: returns (W' = bf16(gamma (.) W) [N,K], colsum[n] = sum_k W'[n,k] (fp32,
+    from the ROUNDED W' so that the mean term cancels exactly), b'[n] = bias[n] + sum_k beta[k] W[n,k]).
+    LayerNorm(x).W^T + bias == rstd * (x.W'^T - mean*colsum) + b'  (supir_gemm_bf16_ln)."""
+    w32 = w.detach().float().reshape(w.shape[0], -1)
+    wp = (w32 * gamma.detach().float()[None, :]).to(BF16).contiguous()
+    colsum = wp.float().sum(dim=1).contiguous()
+    bp = w32 @ beta.detach().float()
+    if bias is not None:
+        bp = bp + bias.detach().float()
+    return wp, colsum, bp.contiguous()

@@ -340,3 +340,31 @@ def test_vae_attention_any_token_count():
         o = F.scaled_dot_product_attention(q, k, v)[:, 0].permute(0, 2, 1).reshape(1, 512, 9, 7)
         ref = x.to(BF).float() + F.conv2d(o, att.proj_out.weight, att.proj_out.bias)
     check(out, ref, rel=1.5e-2, name="vae-attn-63")
+
+
+@pytest.mark.parametrize("M,C,N", [(2048, 1280, 2560), (8192, 640, 640), (200, 320, 640), (77, 640, 1280)])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 3, 5])
+def test_gemm_layernorm_folding(M, C, N, tile):
+    """producer emits row statistics, consumer folds LayerNorm(x).W^T + b (supir_gemm_bf16_ln) -- vs LayerNorm then Linear."""
+    from supir_amd.weights import fold_layernorm
+    a = rnd(M, C).to(BF)
+    wp = rnd(C, C, scale=C ** -0.5, seed=1).to(BF)
+    res = (rnd(M, C, seed=3) * 2 + 0.5).to(BF)
+    x, st = ops.gemm_ln(a, wp, None, residual=res, emit_stats=True, tile=tile)
+    xr = a.float() @ wp.float().T + res.float()
+    check(x, xr, name="producer")
+    xs = x.float()
+    tot = st.buf[:, :st.slots].sum(dim=1)
+    check(tot[:, 0], xs.sum(-1), rel=1e-4, name="rowsum")
+    check(tot[:, 1], (xs * xs).sum(-1), rel=1e-4, name="rowsq")
+    gamma, beta = rnd(C, seed=4) * 0.2 + 1.0, rnd(C, seed=5) * 0.2
+    w = rnd(N, C, scale=C ** -0.5, seed=6)
+    bias = rnd(N, seed=7)
+    wf, cs, bf_ = fold_layernorm(w, bias, gamma, beta)
+    ref = F.layer_norm(xs, (C,), gamma, beta, 1e-5) @ w.to(BF).float().T + bias
+    out = ops.gemm_ln(x, wf, bf_, ln=st, colsum=cs, tile=tile)
+    check(out, ref, rel=6e-3, name="ln-fold")
+    B, T = (2, M // 2) if M % 2 == 0 else (1, M)
+    Tp = (T + 63) // 64 * 64
+    outt = ops.gemm_ln(x, wf, bf_, ln=st, colsum=cs, trans=(B, T, Tp), tile=tile)
+    check(outt[:, :, :T], ref.view(B, T, N).permute(0, 2, 1), rel=6e-3, name="ln-fold-T")
