@@ -62,17 +62,23 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
 
 /* supir_gemm_bf16 with LayerNorm folded in (BasicTransformerBlock, sgm/modules/attention.py:465-486: every nn.LayerNorm there
  * feeds an nn.Linear).  Two halves:
- *   producer  rowstats_out != NULL: besides C (bf16), writes per row m and per wave-column slot s the (sum, sum of squares)
- *             of the bf16 values it stored: rowstats_out[(m*rs_ld + s)*2 + {0,1}], s < ceil(N/BN)*waves_n of the tile used;
+ *   producer  rowstats_out != NULL: besides C (bf16), writes per row m and per column tile s the (sum, sum of squares)
+ *             of the bf16 values it stored: rowstats_out[(m*rs_ld + s)*2 + {0,1}], s < ceil(N/BN) of the tile used; rs_ld even;
  *   consumer  ln_stats != NULL: A is the UN-normalised token stream x [M][K]; with W' = gamma (.) W (folded by the caller),
  *             ln_colsum[n] = sum_k W'[n][k] and bias' = bias + W.beta, the result is
  *             rstd[m] * (x[m].W'[n] - mean[m]*ln_colsum[n]) + bias'[n] == LayerNorm(x)[m] . W[n] + bias[n],
- *             mean / rstd taken from the first ln_slots slots of ln_stats (row stride ln_ld), eps = ln_eps.
+ *             mean / rstd taken from the first ln_slots slots of ln_stats (row stride ln_ld), eps = ln_eps; or, with
+ *             ln_slots = 0, read directly from ln_stats = [M][2] (mean, rstd) produced by supir_rowstats_finalize.
  * No LayerNorm kernel, no normalised copy of x in HBM. */
 int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
                        const void* residual, int ldr, int act, int out_mode, int rows_per_batch, float alpha, int tile,
                        float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                        const float* ln_colsum, float ln_eps, void* stream);
+
+/* Reduce a producer's row-statistic partials [M][ld][2] to (mean, rstd) [M][2] over `dim` elements per row (fixed order).
+ * Consumers then pass ln_slots = 0 and ln_stats = that [M][2] array: two floats per row instead of `slots` partials. */
+int supir_rowstats_finalize(const float* partials, float* mean_rstd, int M, int ld, int slots, int dim, float eps,
+                            void* stream);
 
 /* Which tile (index into the table of csrc/gemm.hip) tile=-1 selects for an (M, N, act) problem: lets a profiler name the
  * kernel instantiation a launch used. Host-only, no GPU access. */

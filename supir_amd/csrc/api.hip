@@ -42,7 +42,7 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
     if (!A || !W || !C) return SUPIR_ERR_ARG;
     if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 31) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
-    if (ln_stats && (!ln_colsum || ln_slots <= 0 || ln_ld < ln_slots)) return SUPIR_ERR_ARG;
+    if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
     if (rowstats_out && (out_mode != 0 || act == 2 || rs_ld <= 0)) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
@@ -55,10 +55,16 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
     if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0))) return SUPIR_ERR_SHAPE;
     if (rowstats_out) {  // the slot index is tile_n * waves_n + wave_n: the caller's rs_ld must cover the tile actually used
         const int sel = supir_gemm_select_tile(M, N, act, tile < 0 ? -1 : (tile & 7));
-        const int bn = (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128), wn = sel == 5 ? 4 : 2;
-        if (((N + bn - 1) / bn) * wn > rs_ld) return SUPIR_ERR_ARG;
+        const int bn = (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
+        if ((N + bn - 1) / bn > rs_ld || (rs_ld & 1)) return SUPIR_ERR_ARG;
     }
     return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
+}
+
+int supir_rowstats_finalize(const float* partials, float* mean_rstd, int M, int ld, int slots, int dim, float eps,
+                            void* stream) {
+    if (!partials || !mean_rstd) return SUPIR_ERR_ARG;
+    return supir_rowstats_finalize_launch(partials, mean_rstd, M, ld, slots, dim, eps, (hipStream_t)stream);
 }
 
 int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int Wd, int Cin, int ldx, int Cout,

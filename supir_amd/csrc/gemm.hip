@@ -224,9 +224,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
         for (int i = 0; i < MI; ++i) {
             int m = m0 + wm * WTM + i * 32 + l31;
             m = m < p.M ? m : p.M - 1;
-            const float* st = p.ln_stats + (size_t)m * p.ln_ld * 2;
+            if (p.ln_slots == 0) {   // finalised statistics: [M][2] = (mean, rstd) from supir_rowstats_finalize
+                const float* st2 = p.ln_stats + (size_t)m * 2;
+                ln_mean[i] = st2[0];
+                ln_rstd[i] = st2[1];
+                continue;
+            }
+            const float* st = p.ln_stats + (size_t)m * p.ln_ld * 2;   // ln_ld is even: rows are 16-byte aligned
             float sm = 0.f, sq = 0.f;
-            for (int sl = 0; sl < p.ln_slots; ++sl) {
+            int sl = 0;
+#pragma unroll 2
+            for (; sl + 4 <= p.ln_slots; sl += 4) {   // 2 independent 16-byte loads per trip
+                const f32x4 u = *(const f32x4*)(st + 2 * sl), v = *(const f32x4*)(st + 2 * sl + 4);
+                sm += (u[0] + u[2]) + (v[0] + v[2]);
+                sq += (u[1] + u[3]) + (v[1] + v[3]);
+            }
+            for (; sl < p.ln_slots; ++sl) {
                 sm += st[2 * sl];
                 sq += st[2 * sl + 1];
             }
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
             ln_rstd[i] = rsqrtf(var + p.ln_eps);
         }
     }
+    if (p.rowstats_out) __syncthreads();   // LDS is reused below: every wave must be done with its last fragment reads
     if constexpr (TRANS) {
         // D[i = token][j = channel]: lane owns channel l31, tokens (r&3)+8*(r>>2)+4*half -> 4 consecutive tokens
         bf16_t* Cb = (bf16_t*)p.C;
@@ -372,11 +386,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
             if (p.rowstats_out) {
                 rsum += __shfl_xor(rsum, 32, 64);
                 rsq += __shfl_xor(rsq, 32, 64);
-                if (half == 0 && m_ok) {
-                    float* dst = p.rowstats_out + ((size_t)m * p.rs_ld + tile_n * WN + wn) * 2;
-                    dst[0] = rsum;
-                    dst[1] = rsq;
+                if (half == 0) {   // per wave column -> LDS [WN][BM][2]
+                    float* red = (float*)smem + ((size_t)wn * BM + wm * WTM + i * 32 + l31) * 2;
+                    red[0] = rsum;
+                    red[1] = rsq;
                 }
+            }
+        }
+        if (p.rowstats_out) {
+            // one slot per tile column: the WN wave columns are combined here in a fixed order (reproducible)
+            __syncthreads();
+            for (int r = tid; r < BM; r += NT) {
+                const int m = m0 + r;
+                if (m >= p.M) continue;
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) {
+                    sm += ((const float*)smem)[((size_t)w * BM + r) * 2];
+                    sq += ((const float*)smem)[((size_t)w * BM + r) * 2 + 1];
+                }
+                float* dst = p.rowstats_out + ((size_t)m * p.rs_ld + tile_n) * 2;
+                dst[0] = sm;
+                dst[1] = sq;
             }
         }
     }
@@ -440,6 +471,37 @@ static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
         default: return launch_gemm<256, 128, 2, 2, 2, CONV, TRANS>(a, st);
     }
 #undef SUPIR_GEMM_CASE
+}
+
+// (sum, sum of squares) partials [M][ld][2] -> (mean, rstd) [M][2]; one thread per row, fixed summation order
+__global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int M,
+                                                                int ld, int slots, int dim, float eps) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* st = part + (size_t)m * ld * 2;
+    float sm = 0.f, sq = 0.f;
+    int sl = 0;
+    for (; sl + 4 <= slots; sl += 4) {
+        const f32x4 u = *(const f32x4*)(st + 2 * sl), v = *(const f32x4*)(st + 2 * sl + 4);
+        sm += (u[0] + u[2]) + (v[0] + v[2]);
+        sq += (u[1] + u[3]) + (v[1] + v[3]);
+    }
+    for (; sl < slots; ++sl) {
+        sm += st[2 * sl];
+        sq += st[2 * sl + 1];
+    }
+    const float inv = 1.0f / (float)dim;
+    const float mean = sm * inv;
+    float var = sq * inv - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    out[(size_t)m * 2] = mean;
+    out[(size_t)m * 2 + 1] = rsqrtf(var + eps);
+}
+
+int supir_rowstats_finalize_launch(const float* part, float* out, int M, int ld, int slots, int dim, float eps, hipStream_t st) {
+    if (M <= 0 || slots <= 0 || ld < slots || (ld & 1) || dim <= 0) return SUPIR_ERR_SHAPE;
+    SUPIR_LAUNCH(rowstats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, out, M, ld, slots, dim, eps);
+    return SUPIR_LAUNCH_STATUS();
 }
 
 int supir_gemm_launch(const GemmArgs& a_in, bool conv, hipStream_t st, int force_tile) {

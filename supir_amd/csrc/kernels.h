@@ -57,6 +57,7 @@ struct GnArgs {
 };
 
 int supir_gemm_select_tile(int M, int N, int act, int force_tile);
+int supir_rowstats_finalize_launch(const float* part, float* out, int M, int ld, int slots, int dim, float eps, hipStream_t st);
 int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile);
 int supir_attn_launch(const AttnArgs& a, hipStream_t st);
 int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, int Tpad, long lds_, long ldp, float scale,

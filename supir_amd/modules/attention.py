@@ -15,6 +15,8 @@ from .base import BF16, Linear, Norm, Normalize, Passthrough, Prep, to_nchw, to_
 
 
 FOLD_LAYERNORM = True   # SpatialTransformer runs its blocks through BasicTransformerBlock.forward_fused
+FINALIZE_STATS = False  # (measured equal to summing in the consumer; off = fewer launches)
+# when True: reduce the row-statistic partials once per LayerNorm (tiny launch) instead of in every consumer
 
 
 def _pad64(t):
@@ -159,6 +161,8 @@ class BasicTransformerBlock(nn.Module):
         H = self.attn1.heads
         inner = H * 64
         e1, e2, e3 = self.norm1.eps, self.norm2.eps, self.norm3.eps
+        if FINALIZE_STATS:
+            stats = ops.rowstats_finalize(stats, C, e1)
         w, cs, b = f["qk"]
         qk = ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e1)
         w, cs, b = f["v"]
@@ -166,12 +170,16 @@ class BasicTransformerBlock(nn.Module):
         a = ops.flash_attn(qk[:, :, :inner], qk[:, :, inner:], vt, B, H, T, T)
         o1 = self.attn1.to_out[0]
         x, stats = ops.gemm_ln(a, o1.w(), o1.b32(), residual=x, out=x, emit_stats=True)
+        if FINALIZE_STATS:
+            stats = ops.rowstats_finalize(stats, C, e2)
         w, cs, b = f["q2"]
         q = ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e2)
         k, vt2 = self.attn2._context_kv(context)
         a = ops.flash_attn(q, k, vt2, B, H, T, k.shape[1])
         o2 = self.attn2.to_out[0]
         x, stats = ops.gemm_ln(a, o2.w(), o2.b32(), residual=x, out=x, emit_stats=True)
+        if FINALIZE_STATS:
+            stats = ops.rowstats_finalize(stats, C, e3)
         w, cs, b = f["geglu"]
         g = ops.gemm_ln(x, w, b, act=2, ln=stats, colsum=cs, ln_eps=e3)
         l2 = self.ff.net[2]

@@ -200,11 +200,26 @@ MAX_SLOTS_PER = 32   # rowstats slot granularity: one slot per 32 output columns
 
 
 class RowStats:
-    """Per-row (sum, sum of squares) partials a producer GEMM left behind for the LayerNorm folded into its consumers."""
+    """Per-row statistics a producer GEMM left behind for the LayerNorm folded into its consumers: either partial
+    (sum, sum of squares) per column tile [M, ld, 2] with `slots` valid slots, or (slots == 0) finalised (mean, rstd) [M, 2]."""
     __slots__ = ("buf", "slots", "ld")
 
     def __init__(self, buf, slots, ld):
         self.buf, self.slots, self.ld = buf, slots, ld
+
+
+def rowstats_finalize(st, dim, eps):
+    """partials -> (mean, rstd) per row, one tiny launch shared by all consumers of the same LayerNorm."""
+    if st.slots == 0:
+        return st
+    lib = _lib.load()
+    M = st.buf.shape[0]
+    out = torch.empty(M, 2, dtype=torch.float32, device=st.buf.device)
+    ev = _ev()
+    rc = lib.supir_rowstats_finalize(st.buf.data_ptr(), out.data_ptr(), M, st.ld, st.slots, dim, eps, _stream())
+    _lib.check(rc, "supir_rowstats_finalize")
+    _rec("rowstats_finalize", 0, 8.0 * M * (st.slots + 1), ev)
+    return RowStats(out, 0, 0)
 
 
 def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=-1, emit_stats=False, ln=None, colsum=None,
@@ -235,7 +250,8 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
     stats = None
     rs_ld = 0
     if emit_stats:
-        rs_ld = (N + MAX_SLOTS_PER - 1) // MAX_SLOTS_PER
+        rs_ld = (N + 63) // 64          # finest column tile is 64 wide
+        rs_ld += rs_ld & 1              # even: 16-byte aligned rows for the consumer's vector loads
         stats = torch.empty(M, rs_ld, 2, dtype=torch.float32, device=a.device)
     ln_p, ln_ld, ln_slots = 0, 0, 0
     if ln is not None:
@@ -260,8 +276,8 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
          tile=tile)
     if emit_stats:
         t_used = (tile & 7) if tile >= 0 else lib.supir_gemm_tile_for(M, N, act)
-        bn, wn = _TILE_BN_WN[t_used]
-        return out, RowStats(stats, ((N + bn - 1) // bn) * wn, rs_ld)
+        bn, _ = _TILE_BN_WN[t_used]
+        return out, RowStats(stats, (N + bn - 1) // bn, rs_ld)
     return out
 
 

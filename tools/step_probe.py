@@ -39,19 +39,23 @@ with torch.no_grad():
     for k, (n, f, b) in agg.items():
         print(f"  {k:16s} launches {n:5d}  TFLOP {f / 1e12:8.3f}  GB {b / 1e9:8.3f}")
     print("  total launches", len(tr), "TFLOP", sum(r["flops"] for r in tr) / 1e12)
-    for mode in ("graph-serial", "graph-overlap"):
-        wrap.overlap_branches = mode.endswith("overlap")
-        wrap.enable_graph(False)
-        wrap.enable_graph(mode.startswith("graph"))
-        for _ in range(2):
-            wrap(x, t, cond, 1.0)
-        torch.cuda.synchronize()
-        n = 5
-        t1 = time.time()
-        for _ in range(n):
-            wrap(x, t, cond, 1.0)
-        torch.cuda.synchronize()
-        print(f"{mode}: {(time.time() - t1) / n * 1e3:.2f} ms/step", flush=True)
+    from supir_amd.modules import attention as ATT
+    configs = [("ln-kernels", False, False), ("ln-folded-partials", True, False)]
+    for rep in range(2):
+        for name, fold, fin in configs:
+            ATT.FOLD_LAYERNORM, ATT.FINALIZE_STATS = fold, fin
+            wrap.overlap_branches = True
+            wrap.enable_graph(False)
+            wrap.enable_graph(True)
+            for _ in range(3):
+                wrap(x, t, cond, 1.0)
+            torch.cuda.synchronize()
+            n = 8
+            t1 = time.time()
+            for _ in range(n):
+                wrap(x, t, cond, 1.0)
+            torch.cuda.synchronize()
+            print(f"rep{rep} {name}: {(time.time() - t1) / n * 1e3:.2f} ms/step", flush=True)
     wrap.enable_graph(False)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(tr, open("gpurun_out/step_trace.json", "w"))
