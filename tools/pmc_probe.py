@@ -8,7 +8,7 @@ dev = "cuda"
 which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
 torch.manual_seed(0)
 if which == "gemm":
-    for (M, N, K, tile) in [(2048, 1280, 1280, 3), (2048, 1280, 1280, 1), (2048, 10240, 1280, 0),
+    for (M, N, K, tile) in [(2048, 1280, 1280, 3), (2048, 1280, 1280, 1), (2048, 10240, 1280, 0), (2048, 1280, 5120, 3),
                             (8192, 640, 2560, 0)]:
         a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
         for _ in range(3):
