@@ -244,10 +244,14 @@ def _sliding_windows(h, w, tile_size, tile_stride):
 class TiledRestoreEDMSampler(RestoreEDMSampler):
     """sampling.py:600-660: per step, every 128x128 latent tile takes a full sampler step; Gaussian-weighted blend."""
 
-    def __init__(self, tile_size=128, tile_stride=64, *args, **kwargs):
+    def __init__(self, tile_size=128, tile_stride=64, *args, tile_batch=1, **kwargs):
         super().__init__(*args, **kwargs)
         self.tile_size, self.tile_stride = tile_size, tile_stride
         self.tile_weights = None
+        # tiles of one step are independent given x and eps_noise (sampling.py:629-657): `tile_batch` > 1 stacks that many
+        # tiles along the batch axis of ONE denoiser call (M of every GEMM grows k-fold, 49 -> ceil(49/k) launches of the
+        # network per step); per-tile arithmetic is unchanged, so the result is identical.
+        self.tile_batch = max(1, int(tile_batch))
 
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None, x_center=None, control_scale=1.0,
                  use_linear_control_scale=False, control_scale_start=0.0):
@@ -276,23 +280,59 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
             x_next = torch.zeros_like(x)
             count = torch.zeros_like(x)
             eps_noise = torch.randn_like(x)
-            for j, (hi, he, wi, we) in enumerate(tiles):
-                cj = conds[j] if use_local_prompt else conds[0]
-                ctl = lq[:, :, hi:he, wi:we]
-                cj["control"] = ctl
-                uc["control"] = ctl
-                cat = dict(static[j if use_local_prompt else 0])
-                cat["control"] = torch.cat((ctl, ctl), 0) if not isinstance(self.guider, IdentityGuider) else ctl
-                _x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x[:, :, hi:he, wi:we], cj, uc, gamma,
-                                       x_center[:, :, hi:he, wi:we], eps_noise=eps_noise[:, :, hi:he, wi:we],
-                                       control_scale=control_scale, use_linear_control_scale=use_linear_control_scale,
-                                       control_scale_start=control_scale_start, cond_cat=cat, sigma_f=sf[i],
-                                       next_sigma_f=sf[i + 1])
-                x_next[:, :, hi:he, wi:we] += _x * tile_weights
-                count[:, :, hi:he, wi:we] += tile_weights
+            kb = 1 if use_local_prompt else self.tile_batch
+            for j0 in range(0, len(tiles), kb):
+                grp = tiles[j0:j0 + kb]
+                k = len(grp)
+                if k == 1:
+                    hi, he, wi, we = grp[0]
+                    cj = conds[j0] if use_local_prompt else conds[0]
+                    ctl = lq[:, :, hi:he, wi:we]
+                    cj["control"] = ctl
+                    uc["control"] = ctl
+                    cat = dict(static[j0 if use_local_prompt else 0])
+                    cat["control"] = torch.cat((ctl, ctl), 0) if not isinstance(self.guider, IdentityGuider) else ctl
+                    _x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x[:, :, hi:he, wi:we], cj, uc, gamma,
+                                           x_center[:, :, hi:he, wi:we], eps_noise=eps_noise[:, :, hi:he, wi:we],
+                                           control_scale=control_scale, use_linear_control_scale=use_linear_control_scale,
+                                           control_scale_start=control_scale_start, cond_cat=cat, sigma_f=sf[i],
+                                           next_sigma_f=sf[i + 1])
+                    outs = [_x]
+                else:
+                    def stack(t):
+                        return torch.cat([t[:, :, a:b_, c:d] for (a, b_, c, d) in grp], 0)
+                    ctl = stack(lq)
+                    cat = self._static_rep(static[0], k)
+                    cat["control"] = torch.cat((ctl, ctl), 0) if not isinstance(self.guider, IdentityGuider) else ctl
+                    s_k = s_in.repeat(k)
+                    _x = self.sampler_step(s_k * sigmas[i], s_k * sigmas[i + 1], denoiser, stack(x), conds[0], uc, gamma,
+                                           stack(x_center), eps_noise=stack(eps_noise), control_scale=control_scale,
+                                           use_linear_control_scale=use_linear_control_scale,
+                                           control_scale_start=control_scale_start, cond_cat=cat, sigma_f=sf[i],
+                                           next_sigma_f=sf[i + 1])
+                    outs = list(_x.chunk(k, 0))
+                for (hi, he, wi, we), _xt in zip(grp, outs):
+                    x_next[:, :, hi:he, wi:we] += _xt * tile_weights
+                    count[:, :, hi:he, wi:we] += tile_weights
             x_next /= count
             x = x_next
         return x
+
+    def _static_rep(self, cat, k):
+        """[uncond; cond] text / vector conditioning repeated for k stacked tiles: [uc]*k ; [c]*k (cached per k, so the
+        network's per-context caches and its hipGraph see the same tensors every step)."""
+        cache = self.__dict__.setdefault("_rep_cache", {})
+        key = (id(cat), k)
+        if key not in cache:
+            rep = {}
+            for name, v in cat.items():
+                if name == "control" or not torch.is_tensor(v):
+                    continue
+                u, c = v.chunk(2, 0) if not isinstance(self.guider, IdentityGuider) else (v, None)
+                rep[name] = torch.cat([u.repeat(k, *([1] * (v.dim() - 1))), c.repeat(k, *([1] * (v.dim() - 1)))], 0).contiguous() \
+                    if c is not None else u.repeat(k, *([1] * (v.dim() - 1))).contiguous()
+            cache[key] = (cat, rep)   # keep `cat` alive: the key uses its id
+        return dict(cache[key][1])
 
 
 # ----------------------------------------------------------------------------------------------- DPM++ 2M restore sampler

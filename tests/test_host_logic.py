@@ -95,14 +95,15 @@ def test_restore_edm_sampler_vs_reference(g, name, steps, rcfg):
     assert rel_l2(out, g["sampler_" + name]) <= 5e-5
 
 
-def test_tiled_sampler_vs_reference(g):
+@pytest.mark.parametrize("tile_batch", [1, 2, 4])
+def test_tiled_sampler_vs_reference(g, tile_batch):
     c, uc = _io()
     big = (1, 4, 24, 40)
     lqb = synth_tensor("lq_big", big)
     c, uc = dict(c, control=lqb), dict(uc, control=lqb)
     den = S.DiscreteDenoiserWithControl()
     smp = S.TiledRestoreEDMSampler(tile_size=16, tile_stride=8, num_steps=3, s_churn=5, s_noise=1.01, restore_cfg=4.0,
-                                   device="cpu", guider_config=S.LinearCFG(1.0, 4.0))
+                                   device="cpu", guider_config=S.LinearCFG(1.0, 4.0), tile_batch=tile_batch)
     with _Noise([synth_tensor(f"tiled.eps{i}", big) for i in range(3)]):
         out = smp(lambda i, s, cc, cs: den(_fake_net, i, s, cc, cs), synth_tensor("noised_big", big), cond=c, uc=uc,
                   x_center=synth_tensor("xc_big", big), control_scale=1.0)
