@@ -47,19 +47,27 @@ class CrossAttention(nn.Module):
                             lambda: torch.cat([Wt.linear_w(self.to_q.weight), Wt.linear_w(self.to_k.weight)], 0).contiguous())
 
     def _context_kv(self, context):
-        """K [B,Tk,C] and V^T [B,C,Tpad] of a context tensor, cached on tensor identity + version."""
-        c = self._kv_cache
+        """K [B,Tk,C] and V^T [B,C,Tpad] of a context tensor.  One cache entry PER CONTEXT SHAPE, keyed on tensor identity +
+        version and refreshed IN PLACE: a captured hipGraph holds raw pointers to these buffers, so an entry is never
+        reallocated or evicted once created (switching between batch sizes -- e.g. tile-batched and single-tile calls of the
+        tiled sampler -- alternates between entries instead of freeing the other graph's buffers)."""
         wk, wv = self.to_k.w(), self.to_v.w()
+        cache = self._kv_cache
+        if cache is None:
+            cache = {}
+            object.__setattr__(self, "_kv_cache", cache)
+        key = (tuple(context.shape), context.device)
+        c = cache.get(key)
         if c is not None and c[0] is context and c[1] == context._version and c[2] is wk and c[3] is wv:
             return c[4], c[5]
         ctx = tokens_bf16(context)
         B, Tk, _ = ctx.shape
         k_old = vt_old = None
-        if c is not None and c[2] is wk and c[3] is wv and c[4].shape[:2] == (B, Tk) and c[4].device == ctx.device:
-            k_old, vt_old = c[4], c[5]   # same shape: refresh IN PLACE so a captured hipGraph keeps reading these buffers
+        if c is not None:
+            k_old, vt_old = c[4], c[5]
         k = ops.gemm(ctx, wk, out=k_old)
         vt = ops.gemm_t(ctx, wv, None, B, Tk, _pad64(Tk), out=vt_old)
-        object.__setattr__(self, "_kv_cache", (context, context._version, wk, wv, k, vt))
+        cache[key] = (context, context._version, wk, wv, k, vt)
         return k, vt
 
     def attend(self, x, context=None, residual=None, alpha=1.0, inplace=False):

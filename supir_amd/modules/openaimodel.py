@@ -221,15 +221,20 @@ class UNetModel(nn.Module):
         return EmbBundle(emb.to(BF16), proj)
 
     def _label(self, y):
-        """label_emb(y): constant over the sampling loop -> cached on tensor identity/version, refreshed in place."""
-        c = self._label_cache
+        """label_emb(y): constant over the sampling loop -> cached per y-shape on tensor identity/version and refreshed in
+        place (captured hipGraphs point at these buffers; see CrossAttention._context_kv)."""
+        cache = self._label_cache
+        if cache is None:
+            cache = {}
+            object.__setattr__(self, "_label_cache", cache)
+        key = (tuple(y.shape), y.device)
+        c = cache.get(key)
         if c is None or c[0] is not y or c[1] != y._version:
             m0, m2 = self.label_emb[0][0], self.label_emb[0][2]
-            old = c[2] if (c is not None and c[2].shape[0] == y.shape[0] and c[2].device == y.device) else None
             lab = ops.gemm(ops.gemm(y.to(BF16).contiguous(), m0.w(), m0.b32(), act=1), m2.w(), m2.b32(),
-                           out_dtype=torch.float32, out=old)
-            object.__setattr__(self, "_label_cache", (y, y._version, lab))
-        return self._label_cache[2]
+                           out_dtype=torch.float32, out=None if c is None else c[2])
+            cache[key] = (y, y._version, lab)
+        return cache[key][2]
 
     def refresh_static_conditioning(self, context, y):
         """Recompute every step-independent quantity (text K / V^T of all cross-attention layers, label embedding) for a

@@ -261,3 +261,26 @@ def test_tiled_vae_vs_reference_golden(g):
     print(f"tiled vae: encoder {e_e:.3e}, decoder {e_d:.3e}")
     assert tuple(enc.shape) == (1, 8, 24, 20) and tuple(dec.shape) == (1, 3, 320, 256) and tuple(tiny.shape) == (1, 3, 64, 64)
     assert e_e <= 2.5e-2 and e_d <= 2.5e-2
+
+
+def test_graphs_of_two_batch_sizes_keep_their_static_buffers(wrap):
+    """Alternating between two captured graphs (B=2 and B=4: single-tile and tile-batched calls of the tiled sampler) must not
+    free / reallocate the cached text K/V^T or label buffers the other graph points at."""
+    x, t, cond = _wrapper_inputs()
+    x4, t4 = torch.cat([x, x * 0.5]), torch.cat([t, t])
+    cond4 = {"crossattn": cond["crossattn"].repeat(2, 1, 1).contiguous(), "vector": cond["vector"].repeat(2, 1).contiguous(),
+             "control": torch.cat([cond["control"], cond["control"] * 0.7])}
+    with torch.no_grad():
+        e2 = wrap(x, t, cond, 1.0).clone()
+        e4 = wrap(x4, t4, cond4, 1.0).clone()
+        wrap.enable_graph(True)
+        try:
+            outs = []
+            for _ in range(3):
+                outs.append((wrap(x, t, cond, 1.0).clone(), wrap(x4, t4, cond4, 1.0).clone()))
+                torch.empty(64 << 20, device=DEV).fill_(1.0)   # churn the allocator between replays
+        finally:
+            wrap.enable_graph(False)
+    for a2, a4 in outs:
+        assert torch.equal(a2, e2) and torch.equal(a4, e4)
+    assert torch.equal(e4[:2], e2)
