@@ -19,6 +19,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--tiled-steps", type=int, default=4)
 ap.add_argument("--tile-batch", type=int, default=4)
 ap.add_argument("--skip-tiled", action="store_true")
+ap.add_argument("--only-tiled", action="store_true")
+ap.add_argument("--tiled-res", type=int, default=4096)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 
@@ -57,15 +59,16 @@ def run(model, P, steps, reps=1, **kw):
 
 res = {}
 m = build("RestoreEDMSampler")
-s, ok, shp = run(m, 512, 2, reps=3)
-res["config1_512px_2steps"] = {"s_per_image": s, "finite": ok, "shape": shp}
-print(res, flush=True)
-m.sampler_config["target"] = "sgm.modules.diffusionmodules.sampling.RestoreDPMPP2MSampler"
-m.sampler_config["params"]["eta"] = 1.0
-for steps in (8, 4):
-    s, ok, shp = run(m, 1024, steps, reps=2, cfg_scale=2.0, cfg_scale_start=2.0)
-    res[f"config5_1024px_dpmpp2m_{steps}steps"] = {"s_per_image": s, "images_per_s": 1 / s, "finite": ok}
+if not args.only_tiled:
+    s, ok, shp = run(m, 512, 2, reps=3)
+    res["config1_512px_2steps"] = {"s_per_image": s, "finite": ok, "shape": shp}
     print(res, flush=True)
+    m.sampler_config["target"] = "sgm.modules.diffusionmodules.sampling.RestoreDPMPP2MSampler"
+    m.sampler_config["params"]["eta"] = 1.0
+    for steps in (8, 4):
+        s, ok, shp = run(m, 1024, steps, reps=2, cfg_scale=2.0, cfg_scale_start=2.0)
+        res[f"config5_1024px_dpmpp2m_{steps}steps"] = {"s_per_image": s, "images_per_s": 1 / s, "finite": ok}
+        print(res, flush=True)
 if not args.skip_tiled:
     m.sampler_config["target"] = "sgm.modules.diffusionmodules.sampling.TiledRestoreEDMSampler"
     m.sampler_config["params"].pop("eta", None)
@@ -73,7 +76,8 @@ if not args.skip_tiled:
     m.init_tile_vae(encoder_tile_size=512, decoder_tile_size=64)
     torch.cuda.reset_peak_memory_stats()
     t0 = time.time()
-    x = synth_tensor("img4096", (1, 3, 4096, 4096), scale=0.5).clamp(-1, 1).to(dev)
+    R = args.tiled_res
+    x = synth_tensor(f"img{R}", (1, 3, R, R), scale=0.5).clamp(-1, 1).to(dev)
     out = m.batchify_sample(x, cond=cond(), num_steps=args.tiled_steps, restoration_scale=-1, s_churn=5, s_noise=1.01, cfg_scale=4.0,
                             seed=1234, color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=1.0)
     torch.cuda.synchronize()
@@ -84,7 +88,7 @@ if not args.skip_tiled:
                             seed=1234, color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=1.0)
     torch.cuda.synchronize()
     t2 = time.time() - t0
-    res["config3_4096px_tiled"] = {"edm_steps": args.tiled_steps, "tile_batch": args.tile_batch, "s_first_call": t_all, "s_per_image": t2,
+    res[f"config3_{R}px_tiled"] = {"edm_steps": args.tiled_steps, "tile_batch": args.tile_batch, "s_first_call": t_all, "s_per_image": t2,
                                    "finite": bool(torch.isfinite(out).all()), "shape": tuple(out.shape),
                                    "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
                                    "note": "49 latent tiles x steps network calls + tiled VAE (64 tiles) x 4; extrapolate sampler linearly to 50 steps"}
