@@ -21,6 +21,7 @@
 //  * double-buffered LDS, counted vmcnt so the next K tile stays in flight across the barrier;
 //  * XCD-aware workgroup -> tile mapping (8 private L2s).
 #include "kernels.h"
+#include <stdlib.h>
 
 #ifndef SUPIR_GEMM_PRELOAD
 #define SUPIR_GEMM_PRELOAD 0
@@ -52,12 +53,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
     const int half = lane >> 5, l31 = lane & 31;
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    // neighbours (same XCD, same L2) share the W panel (order 0) or the A panel (order 1): the host picks the order that
-    // minimises L2 fills, i.e. keeps the BIGGER operand from being re-fetched by every XCD
+    // Workgroup -> tile: block b runs on XCD b % 8, and every XCD has a private 4 MB L2.  The host picks the partition of
+    // the tile grid over the 8 XCDs that minimises what the L2s have to pull in (each XCD touching an operand panel
+    // fetches its own copy): a gm x gn grid of XCD regions (each needing 1/gm of A and 1/gn of W), or, when the tile
+    // counts do not divide, contiguous 1-D id ranges; `order` = which tile index runs fastest inside a region.
     int tile_m, tile_n;
-    if (p.order == 0) { tile_n = id / tiles_m; tile_m = id - tile_n * tiles_m; }
-    else { tile_m = id / tiles_n; tile_n = id - tile_m * tiles_n; }
+    if (p.gm > 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int rm = tiles_m / p.gm, rn = tiles_n / p.gn;
+        const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
+        int lm, ln;
+        if (p.order == 0) { ln = idx / rm; lm = idx - ln * rm; }
+        else { lm = idx / rn; ln = idx - lm * rn; }
+        tile_m = xm * rm + lm;
+        tile_n = xn * rn + ln;
+    } else {
+        const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        if (p.order == 0) { tile_n = id / tiles_m; tile_m = id - tile_n * tiles_m; }
+        else { tile_m = id / tiles_n; tile_n = id - tile_m * tiles_n; }
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- loader state: slot s = j*256 + tid -> row j*32 + (tid>>3), physical chunk tid&7 ----
@@ -413,8 +427,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
     }
 }
 
+static bool xcd_grid_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SUPIR_XCD_GRID");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// choose the XCD partition for a tiles_m x tiles_n grid (see the kernel comment); a_bytes / w_bytes = operand footprints
+static void choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes) {
+    a.gm = a.gn = 0;
+    if (!xcd_grid_enabled() || ((tiles_m * tiles_n) & 7)) return;
+    const double c_bytes = 2.0 * (double)a.M * a.N / 8.0;   // each XCD also write-allocates its share of the output
+    double best = 0.0;
+    for (int gm = 8; gm >= 1; gm >>= 1) {
+        const int gn = 8 / gm;
+        if (tiles_m % gm || tiles_n % gn) continue;
+        double cost = gn * a_bytes + gm * w_bytes;                            // L2 fills summed over the 8 XCDs
+        if (a_bytes / gm + w_bytes / gn + c_bytes > 3.3e6) cost *= 1.5;       // region does not fit a 4 MB L2: re-fetches
+        if (a.gm == 0 || cost < best) {
+            best = cost;
+            a.gm = gm;
+            a.gn = gn;
+            a.order = (a_bytes / gm > w_bytes / gn) ? 1 : 0;   // keep the region's bigger operand panel resident longer
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int S, bool CONV, bool TRANS>
-static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+static int launch_gemm(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    {
+        const double a_bytes = CONV ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin
+                                    : 2.0 * (double)a.M * a.K;
+        choose_xcd_grid(a, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a_bytes, 2.0 * (double)a.N * a.K);
+    }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     constexpr int smem = S * (BM + BN) * 128;
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, S, CONV, TRANS>;

@@ -17,6 +17,7 @@ struct GemmArgs {
     int out_mode;           // 0 bf16 [M][ldc], 1 fp32 [M][ldc], 2 bf16 transposed [batch][N][ldc]
     float alpha;            // result = alpha * act(acc + bias + rowbias) + residual
     int order;              // tile order inside an XCD's id range: 0 = tile_m fastest (W panel shared), 1 = tile_n fastest
+    int gm, gn;             // 2-D XCD grid (gm*gn == 8): XCD x owns tile rows chunk x/gn, tile columns chunk x%gn; 0 = 1-D ranges
     // ---- LayerNorm folding (transformer blocks): y = LN(x).W^T == rstd*(x.W'^T - mean*colsum) + b'  with W' = gamma (.) W
     float* rowstats_out;    // producer: [M][rs_ld][2] per-row (sum, sum of squares) of the bf16 output, one slot per wave column
     int rs_ld;              //           slots allocated per row (>= tiles_n * waves_n)
