@@ -148,6 +148,12 @@ int supir_conv3x3_smallcout(const void* x, const void* w, const float* bias, flo
 int supir_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
                          long HW, float in_scale, void* stream);
 
+/* Touch one dword per 128-byte line of [p, p+bytes) (a weight matrix) so that it is in flight through the memory-side
+ * cache before the kernel that consumes it starts; launched a few ops ahead on a separate stream. `sink`: any 4 writable
+ * device bytes (never written in practice). No reference counterpart: the reference re-reads fp32 weights through
+ * autocast casts every step (sgm/modules/diffusionmodules/wrappers.py:87). */
+int supir_prefetch(const void* p, size_t bytes, void* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

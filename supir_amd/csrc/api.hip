@@ -151,6 +151,11 @@ int supir_conv3x3_smallcout(const void* x, const void* w, const float* bias, flo
                                           (hipStream_t)stream);
 }
 
+int supir_prefetch(const void* p, size_t bytes, void* sink, void* stream) {
+    if (!p) return SUPIR_ERR_ARG;
+    return supir_prefetch_launch(p, bytes, sink, (hipStream_t)stream);
+}
+
 int supir_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
                          long HW, float in_scale, void* stream) {
     if (!x || !w || !out) return SUPIR_ERR_ARG;

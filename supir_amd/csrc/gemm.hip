@@ -23,9 +23,6 @@
 #include "kernels.h"
 #include <stdlib.h>
 
-#ifndef SUPIR_GEMM_PRELOAD
-#define SUPIR_GEMM_PRELOAD 0
-#endif
 #ifndef SUPIR_DEFAULT_STAGES_CODE
 #define SUPIR_DEFAULT_STAGES_CODE 1  /* 2-deep ring: measured best (deeper rings cost a resident workgroup per CU) */
 #endif
@@ -173,35 +170,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
         const int buf = kt % S;
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + A_BYTES;
-#if SUPIR_GEMM_PRELOAD
-        // phase-separated K step: pull the whole 64-deep fragment set into registers first (16 ds_read_b128 for a 64x64
-        // wave tile), then issue the MFMAs back to back at raised priority.  With two workgroups resident per CU the
-        // co-resident wave's LDS phase overlaps this wave's matrix phase instead of interleaving with it.
-        bf16x8 af[4][MI], bfr[4][NI];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int coff = ((2 * ks + half) ^ sw) * 16;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[ks][i] = *(const bf16x8*)(sA + a_row_off + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[ks][j] = *(const bf16x8*)(sB + b_row_off + j * 32 * 128 + coff);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if constexpr (TRANS)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-                }
-        __builtin_amdgcn_s_setprio(0);
-#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int coff = ((2 * ks + half) ^ sw) * 16;
@@ -221,7 +189,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     }
 
     // ------------------------------------------------------------------ epilogue

@@ -20,6 +20,10 @@ class ControlWrapper(nn.Module):
         self._graph_on = False
         self._graphs = {}
         self.overlap_branches = True   # GLVControl || UNet encoder on two HIP streams
+        # weight prefetch inside captured graphs, `distance` ops ahead (ops.WeightPrefetch).  Measured on MI355X: the cold-weight
+        # penalty is real (tools/cold_probe.py: +25..40 % per GEMM) and a side-stream touch recovers 16 % on K = 5120 GEMMs in
+        # isolation, but 1168 extra graph nodes + event edges per step cost more than they save (44.3 -> 62-65 ms): off.
+        self.prefetch_distance = 0
         self._side = None
         self._warm = False
 
@@ -93,13 +97,25 @@ class ControlWrapper(nn.Module):
             # warm-up on a side stream: fills the weight / text-KV / label caches OUTSIDE the capture
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
+            from .. import ops
+            pf = ops.WeightPrefetch(self.prefetch_distance) if self.prefetch_distance > 0 else None
             with torch.cuda.stream(s):
-                for _ in range(2):
-                    self._forward_eager(sx, st, cond, control_scale)
+                self._forward_eager(sx, st, cond, control_scale)
+                if pf is not None:            # second warm-up pass doubles as the recording pass (op order is static)
+                    ops.set_prefetch(pf)
+                    pf.begin_record()
+                self._forward_eager(sx, st, cond, control_scale)
+                if pf is not None:
+                    pf.end()
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
+                if pf is not None:
+                    pf.begin_replay(x.device)
                 out = self._forward_eager(sx, st, cond, control_scale)
+                if pf is not None:
+                    pf.end()
+            ops.set_prefetch(None)
             g = [graph, sx, st, sc, out, ctx, ctx._version, vec, vec._version]
             self._graphs[key] = g
         graph, sx, st, sc, out = g[:5]

@@ -154,6 +154,68 @@ def _autotune(key, candidates, launch):
     return best
 
 
+# --------------------------------------------------------------------------------------------- weight prefetch plan
+class WeightPrefetch:
+    """Record the order in which weight matrices are consumed during one network call, then (while the same call is being
+    captured into a hipGraph) launch `supir_prefetch` for the weight of op i+distance on a dedicated stream as soon as op i
+    is reached.  The dependency op i -> prefetch(i+distance) is an event edge, so the prefetcher can never run further
+    ahead than `distance` ops (the Infinity Cache holds ~256 MB, a few dozen layers)."""
+
+    def __init__(self, distance=4):
+        self.distance = distance
+        self.plan = []
+        self.mode = None
+        self.idx = 0
+        self.stream = None
+        self.sink = None
+
+    def begin_record(self):
+        self.plan, self.mode, self.idx = [], "record", 0
+
+    def begin_replay(self, device):
+        self.mode, self.idx = "replay", 0
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=device)
+            self.sink = torch.zeros(4, dtype=torch.int32, device=device)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        lib = _lib.load()
+        for j in range(min(self.distance, len(self.plan))):      # prime the first `distance` weights
+            ptr, nb = self.plan[j]
+            lib.supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
+
+    def end(self):
+        if self.mode == "replay" and self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)     # join (required inside a capture)
+        self.mode = None
+
+    def touch(self, w):
+        if self.mode == "record":
+            self.plan.append((w.data_ptr(), w.numel() * w.element_size()))
+        elif self.mode == "replay":
+            i = self.idx
+            self.idx += 1
+            j = i + self.distance
+            if j < len(self.plan) and i < len(self.plan) and self.plan[i][0] == w.data_ptr():
+                ev = torch.cuda.Event()
+                ev.record()                       # on the op's own stream: "op i is next"
+                self.stream.wait_event(ev)
+                ptr, nb = self.plan[j]
+                _lib.load().supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
+
+
+_PF = None
+
+
+def set_prefetch(pf):
+    global _PF
+    _PF = pf
+
+
+def _pf(w):
+    if _PF is not None and _PF.mode is not None:
+        _PF.touch(w)
+
+
 # --------------------------------------------------------------------------------------------- GEMM family
 def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=0, alpha=1.0, out=None,
          out_dtype=BF16, tile=-1):
@@ -188,6 +250,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
             tile = _TUNE.get(key, -1)   # in-place accumulate: re-launching would change the data, only reuse a known winner
         else:
             tile = _autotune(key, (0, 2, 4, 5, 6) if act == 2 else (0, 1, 2, 3, 4, 5, 6), launch)
+    _pf(w)
     ev = _ev()
     rc = launch(tile)
     _lib.check(rc, "supir_gemm_bf16")
@@ -269,6 +332,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
             tile = _TUNE.get(key, -1)
         else:
             tile = _autotune(key, (0, 2, 4, 5, 6) if act == 2 else (0, 1, 2, 3, 4, 5, 6), launch)
+    _pf(w)
     ev = _ev()
     rc = launch(tile)
     _lib.check(rc, "supir_gemm_bf16_ln")
@@ -291,6 +355,7 @@ def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
     if out is None:
         out = torch.zeros(B, N, Tpad, dtype=BF16, device=a.device) if Tpad != T else \
             torch.empty(B, N, Tpad, dtype=BF16, device=a.device)
+    _pf(w)
     ev = _ev()
     rc = lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, Tpad, _p(bias), 0, 0, T, 0, 0, 0, 2,
                              1.0, tile, _stream())
@@ -336,6 +401,7 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
 
     if tile == -1:
         tile = _autotune(("conv", B, H, W, Cin, Cout, stride, bool(upsample)), (0, 1, 2, 3, 4, 5, 6), launch)
+    _pf(w)
     ev = _ev()
     rc = launch(tile)
     _lib.check(rc, "supir_conv3x3_bf16")

@@ -39,11 +39,9 @@ with torch.no_grad():
     for k, (n, f, b) in agg.items():
         print(f"  {k:16s} launches {n:5d}  TFLOP {f / 1e12:8.3f}  GB {b / 1e9:8.3f}")
     print("  total launches", len(tr), "TFLOP", sum(r["flops"] for r in tr) / 1e12)
-    from supir_amd.modules import attention as ATT
-    configs = [("ln-kernels", False, False), ("ln-folded-partials", True, False)]
     for rep in range(2):
-        for name, fold, fin in configs:
-            ATT.FOLD_LAYERNORM, ATT.FINALIZE_STATS = fold, fin
+        for dist in (0, 3, 8, 20):
+            wrap.prefetch_distance = dist
             wrap.overlap_branches = True
             wrap.enable_graph(False)
             wrap.enable_graph(True)
@@ -55,7 +53,7 @@ with torch.no_grad():
             for _ in range(n):
                 wrap(x, t, cond, 1.0)
             torch.cuda.synchronize()
-            print(f"rep{rep} {name}: {(time.time() - t1) / n * 1e3:.2f} ms/step", flush=True)
+            print(f"rep{rep} prefetch distance {dist}: {(time.time() - t1) / n * 1e3:.2f} ms/step", flush=True)
     wrap.enable_graph(False)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(tr, open("gpurun_out/step_trace.json", "w"))
