@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the shared library is a build artefact (git-ignored): make sure it exists before any test imports the ctypes binding
+    # (this is __graft_entry__.build()'s job; doing it here too keeps a fresh checkout + `pytest` self-contained)
+    from supir_amd import build as _build
+    _build.build(force=False, verbose=False)
 
 
 def pytest_collection_modifyitems(config, items):
