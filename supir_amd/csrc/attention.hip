@@ -17,6 +17,7 @@
 // arranged (K rows read with bits 2/3 of the row index swapped) so that it is one 16-byte chunk of a Vt row: no
 // cross-lane exchange, conflict-free ds_read_b128 on both operands.
 #include "kernels.h"
+#include <stdlib.h>
 
 
 template <int N>
@@ -24,8 +25,11 @@ __device__ __forceinline__ void attn_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int S>
 __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+    // S-deep ring of (K tile, V^T tile) pairs, 16 KB each.  A (batch, head, 128-query) workgroup is alone or nearly alone
+    // on its CU (320-640 workgroups per launch), so the latency of the next tiles has to be hidden by queue depth.
+    __shared__ __attribute__((aligned(16))) char smem[S * 16384];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
 
@@ -81,17 +85,27 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnArgs p) {
     const int krow_off = krow * 128;
     const int ksw = (krow >> 1) & 7;
 
-    stage(0, 0);
+    {
+        const int pre = nt < S - 1 ? nt : S - 1;
+        for (int t = 0; t < pre; ++t) stage(t, t);
+    }
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) {
-            stage(t + 1, buf ^ 1);
-            attn_wait_vmcnt<4>();
+        const int buf = t % S;
+        const int rem = nt - 1 - t;
+        const int inflight = rem < S - 2 ? rem : S - 2;   // younger tiles allowed to stay outstanding (4 loads each)
+        if constexpr (S >= 4) {
+            if (inflight >= 2) attn_wait_vmcnt<8>();
+            else if (inflight == 1) attn_wait_vmcnt<4>();
+            else attn_wait_vmcnt<0>();
+        } else if constexpr (S == 3) {
+            if (inflight >= 1) attn_wait_vmcnt<4>();
+            else attn_wait_vmcnt<0>();
         } else {
             attn_wait_vmcnt<0>();
         }
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();   // tile t visible to all waves; all waves are done with tile t-1's buffer
         asm volatile("" ::: "memory");
+        if (t + S - 1 < nt) stage(t + S - 1, (t + S - 1) % S);
         const char* sK = smem + buf * 16384;
         const char* sV = sK + 8192;
 
@@ -155,8 +169,6 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(const AttnArgs p) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -180,7 +192,14 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
     if ((a.ldq | a.ldk | a.ldvt) % 8 != 0 || a.ldo % 4 != 0) return SUPIR_ERR_SHAPE;
     if (a.ldvt < ((a.Tk + 63) / 64) * 64) return SUPIR_ERR_SHAPE;
     const int nqb = (a.Tq + 127) / 128;
-    SUPIR_LAUNCH(attn_d64_kernel, dim3(nqb * a.H * a.B), dim3(256), 0, st, a);
+    static int ring = -1;
+    if (ring < 0) {
+        const char* e = getenv("SUPIR_ATTN_RING");
+        ring = e ? atoi(e) : 3;
+    }
+    if (ring == 2) SUPIR_LAUNCH(attn_d64_kernel<2>, dim3(nqb * a.H * a.B), dim3(256), 0, st, a);
+    else if (ring == 4) SUPIR_LAUNCH(attn_d64_kernel<4>, dim3(nqb * a.H * a.B), dim3(256), 0, st, a);
+    else SUPIR_LAUNCH(attn_d64_kernel<3>, dim3(nqb * a.H * a.B), dim3(256), 0, st, a);
     return SUPIR_LAUNCH_STATUS();
 }
 

@@ -12,6 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 
 #include "../../include/supir_hip.h"  // error codes shared with the C ABI
@@ -29,17 +30,34 @@ int supir_note_hip_status(hipError_t e);
 #define SUPIR_LAUNCH_STATUS() supir_note_hip_status(hipGetLastError())
 
 // round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ u16 f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+typedef float supir_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 supir_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {   // (lo, hi) -> two bf16 in one dword
+    const supir_f32x2 v = {lo, hi};
+    const supir_bf16x2 b = __builtin_convertvector(v, supir_bf16x2);
+    return __builtin_bit_cast(uint32_t, b);
 }
+__device__ __forceinline__ u16 f2bf(float f) { return (u16)(f2bf_pk(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bflo2f(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi2f(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact (erf) GELU, F.gelu default  (reference: sgm/modules/attention.py:91)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf GELU (F.gelu default; reference: sgm/modules/attention.py:91).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,
+// below fp32 resolution of the 1 + erf term and far below the bf16 output): a dozen instructions instead of the libm erff call
+// in the epilogue of the widest GEMM of every transformer block.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float y = 1.0f - pl * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -22,6 +22,7 @@
 //  * XCD-aware workgroup -> tile mapping (8 private L2s).
 #include "kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifndef SUPIR_DEFAULT_STAGES_CODE
 #define SUPIR_DEFAULT_STAGES_CODE 1  /* 2-deep ring: measured best (deeper rings cost a resident workgroup per CU) */
@@ -30,13 +31,28 @@
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
 
+#ifdef SUPIR_GEMM_TIMELINE
+// tools/probes/gemm_timeline.hip only: per-wave s_memtime breakdown of the main loop (never defined in the product build)
+__device__ unsigned long long* g_tl_buf;
+extern "C" void supir_tl_set(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &p, sizeof(p)); }
+#define TL_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// waves per SIMD the register allocator must leave room for: as many workgroups as the LDS ring lets a CU hold
+constexpr int gemm_min_waves(int BM, int BN, int WM, int WN, int S) {
+    int blocks = 163840 / (S * (BM + BN) * 128);
+    if (blocks < 1) blocks = 1;
+    int w = blocks * WM * WN / 4;
+    return w < 1 ? 1 : (w > 6 ? 6 : w);
+}
+
 template <int BM, int BN, int WM, int WN, int S, bool CONV, bool TRANS>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) void gemm_bf16_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * WM * WN;          // threads: WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile
     constexpr int RPL = NT / 8;               // tile rows staged per load instruction of the workgroup
@@ -44,6 +60,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
     constexpr int A_LOADS = BM / RPL, B_LOADS = BN / RPL, LOADS = A_LOADS + B_LOADS;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int WTM = BM / WM, WTN = BN / WN;
+    // epilogue scratch carved out of the (then idle) ring: row statistics < 16 KB, bias / column sums at 16 KB, C staging at 20 KB
+    static_assert(20480 + WM * WN * 32 * (WTN * 2 + 16) <= 2 * STAGE, "epilogue scratch must fit the smallest LDS ring");
+    static_assert(WM * BM * 0 + WN * BM * 8 <= 16384 && 16384 + 2 * BN * 4 <= 20480, "epilogue scratch regions overlap");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -102,11 +121,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
     const bf16_t* zero = (const bf16_t*)g_zero_page;
 
     int ld_k0 = 0, ld_cin0 = 0, ld_ky = 0, ld_kx = 0;  // position of the NEXT tile to stage
-    auto stage = [&](int buf) {
+    // one global->LDS instruction (q < A_LOADS: A rows, else W rows) of the tile at the current stage position
+    auto stage_one = [&](int buf, int q) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < A_LOADS; ++j) {
+        if (q < A_LOADS) {
+            const int j = q;
             const bf16_t* src;
             if constexpr (CONV) {
                 int iy = a_iy0[j] + ld_ky, ix = a_ix0[j] + ld_kx;
@@ -117,9 +137,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
                 src = a_ptr[j] + ld_k0;
             }
             glds16(src, sA + (j * NT + wave * 64) * 16);
+        } else {
+            const int j = q - A_LOADS;
+            glds16(b_ptr[j] + ld_k0, sB + (j * NT + wave * 64) * 16);
         }
-#pragma unroll
-        for (int j = 0; j < B_LOADS; ++j) glds16(b_ptr[j] + ld_k0, sB + (j * NT + wave * 64) * 16);
+    };
+    auto stage_advance = [&]() {
         ld_k0 += 64;
         if constexpr (CONV) {
             ld_cin0 += 64;
@@ -129,6 +152,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
             }
         }
     };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LOADS; ++q) stage_one(buf, q);
+        stage_advance();
+    };
+
+    // epilogue vectors of this tile's BN columns: fetched now (one element per thread), parked in LDS after the main loop
+    float pre_bias = 0.f, pre_cs = 0.f;
+    if constexpr (!TRANS) {
+        if (tid < BN) {
+            const int n = n0 + tid < p.N ? n0 + tid : p.N - 1;
+            if (p.bias) pre_bias = p.bias[n];
+            if (p.ln_stats) pre_cs = p.ln_colsum[n];
+        }
+    }
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -147,11 +185,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
     // the buffer step kt-1 just finished reading) and stay in flight across the next S-2 barriers (counted vmcnt).
     // With M = 2048 the grid is only 1-2 workgroups per CU, so latency hiding has to come from this queue depth.
     const int nk = p.K >> 6;
+#ifdef SUPIR_GEMM_TIMELINE
+    unsigned long long tl_wait = 0, tl_bar = 0, tl_issue = 0, tl_comp = 0;
+    const unsigned long long tl_t0 = TL_NOW();
+#endif
     {
         const int pre = nk < S - 1 ? nk : S - 1;
         for (int s = 0; s < pre; ++s) stage(s);
     }
+#ifdef SUPIR_GEMM_TIMELINE
+    const unsigned long long tl_loop0 = TL_NOW();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+#ifdef SUPIR_GEMM_TIMELINE
+        const unsigned long long tl_a = TL_NOW();
+#endif
         const int rem = nk - 1 - kt;
         const int inflight = rem < S - 2 ? rem : S - 2;  // younger tiles allowed to stay outstanding
         if constexpr (S >= 4) {
@@ -164,32 +212,73 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
         } else {
             wait_vmcnt<0>();
         }
+#ifdef SUPIR_GEMM_TIMELINE
+        const unsigned long long tl_b = TL_NOW();
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + S - 1 < nk) stage((kt + S - 1) % S);
+#ifdef SUPIR_GEMM_TIMELINE
+        const unsigned long long tl_c = TL_NOW();
+#endif
+#ifdef SUPIR_GEMM_TIMELINE
+        const unsigned long long tl_d = tl_c;
+#endif
+        // The next tile's global->LDS instructions are spread over the four 16-wide K slices, between the MFMA groups:
+        // issued back to back after the barrier they stall on the CU's 64 B/clk vector-memory path for as long as the
+        // whole MFMA group takes (s_memtime: 450 cycles of issue stall + 690 of LDS/MFMA per step on a 128x128 tile, one
+        // wave per SIMD), i.e. nothing overlapped.  Fragments for slice ks+1 are read while slice ks is in the matrix pipe.
+        const bool do_stage = kt + S - 1 < nk;
+        const int sbuf = (kt + S - 1) % S;
         const int buf = kt % S;
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + A_BYTES;
+        constexpr int FB = (MI * NI >= 8) ? 1 : 2;   // fragment double buffering, unless the accumulators already fill the file
+        bf16x8 af[FB][MI], bfr[FB][NI];
+        auto read_frags = [&](int ks, int slot) {
+            const int coff = ((2 * ks + half) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[slot][i] = *(const bf16x8*)(sA + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[slot][j] = *(const bf16x8*)(sB + b_row_off + j * 32 * 128 + coff);
+        };
+        if constexpr (FB == 2) read_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int coff = ((2 * ks + half) ^ sw) * 16;
-            bf16x8 af[MI], bfr[NI];
+            if constexpr (FB == 2) {
+                if (ks < 3) read_frags(ks + 1, (ks + 1) & 1);
+            } else {
+                read_frags(ks, 0);
+            }
+            if (do_stage) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sA + a_row_off + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(sB + b_row_off + j * 32 * 128 + coff);
+                for (int q = (ks * LOADS) / 4; q < ((ks + 1) * LOADS) / 4; ++q) stage_one(sbuf, q);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     if constexpr (TRANS)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & (FB - 1)][i], bfr[ks & (FB - 1)][j], acc[i][j], 0, 0, 0);
                     else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & (FB - 1)][j], af[ks & (FB - 1)][i], acc[i][j], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);   // keep the slice order: the scheduler must not regroup loads and MFMAs
         }
+        if (do_stage) stage_advance();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SUPIR_GEMM_TIMELINE
+        {
+            const unsigned long long tl_e = TL_NOW();
+            tl_wait += tl_b - tl_a;
+            tl_bar += tl_c - tl_b;
+            tl_issue += tl_d - tl_c;
+            tl_comp += tl_e - tl_d;
+        }
+#endif
     }
+#ifdef SUPIR_GEMM_TIMELINE
+    const unsigned long long tl_loop1 = TL_NOW();
+#endif
 
     // ------------------------------------------------------------------ epilogue
     // LayerNorm folding: per-row mean / rstd of the A operand, reduced from the producer GEMM's per-wave-column partial
@@ -232,19 +321,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
             ln_rstd[i] = rsqrtf(var + p.ln_eps);
         }
     }
-    if (p.rowstats_out) __syncthreads();   // LDS is reused below: every wave must be done with its last fragment reads
+    __syncthreads();   // LDS is reused below: every wave must be done with its last fragment reads
+    float* s_bias = (float*)(smem + 16384);   // [BN] bias, [BN] LN column sums (the row-statistics scratch lives below 16 KB)
+    float* s_cs = s_bias + BN;
+    if constexpr (!TRANS) {
+        if (tid < BN) {
+            s_bias[tid] = pre_bias;
+            s_cs[tid] = pre_cs;
+        }
+        __syncthreads();
+    }
     if constexpr (TRANS) {
         // D[i = token][j = channel]: lane owns channel l31, tokens (r&3)+8*(r>>2)+4*half -> 4 consecutive tokens
         bf16_t* Cb = (bf16_t*)p.C;
+        float t_bias[NI], t_cs[NI];   // loaded once, ahead of every dependent use (the epilogue is latency-bound otherwise)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + l31;
+            const int nc = n < p.N ? n : p.N - 1;
+            t_bias[j] = p.bias ? p.bias[nc] : 0.f;
+            t_cs[j] = p.ln_stats ? p.ln_colsum[nc] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int n = n0 + wn * WTN + j * 32 + l31;
                 const bool n_ok = n < p.N;
-                const int nc = n_ok ? n : p.N - 1;
-                const float bz = p.bias ? p.bias[nc] : 0.f;
-                const float cs = p.ln_stats ? p.ln_colsum[nc] : 0.f;
+                const float bz = t_bias[j], cs = t_cs[j];
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     float val[4];
@@ -280,99 +384,154 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
             }
         return;
     } else {
-        // D[i = channel][j = token]: lane owns token l31, channels (r&3)+8*(r>>2)+4*half -> 4 consecutive channels
+        // D[i = channel][j = token]: lane owns token l31, channels (r&3)+8*(r>>2)+4*half -> 4 consecutive channels.
+        //
+        // Measured with s_memtime (tools/probes/gemm_timeline.hip) the first form of this epilogue -- per fragment:
+        // conditional loads, conditional math, store -- took 40-50 % of a K = 1280 launch: ~7000 instructions of branchy,
+        // fully unrolled code streamed once through the instruction cache, with a dependent global load in every
+        // iteration.  Now: bias / LN column sums come from LDS (fetched before the main loop), row bias and residual
+        // are fetched as one batch per 32-row block, the arithmetic is branch-free (absent terms are exact zeros /
+        // mean 0 / rstd 1), and the three run-time switches that remain (SiLU, output type, store path) select one of a
+        // few compact compile-time variants so a launch only executes the code it needs.
+        if (p.act == 2) {
+            // GEGLU: fragment pair (value, gate) = (j even, j odd) inside the wave's 64 columns
+            if constexpr (NI == 2) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * WTM + i * 32 + l31;
-            const bool m_ok = m < p.M;
-            const int bidx = (p.rowbias && m_ok) ? m / p.rows_per_batch : 0;
-            const float mu = ln_mean[i], rs = ln_rstd[i];
-            if (p.act == 2) {
-                // GEGLU: fragment pair (value, gate) = (j even, j odd) inside the wave's 64 columns
-                if constexpr (NI == 2) {
-                    if (m_ok) {
+                for (int i = 0; i < MI; ++i) {
+                    const int m = m0 + wm * WTM + i * 32 + l31;
+                    const bool m_ok = m < p.M;
+                    const float mu = ln_mean[i], rs = ln_rstd[i];
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const int nl = wn * 64 + 8 * rg + 4 * half;  // column inside the tile (each wave owns 64 columns)
-                            const int nv = n0 + nl, ng = n0 + nl + 32;   // interleaved weight rows
-                            if (ng >= p.N) continue;
-                            f32x4 bv = {0, 0, 0, 0}, bg = {0, 0, 0, 0}, cv = {0, 0, 0, 0}, cg = {0, 0, 0, 0};
-                            if (p.bias) { bv = *(const f32x4*)(p.bias + nv); bg = *(const f32x4*)(p.bias + ng); }
-                            if (p.ln_stats) { cv = *(const f32x4*)(p.ln_colsum + nv); cg = *(const f32x4*)(p.ln_colsum + ng); }
-                            u16x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float v = acc[i][0][rg * 4 + e], g = acc[i][1][rg * 4 + e];
-                                if (p.ln_stats) { v = rs * (v - mu * cv[e]); g = rs * (g - mu * cg[e]); }
-                                v += bv[e];
-                                g += bg[e];
-                                o[e] = f2bf(v * gelu_f(g));
-                            }
-                            const int no = (n0 >> 1) + wn * 32 + 8 * rg + 4 * half;
-                            *(u16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
-                        }
-                    }
-                }
-                continue;
-            }
-            float rsum = 0.f, rsq = 0.f;   // row statistics of what this wave writes (for the NEXT LayerNorm)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int n = n0 + wn * WTN + j * 32 + 8 * rg + 4 * half;
-                    if (n >= p.N || !m_ok) continue;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
-                    if (p.ln_stats) {
-                        const f32x4 cs = *(const f32x4*)(p.ln_colsum + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = rs * (v[e] - mu * cs[e]);
-                    }
-                    if (p.bias) {
-                        const f32x4 bz = *(const f32x4*)(p.bias + n);
-                        v += bz;
-                    }
-                    if (p.rowbias) {
-                        const u16x4 rb = *(const u16x4*)(p.rowbias + (size_t)bidx * p.ld_rb + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += bf2f(rb[e]);
-                    }
-                    if (p.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-                    if (p.res) {
-                        const u16x4 rr = *(const u16x4*)(p.res + (size_t)m * p.ldr + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += bf2f(rr[e]);
-                    }
-                    if (p.out_mode == 1) {
-                        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-                    } else {
-                        u16x4 o;
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int nl = wn * 64 + 8 * rg + 4 * half;  // column inside the tile (each wave owns 64 columns);
+                        // value rows nl.., gate rows nl+32.. (interleaved weights)
+                        const f32x4 bv = *(const f32x4*)(s_bias + nl), bg = *(const f32x4*)(s_bias + nl + 32);
+                        const f32x4 cv = *(const f32x4*)(s_cs + nl), cg = *(const f32x4*)(s_cs + nl + 32);
+                        float r[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            o[e] = f2bf(v[e]);
-                            const float r = bf2f(o[e]);
-                            rsum += r;
-                            rsq += r * r;
+                            const float v = rs * (acc[i][0][rg * 4 + e] - mu * cv[e]) + bv[e];
+                            const float g = rs * (acc[i][1][rg * 4 + e] - mu * cg[e]) + bg[e];
+                            r[e] = v * gelu_f(g);
                         }
-                        *(u16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                        u32x2 o = {f2bf_pk(r[0], r[1]), f2bf_pk(r[2], r[3])};
+                        const int no = (n0 >> 1) + wn * 32 + 8 * rg + 4 * half;
+                        if (m_ok && n0 + nl + 32 < p.N) *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
                     }
                 }
-            if (p.rowstats_out) {
-                rsum += __shfl_xor(rsum, 32, 64);
-                rsq += __shfl_xor(rsq, 32, 64);
-                if (half == 0) {   // per wave column -> LDS [WN][BM][2]
-                    float* red = (float*)smem + ((size_t)wn * BM + wm * WTM + i * 32 + l31) * 2;
-                    red[0] = rsum;
-                    red[1] = rsq;
+            }
+            return;
+        }
+        // bf16 output can go through a wave-private LDS block (row stride padded by 16 B) so that the global stores are
+        // 16 B per lane and row-contiguous instead of 32 rows x 16 bytes per store instruction
+        constexpr int C_RS = WTN * 2 + 16;
+        char* c_stage = smem + 20480 + wave * (32 * C_RS);
+        auto epilogue = [&](auto silu_c, auto mode_c) {
+            constexpr bool SILU = decltype(silu_c)::value;
+            constexpr int MODE = decltype(mode_c)::value;   // 0: bf16 direct, 1: fp32 direct, 2: bf16 via LDS
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * WTM + i * 32 + l31;
+                const bool m_ok = m < p.M;
+                const int mc = m_ok ? m : p.M - 1;
+                const float mu = ln_mean[i], rs = ln_rstd[i];
+                u32x2 e_rb[NI][4], e_res[NI][4];
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) e_rb[j][rg] = e_res[j][rg] = u32x2{0u, 0u};
+                if (p.rowbias) {
+                    const bf16_t* rbp = p.rowbias + (size_t)(mc / p.rows_per_batch) * p.ld_rb;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int n = n0 + wn * WTN + j * 32 + 8 * rg + 4 * half;
+                            e_rb[j][rg] = *(const u32x2*)(rbp + (n < p.N ? n : 0));
+                        }
+                }
+                if (p.res) {
+                    const bf16_t* rp = p.res + (size_t)mc * p.ldr;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int n = n0 + wn * WTN + j * 32 + 8 * rg + 4 * half;
+                            e_res[j][rg] = *(const u32x2*)(rp + (n < p.N ? n : 0));
+                        }
+                }
+                float rsum = 0.f, rsq = 0.f;   // row statistics of what this wave writes (for the NEXT LayerNorm)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int nl = wn * WTN + j * 32 + 8 * rg + 4 * half;
+                        const int n = n0 + nl;
+                        const bool ok = m_ok && n < p.N;   // N % 4 == 0: a lane's 4 channels are valid together
+                        const f32x4 cs = *(const f32x4*)(s_cs + nl), bz = *(const f32x4*)(s_bias + nl);
+                        const u32x2 rb = e_rb[j][rg], rr = e_res[j][rg];
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = rs * (acc[i][j][rg * 4 + e] - mu * cs[e]) + bz[e];
+                            t += (e & 1) ? bfhi2f(rb[e >> 1]) : bflo2f(rb[e >> 1]);
+                            if constexpr (SILU) t = silu_f(t);
+                            t *= p.alpha;
+                            t += (e & 1) ? bfhi2f(rr[e >> 1]) : bflo2f(rr[e >> 1]);
+                            v[e] = t;
+                        }
+                        if constexpr (MODE == 1) {
+                            if (ok) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+                        } else {
+                            const u32x2 o = {f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3])};
+                            const float r0 = bflo2f(o[0]), r1 = bfhi2f(o[0]), r2 = bflo2f(o[1]), r3 = bfhi2f(o[1]);
+                            const float ps = (r0 + r1) + (r2 + r3), pq = (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+                            rsum += ok ? ps : 0.f;
+                            rsq += ok ? pq : 0.f;
+                            if constexpr (MODE == 2) {
+                                *(u32x2*)(c_stage + l31 * C_RS + (j * 32 + 8 * rg + 4 * half) * 2) = o;
+                            } else {
+                                if (ok) *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                            }
+                        }
+                    }
+                if constexpr (MODE == 2) {
+                    // the wave's 32 x WTN block, now row-major in LDS: CPR lanes cover one row contiguously
+                    constexpr int CPR = WTN / 8, RPI = 64 / CPR;
+#pragma unroll
+                    for (int rr = 0; rr < 32 / RPI; ++rr) {
+                        const int row = rr * RPI + lane / CPR, ch = lane % CPR;
+                        const int m2 = m0 + wm * WTM + i * 32 + row, n2 = n0 + wn * WTN + ch * 8;
+                        const f32x4 piece = *(const f32x4*)(c_stage + row * C_RS + ch * 16);
+                        if (m2 < p.M && n2 < p.N) *(f32x4*)((bf16_t*)p.C + (size_t)m2 * p.ldc + n2) = piece;
+                    }
+                }
+                if (p.rowstats_out) {
+                    rsum += __shfl_xor(rsum, 32, 64);
+                    rsq += __shfl_xor(rsq, 32, 64);
+                    if (half == 0) {   // per wave column -> LDS [WN][BM][2]
+                        float* red = (float*)smem + ((size_t)wn * BM + wm * WTM + i * 32 + l31) * 2;
+                        red[0] = rsum;
+                        red[1] = rsq;
+                    }
                 }
             }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        using M0_ = std::integral_constant<int, 0>;
+        using M1_ = std::integral_constant<int, 1>;
+        using M2_ = std::integral_constant<int, 2>;
+        const bool via_lds = (p.ldc & 7) == 0 && (p.N & 7) == 0 && (((size_t)p.C) & 15) == 0;
+        if (p.out_mode == 1) {
+            if (p.act == 1) epilogue(T_{}, M1_{});
+            else epilogue(F_{}, M1_{});
+        } else if (via_lds) {
+            if (p.act == 1) epilogue(T_{}, M2_{});
+            else epilogue(F_{}, M2_{});
+        } else {
+            if (p.act == 1) epilogue(T_{}, M0_{});
+            else epilogue(F_{}, M0_{});
         }
         if (p.rowstats_out) {
             // one slot per tile column: the WN wave columns are combined here in a fixed order (reproducible)
@@ -392,6 +551,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(const GemmArgs 
             }
         }
     }
+#ifdef SUPIR_GEMM_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g_tl_buf && lane == 0) {
+        const unsigned long long tl_end = TL_NOW();
+        unsigned long long* o = g_tl_buf + ((size_t)blockIdx.x * (NT / 64) + wave) * 8;
+        o[0] = tl_t0;
+        o[1] = tl_loop0 - tl_t0;
+        o[2] = tl_wait;
+        o[3] = tl_bar;
+        o[4] = tl_issue;
+        o[5] = tl_comp;
+        o[6] = tl_end - tl_loop1;
+        o[7] = tl_end - tl_t0;
+    }
+#endif
 }
 
 static bool xcd_grid_enabled() {

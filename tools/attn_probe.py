@@ -1,0 +1,30 @@
+"""A/B of the flash-attention K/V^T ring depth (SUPIR_ATTN_RING=2|3|4, read once per process) at the step's shapes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from supir_amd import ops
+
+BF = torch.bfloat16
+for (B, H, Tq, Tk) in [(2, 20, 1024, 1024), (2, 10, 4096, 4096), (2, 20, 1024, 77), (2, 10, 4096, 77), (2, 10, 4096, 1024),
+                       (1, 1, 16384, 16384)]:
+    C = H * 64
+    q = torch.randn(B, Tq, C, device="cuda").to(BF)
+    k = torch.randn(B, Tk, C, device="cuda").to(BF)
+    Tp = (Tk + 63) // 64 * 64
+    vt = torch.zeros(B, C, Tp, device="cuda", dtype=BF)
+    vt[:, :, :Tk] = torch.randn(B, C, Tk, device="cuda").to(BF)
+    for _ in range(3):
+        ops.flash_attn(q, k, vt, B, H, Tq, Tk)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        ops.flash_attn(q, k, vt, B, H, Tq, Tk)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 50 * 1e-3
+    print(dict(ring=os.environ.get("SUPIR_ATTN_RING", "default"), B=B, H=H, Tq=Tq, Tk=Tk, us=round(t * 1e6, 1),
+               tflops=round(4.0 * B * H * Tq * Tk * 64 / t / 1e12, 1)), flush=True)
