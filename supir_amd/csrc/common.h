@@ -29,7 +29,6 @@ typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 int supir_note_hip_status(hipError_t e);
 #define SUPIR_LAUNCH_STATUS() supir_note_hip_status(hipGetLastError())
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
 // fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
 typedef float supir_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 supir_bf16x2 __attribute__((ext_vector_type(2)));

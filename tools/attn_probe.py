@@ -1,4 +1,5 @@
-"""A/B of the flash-attention K/V^T ring depth (SUPIR_ATTN_RING=2|3|4, read once per process) at the step's shapes."""
+"""A/B of the flash-attention workgroup size (SUPIR_ATTN_NW=2|4 waves, read once per process; unset = heuristic) at the
+step's shapes."""
 import os
 import sys
 
@@ -26,5 +27,5 @@ for (B, H, Tq, Tk) in [(2, 20, 1024, 1024), (2, 10, 4096, 4096), (2, 20, 1024, 7
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 50 * 1e-3
-    print(dict(ring=os.environ.get("SUPIR_ATTN_RING", "default"), B=B, H=H, Tq=Tq, Tk=Tk, us=round(t * 1e6, 1),
+    print(dict(nw=os.environ.get("SUPIR_ATTN_NW", "auto"), B=B, H=H, Tq=Tq, Tk=Tk, us=round(t * 1e6, 1),
                tflops=round(4.0 * B * H * Tq * Tk * 64 / t / 1e12, 1)), flush=True)
