@@ -154,6 +154,13 @@ int supir_pointwise_nchw(const float* x, const float* w, const float* bias, floa
  * autocast casts every step (sgm/modules/diffusionmodules/wrappers.py:87). */
 int supir_prefetch(const void* p, size_t bytes, void* sink, void* stream);
 
+/* One-shot request, consumed by the NEXT supir_gemm_bf16 / supir_gemm_bf16_ln / supir_conv3x3_bf16 call made from this thread:
+ * that launch, after its last store, touches the first `bytes` (whole 128-byte lines) of `p` so that a LATER launch finds
+ * them in the Infinity Cache / L2 instead of HBM.  `p` is the bf16 weight matrix of that later launch (the host mirror knows
+ * the launch order of a network call: supir_amd/ops.py WeightPrefetch).  Read-only, results unaffected; bytes = 0 cancels.
+ * No reference counterpart (the reference's cuBLAS / cuDNN calls meet every weight cold each step as well). */
+int supir_set_next_prefetch(const void* p, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

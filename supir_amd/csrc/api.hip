@@ -1,5 +1,6 @@
 // extern "C" surface of libsupir_hip.so (declared in include/supir_hip.h): argument validation + packing only.
 #include "kernels.h"
+#include <stdlib.h>
 #include "../../include/supir_hip.h"
 
 static thread_local int g_last_hip_error = 0;
@@ -9,7 +10,25 @@ int supir_note_hip_status(hipError_t e) {
     return SUPIR_ERR_HIP;
 }
 
+// one-shot prefetch request, consumed by the next GEMM / conv launch issued from this thread
+static thread_local const char* g_pf_ptr = nullptr;
+static thread_local unsigned g_pf_lines = 0;
+static void take_prefetch(GemmArgs& a) {
+    a.pf_ptr = g_pf_ptr;
+    a.pf_lines = g_pf_lines;
+    g_pf_ptr = nullptr;
+    g_pf_lines = 0;
+}
+
 extern "C" {
+
+int supir_set_next_prefetch(const void* p, size_t bytes) {
+    if (bytes && !p) return SUPIR_ERR_ARG;
+    const size_t lines = bytes / 128;
+    g_pf_ptr = (const char*)p;
+    g_pf_lines = lines > 0x7fffffffu ? 0x7fffffffu : (unsigned)lines;
+    return SUPIR_OK;
+}
 
 int supir_last_hip_error(void) { return g_last_hip_error; }
 const char* supir_hip_error_string(int code) { return hipGetErrorString((hipError_t)code); }
@@ -32,6 +51,7 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
     a.act = act; a.out_mode = out_mode; a.alpha = alpha;
     if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)))
         return SUPIR_ERR_SHAPE;
+    take_prefetch(a);
     return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
 }
 
@@ -58,6 +78,7 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
         const int bn = (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
         if ((N + bn - 1) / bn > rs_ld || (rs_ld & 1)) return SUPIR_ERR_ARG;
     }
+    take_prefetch(a);
     return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
 }
 
@@ -85,6 +106,7 @@ int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int 
     a.H = H; a.W = Wd; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
     a.up = upsample ? 1 : 0;
     a.act = act; a.out_mode = out_mode; a.alpha = alpha;
+    take_prefetch(a);
     return supir_gemm_launch(a, true, (hipStream_t)stream, tile);
 }
 

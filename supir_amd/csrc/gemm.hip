@@ -45,7 +45,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // waves per SIMD the register allocator must leave room for: as many workgroups as the LDS ring lets a CU hold
 constexpr int gemm_min_waves(int BM, int BN, int WM, int WN, int S) {
-    int blocks = 163840 / (S * (BM + BN) * 128);
+    int blocks = 163840 / (S * (BM + BN) * 128 + 256);
     if (blocks < 1) blocks = 1;
     int w = blocks * WM * WN / 4;
     return w < 1 ? 1 : (w > 6 ? 6 : w);
@@ -184,6 +184,25 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
     // S-deep LDS ring, ONE barrier per K step: loads for tile kt+S-1 are issued right after the barrier of step kt (into
     // the buffer step kt-1 just finished reading) and stay in flight across the next S-2 barriers (counted vmcnt).
     // With M = 2048 the grid is only 1-2 workgroups per CU, so latency hiding has to come from this queue depth.
+    // Weights are read once per network call and the two models hold ~5 GB of them, so every launch meets its W cold in HBM
+    // and pays that latency on each K step (tools/cold_probe.py: +25..40 %).  On its way out each wave touches a slice of a
+    // LATER launch's weights: one 4-byte global->LDS load per 128-byte line into a scratch LDS row behind the ring that nothing
+    // reads, issued after the last store so nothing in this kernel ever waits on it (the hardware drains it at s_endpgm with
+    // the store acks).  Measured on the 1024^2 step under graph replay: -4..5.5 % with the weight of the NEXT launch; issuing
+    // before the main loop instead (more lead time, but the K steps' vmcnt waits then cover these loads) gave only -2.6 %,
+    // and looking 2 / 3 / 4 / 8 launches ahead gave -4.4 / -2.3 / -2.0 / +0.5 %.
+    auto prefetch_next = [&]() {
+        const unsigned pf_lines = p.pf_lines;
+        if (pf_lines == 0) return;
+        const unsigned total_waves = gridDim.x * (NT / 64), gw = blockIdx.x * (NT / 64) + wave;
+        const unsigned n_instr = (pf_lines + 63) >> 6;
+        for (unsigned i = gw; i < n_instr; i += total_waves) {
+            unsigned line = i * 64 + lane;
+            line = line < pf_lines ? line : pf_lines - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.pf_ptr + (size_t)line * 128),
+                                             (__attribute__((address_space(3))) void*)(smem + S * STAGE), 4, 0, 0);
+        }
+    };
     const int nk = p.K >> 6;
 #ifdef SUPIR_GEMM_TIMELINE
     unsigned long long tl_wait = 0, tl_bar = 0, tl_issue = 0, tl_comp = 0;
@@ -382,6 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
                     }
                 }
             }
+        prefetch_next();
         return;
     } else {
         // D[i = channel][j = token]: lane owns token l31, channels (r&3)+8*(r>>2)+4*half -> 4 consecutive channels.
@@ -420,6 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
                     }
                 }
             }
+            prefetch_next();
             return;
         }
         // bf16 output can go through a wave-private LDS block (row stride padded by 16 B) so that the global stores are
@@ -550,6 +571,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
                 dst[1] = sq;
             }
         }
+        prefetch_next();
     }
 #ifdef SUPIR_GEMM_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -606,7 +628,7 @@ static int launch_gemm(const GemmArgs& a_in, hipStream_t st) {
         choose_xcd_grid(a, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a_bytes, 2.0 * (double)a.N * a.K);
     }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    constexpr int smem = S * (BM + BN) * 128;
+    constexpr int smem = S * (BM + BN) * 128 + 256;   // ring + the prefetch scratch row
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, S, CONV, TRANS>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -25,6 +25,10 @@ struct GemmArgs {
     int ln_ld, ln_slots;    //           row stride (slots) and number of valid slots to sum
     const float* ln_colsum; // consumer: [N] sum_k W'[n][k]
     float ln_eps;
+    // ---- next-weight prefetch (supir_set_next_prefetch): 128-byte lines of a LATER launch's weight matrix that this launch
+    // touches on its way out, so they are in the Infinity Cache / L2 instead of HBM when that launch streams them
+    const char* pf_ptr;
+    unsigned pf_lines;
 };
 
 struct AttnArgs {

@@ -20,10 +20,12 @@ class ControlWrapper(nn.Module):
         self._graph_on = False
         self._graphs = {}
         self.overlap_branches = True   # GLVControl || UNet encoder on two HIP streams
-        # weight prefetch inside captured graphs, `distance` ops ahead (ops.WeightPrefetch).  Measured on MI355X: the cold-weight
-        # penalty is real (tools/cold_probe.py: +25..40 % per GEMM) and a side-stream touch recovers 16 % on K = 5120 GEMMs in
-        # isolation, but 1168 extra graph nodes + event edges per step cost more than they save (44.3 -> 62-65 ms): off.
-        self.prefetch_distance = 0
+        # Weight prefetch inside captured graphs: op i's GEMM kernel touches the weight of op i+distance on its way out
+        # (ops.WeightPrefetch, supir_set_next_prefetch).  The cold-weight penalty is +25..40 % per GEMM (tools/cold_probe.py).
+        # The earlier form -- a prefetch launch per op on a third stream -- cost more in graph nodes than it saved
+        # (44.3 -> 62-65 ms per step); this one adds no launches.  0 = off.
+        self.prefetch_distance = 1     # measured: 1 -> -4..5.5 % per step, 2 -> -4.4 %, 4 -> -2 %, 8 -> +0.5 %
+        self.prefetch_kind = "inline"
         self._side = None
         self._warm = False
 
@@ -98,7 +100,7 @@ class ControlWrapper(nn.Module):
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             from .. import ops
-            pf = ops.WeightPrefetch(self.prefetch_distance) if self.prefetch_distance > 0 else None
+            pf = ops.WeightPrefetch(self.prefetch_distance, self.prefetch_kind) if self.prefetch_distance > 0 else None
             with torch.cuda.stream(s):
                 self._forward_eager(sx, st, cond, control_scale)
                 if pf is not None:            # second warm-up pass doubles as the recording pass (op order is static)

@@ -156,13 +156,16 @@ def _autotune(key, candidates, launch):
 
 # --------------------------------------------------------------------------------------------- weight prefetch plan
 class WeightPrefetch:
-    """Record the order in which weight matrices are consumed during one network call, then (while the same call is being
-    captured into a hipGraph) launch `supir_prefetch` for the weight of op i+distance on a dedicated stream as soon as op i
-    is reached.  The dependency op i -> prefetch(i+distance) is an event edge, so the prefetcher can never run further
-    ahead than `distance` ops (the Infinity Cache holds ~256 MB, a few dozen layers)."""
+    """Record the order in which weight matrices are consumed during one network call; while the same call is replayed
+    (normally: captured into a hipGraph) make the launch of op i pull the weight of op i+distance towards the caches.
 
-    def __init__(self, distance=4):
+    mode "inline" (default): `supir_set_next_prefetch` -- op i's own GEMM kernel touches the later weight after its last
+    store; no extra launches, streams or graph edges.  mode "stream": a `supir_prefetch` launch per op on a dedicated stream
+    behind an event edge (kept for tools/cold_probe.py; measured slower end to end: +1168 graph nodes per step)."""
+
+    def __init__(self, distance=1, kind="inline"):
         self.distance = distance
+        self.kind = kind
         self.plan = []
         self.mode = None
         self.idx = 0
@@ -174,6 +177,8 @@ class WeightPrefetch:
 
     def begin_replay(self, device):
         self.mode, self.idx = "replay", 0
+        if self.kind != "stream":
+            return
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=device)
             self.sink = torch.zeros(4, dtype=torch.int32, device=device)
@@ -184,8 +189,11 @@ class WeightPrefetch:
             lib.supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
 
     def end(self):
-        if self.mode == "replay" and self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)     # join (required inside a capture)
+        if self.mode == "replay":
+            if self.kind == "stream" and self.stream is not None:
+                torch.cuda.current_stream().wait_stream(self.stream)     # join (required inside a capture)
+            else:
+                _lib.load().supir_set_next_prefetch(None, 0)
         self.mode = None
 
     def touch(self, w):
@@ -194,13 +202,19 @@ class WeightPrefetch:
         elif self.mode == "replay":
             i = self.idx
             self.idx += 1
-            j = i + self.distance
-            if j < len(self.plan) and i < len(self.plan) and self.plan[i][0] == w.data_ptr():
+            # wrap around: the last ops of a step prefetch the first weights of the next step (same graph replayed 50 times)
+            if i >= len(self.plan) or self.plan[i][0] != w.data_ptr():
+                return
+            ptr, nb = self.plan[(i + self.distance) % len(self.plan)]
+            if self.kind == "stream":
+                if i + self.distance >= len(self.plan):
+                    return
                 ev = torch.cuda.Event()
                 ev.record()                       # on the op's own stream: "op i is next"
                 self.stream.wait_event(ev)
-                ptr, nb = self.plan[j]
                 _lib.load().supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
+            else:
+                _lib.load().supir_set_next_prefetch(ptr, nb)
 
 
 _PF = None

@@ -40,7 +40,7 @@ with torch.no_grad():
         print(f"  {k:16s} launches {n:5d}  TFLOP {f / 1e12:8.3f}  GB {b / 1e9:8.3f}")
     print("  total launches", len(tr), "TFLOP", sum(r["flops"] for r in tr) / 1e12)
     for rep in range(2):
-        for dist in (0, 3, 8, 20):
+        for dist in (0, 1, 2, 3):
             wrap.prefetch_distance = dist
             wrap.overlap_branches = True
             wrap.enable_graph(False)
