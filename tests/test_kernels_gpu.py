@@ -368,3 +368,26 @@ def test_gemm_layernorm_folding(M, C, N, tile):
     Tp = (T + 63) // 64 * 64
     outt = ops.gemm_ln(x, wf, bf_, ln=st, colsum=cs, trans=(B, T, Tp), tile=tile)
     check(outt[:, :, :T], ref.view(B, T, N).permute(0, 2, 1), rel=6e-3, name="ln-fold-T")
+
+
+@pytest.mark.parametrize("nbytes", [0, 128, 1000, 3 * 1280 * 1280 * 2])
+@pytest.mark.parametrize("tile", [-1, 0, 3, 5])
+def test_next_weight_prefetch_is_read_only(nbytes, tile):
+    """supir_set_next_prefetch: the launch that carries the request returns bit-identical results, the request is one-shot,
+    and the prefetched buffer is untouched (whole 128-byte lines only, so 1000 bytes -> 7 lines)."""
+    from supir_amd import _lib
+    lib = _lib.load()
+    a = rnd(300, 640).to(BF)
+    w = rnd(320, 640, scale=640 ** -0.5, seed=1).to(BF)
+    b = rnd(320, seed=2)
+    nxt = rnd(3 * 1280, 1280, seed=3).to(BF)
+    nxt_copy = nxt.clone()
+    ref = ops.gemm(a, w, b, tile=tile)
+    assert lib.supir_set_next_prefetch(nxt.data_ptr(), nbytes) == 0
+    out = ops.gemm(a, w, b, tile=tile)          # consumes the request
+    out2 = ops.gemm(a, w, b, tile=tile)         # no request pending any more
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(out2, ref)
+    assert torch.equal(nxt, nxt_copy)
+    assert lib.supir_set_next_prefetch(None, 128) != 0      # bytes without a pointer is an argument error
+    assert lib.supir_set_next_prefetch(None, 0) == 0

