@@ -121,6 +121,22 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
     const bf16_t* zero = (const bf16_t*)g_zero_page;
 
     int ld_k0 = 0, ld_cin0 = 0, ld_ky = 0, ld_kx = 0;  // position of the NEXT tile to stage
+    // conv: the tap (ky, kx) only changes every Cin/64 K steps, so the gather address of each A row (or "padding": null ->
+    // zero page) is computed once per tap, not once per load: the im2col arithmetic was ~800 of the 1800-1950 cycles a K step
+    // of the 128x128 conv tile took (s_memtime; the plain GEMM's K step is ~1050)
+    const bf16_t* a_tap[A_LOADS];
+    auto conv_set_tap = [&]() {
+        if constexpr (CONV) {
+#pragma unroll
+            for (int j = 0; j < A_LOADS; ++j) {
+                int iy = a_iy0[j] + ld_ky, ix = a_ix0[j] + ld_kx;
+                const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                a_tap[j] = ok ? a_ptr[j] + ((size_t)iy * p.W + ix) * p.lda : nullptr;
+            }
+        }
+    };
+    conv_set_tap();
     // one global->LDS instruction (q < A_LOADS: A rows, else W rows) of the tile at the current stage position
     auto stage_one = [&](int buf, int q) {
         char* sA = smem + buf * STAGE;
@@ -128,14 +144,8 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
         if (q < A_LOADS) {
             const int j = q;
             const bf16_t* src;
-            if constexpr (CONV) {
-                int iy = a_iy0[j] + ld_ky, ix = a_ix0[j] + ld_kx;
-                const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW;
-                if (p.up) { iy >>= 1; ix >>= 1; }
-                src = ok ? a_ptr[j] + ((size_t)iy * p.W + ix) * p.lda + ld_cin0 : zero;
-            } else {
-                src = a_ptr[j] + ld_k0;
-            }
+            if constexpr (CONV) src = a_tap[j] ? a_tap[j] + ld_cin0 : zero;
+            else src = a_ptr[j] + ld_k0;
             glds16(src, sA + (j * NT + wave * 64) * 16);
         } else {
             const int j = q - A_LOADS;
@@ -149,6 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
             if (ld_cin0 == p.Cin) {
                 ld_cin0 = 0;
                 if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }
+                conv_set_tap();
             }
         }
     };

@@ -73,5 +73,49 @@ int main() {
             }
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(bias));
     }
+    // implicit-GEMM 3x3 convolutions of the step (stride 1, pad 1): [B][H][W][Cin] -> [B][H][W][Cout]
+    struct Conv { int B, H, W, Cin, Cout; };
+    const Conv convs[] = {{2, 32, 32, 1280, 1280}, {2, 64, 64, 640, 640}, {2, 128, 128, 320, 320}};
+    for (const Conv& c : convs) {
+        const int M = c.B * c.H * c.W, K = 9 * c.Cin;
+        bf16_t *X, *W, *Y;
+        float* bias;
+        CK(hipMalloc(&X, (size_t)M * c.Cin * 2));
+        CK(hipMalloc(&W, (size_t)c.Cout * K * 2));
+        CK(hipMalloc(&Y, (size_t)M * c.Cout * 2));
+        CK(hipMalloc(&bias, (size_t)c.Cout * 4));
+        CK(hipMemset(X, 0x3c, (size_t)M * c.Cin * 2));
+        CK(hipMemset(W, 0x3c, (size_t)c.Cout * K * 2));
+        CK(hipMemset(bias, 0, (size_t)c.Cout * 4));
+        for (int tile : tiles) {
+            GemmArgs a = {};
+            a.A = X; a.Wt = W; a.C = Y; a.bias = bias;
+            a.M = M; a.N = c.Cout; a.K = K; a.lda = c.Cin; a.ldc = c.Cout; a.rows_per_batch = c.H * c.W; a.alpha = 1.f;
+            a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.OH = c.H; a.OW = c.W; a.stride = 1; a.pad_t = 1; a.pad_l = 1;
+            const int ft = tile | (1 << 3);
+            for (int i = 0; i < 3; ++i) supir_gemm_launch(a, true, st, ft);
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < 10; ++i) supir_gemm_launch(a, true, st, ft);
+            CK(hipEventRecord(e1, st));
+            CK(hipStreamSynchronize(st));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const int nblk = ((M + tb[tile][0] - 1) / tb[tile][0]) * ((c.Cout + tb[tile][1] - 1) / tb[tile][1]);
+            const int nw = nblk * tb[tile][2];
+            std::vector<unsigned long long> h((size_t)nw * 8);
+            CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
+            double sum[8] = {0};
+            for (int w = 0; w < nw; ++w)
+                for (int q = 1; q < 8; ++q) sum[q] += (double)h[(size_t)w * 8 + q];
+            const int nk = K / 64;
+            printf("conv B=%d %dx%d Cin=%d Cout=%d tile=%d blocks=%d | event %.1f us, TF %.0f | per wave: prologue %.0f | per K step (%d): wait %.0f  "
+                   "barrier %.0f  issue %.0f  lds+mfma %.0f | epilogue %.0f | total %.0f\n",
+                   c.B, c.H, c.W, c.Cin, c.Cout, tile, nblk, ms * 1000 / 10, 2.0 * M * c.Cout * K / (ms * 1e-3 / 10) / 1e12, sum[1] / nw, nk,
+                   sum[2] / nw / nk, sum[3] / nw / nk, sum[4] / nw / nk, sum[5] / nw / nk, sum[6] / nw, sum[7] / nw);
+            fflush(stdout);
+        }
+        CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(Y)); CK(hipFree(bias));
+    }
     return 0;
 }
