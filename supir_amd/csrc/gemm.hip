@@ -13,13 +13,17 @@
 //    bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the ds_read_b128 side:
 //    16-B chunk c of row r lives at chunk c ^ ((r>>1)&7)  (conflict-free for the 32x32x16 fragment read);
 //  * 3x3 convolution is the same kernel with an im2col gather in the A loader: K runs (ky,kx,cin) and a
-//    64-wide K step never straddles a tap because Cin % 64 == 0; halo / padding lanes read a zero page;
-//    stride 2, asymmetric padding (VAE Downsample) and nearest-2x upsampling are folded into the gather;
-//  * v_mfma_f32_32x32x16_bf16, 4 waves (2x2), operands swapped (a = W rows, b = A rows) so that every lane
-//    ends up with 4 consecutive output channels of one token -> 8-byte bf16 stores, fused epilogue
-//    (bias, per-batch time-embedding add, residual add, SiLU, GEGLU, scale);
-//  * double-buffered LDS, counted vmcnt so the next K tile stays in flight across the barrier;
-//  * XCD-aware workgroup -> tile mapping (8 private L2s).
+//    64-wide K step never straddles a tap because Cin % 64 == 0; the gather address of each row is computed once
+//    per tap; halo / padding lanes read a zero page; stride 2, asymmetric padding (VAE Downsample) and
+//    nearest-2x upsampling are folded into the gather;
+//  * v_mfma_f32_32x32x16_bf16, 4 (or 8) waves, operands swapped (a = W rows, b = A rows) so that every lane
+//    ends up with 4 consecutive output channels of one token; fused epilogue (bias, per-batch time-embedding add,
+//    residual add, SiLU, GEGLU, scale, LayerNorm fold / row statistics), bf16 output staged through LDS so the
+//    global stores are 16 B per lane and row-contiguous;
+//  * S-deep LDS ring (2 by default), ONE raw s_barrier per K step, counted vmcnt for S > 2; the next tile's
+//    global->LDS instructions are interleaved with the MFMA groups of the current one;
+//  * XCD-aware workgroup -> tile mapping (8 private L2s); one-shot prefetch of a later launch's weights on the way out.
+// tools/probes/gemm_timeline.hip builds this file with -DSUPIR_GEMM_TIMELINE for a per-phase s_memtime breakdown.
 #include "kernels.h"
 #include <stdlib.h>
 #include <type_traits>

@@ -229,3 +229,45 @@ def test_plugin_install_registers_reference_paths():
     from supir_amd.modules.supir_v0 import LightGLVUNet
     assert importlib.import_module("SUPIR.modules.SUPIR_v0").LightGLVUNet is LightGLVUNet
     assert sys.modules["sgm.util"].get_obj_from_str("sgm.modules.diffusionmodules.sampling.RestoreEDMSampler") is S.RestoreEDMSampler
+
+
+def test_weight_prefetch_plan_is_one_shot_per_op_and_wraps(monkeypatch):
+    """ops.WeightPrefetch (inline kind): the record pass logs (ptr, bytes) per weight op; in the replay pass op i asks the
+    C ABI to prefetch the weight of op i+distance (wrapping to the first ops: the same graph is replayed every step), a
+    mismatching op order issues nothing, and end() cancels a pending request."""
+    from supir_amd import ops
+
+    calls = []
+
+    class FakeLib:
+        def supir_set_next_prefetch(self, ptr, nbytes):
+            calls.append((ptr, nbytes))
+            return 0
+
+    monkeypatch.setattr(ops._lib, "load", lambda: FakeLib())
+    ws = [torch.zeros(n, 8, dtype=torch.bfloat16) for n in (4, 6, 8)]
+    pf = ops.WeightPrefetch(distance=1)
+    ops.set_prefetch(pf)
+    try:
+        pf.begin_record()
+        for w in ws:
+            ops._pf(w)
+        pf.end()
+        assert pf.plan == [(w.data_ptr(), w.numel() * 2) for w in ws] and calls == []
+        pf.begin_replay(torch.device("cpu"))
+        for w in ws:
+            ops._pf(w)
+        assert calls == [pf.plan[1], pf.plan[2], pf.plan[0]]
+        calls.clear()
+        pf.end()
+        assert calls == [(None, 0)]                      # pending request cancelled
+        calls.clear()
+        pf.begin_replay(torch.device("cpu"))
+        ops._pf(ws[1])                                   # not the recorded first op: stay silent rather than prefetch garbage
+        assert calls == []
+        pf.end()
+        calls.clear()
+        ops._pf(ws[0])                                   # no pass active
+        assert calls == []
+    finally:
+        ops.set_prefetch(None)
