@@ -244,10 +244,17 @@ def _sliding_windows(h, w, tile_size, tile_stride):
 class TiledRestoreEDMSampler(RestoreEDMSampler):
     """sampling.py:600-660: per step, every 128x128 latent tile takes a full sampler step; Gaussian-weighted blend."""
 
-    def __init__(self, tile_size=128, tile_stride=64, *args, tile_batch=1, **kwargs):
+    def __init__(self, tile_size=128, tile_stride=64, *args, tile_batch=1, tile_parallel=False, process_group=None, **kwargs):
         super().__init__(*args, **kwargs)
         self.tile_size, self.tile_stride = tile_size, tile_stride
         self.tile_weights = None
+        # SURVEY 8(f).1: with `tile_parallel` and an initialised torch.distributed group, the tile groups of a step are dealt
+        # round-robin to the ranks (one process per GPU); every rank blends its own tiles into a zero canvas and ONE all-reduce
+        # (sum, RCCL) of that canvas per step assembles x_next -- the only exchange the algorithm needs (the normalising
+        # `count` canvas is tile-geometry only, computed locally).  Rank 0's start latent and per-step churn noise are broadcast
+        # so the ranks cannot drift apart even if their RNG streams differ.
+        self.tile_parallel = bool(tile_parallel)
+        self.process_group = process_group
         # tiles of one step are independent given x and eps_noise (sampling.py:629-657): `tile_batch` > 1 stacks that many
         # tiles along the batch axis of ONE denoiser call (M of every GEMM grows k-fold, 49 -> ceil(49/k) launches of the
         # network per step); per-tile arithmetic is unchanged, so the result is identical.
@@ -275,13 +282,28 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
             cat = self.guider.prepare_cond({k: v for k, v in cj.items() if k != "control"},
                                            {k: v for k, v in uc.items() if k != "control"})
             static.append(cat)
+        import torch.distributed as dist
+        world, rank = 1, 0
+        if self.tile_parallel and dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        kb = 1 if use_local_prompt else self.tile_batch
+        if world > 1:
+            src = dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0
+            x = x.contiguous()
+            dist.broadcast(x, src=src, group=self.process_group)
+            count_all = torch.zeros_like(x)
+            for (hi, he, wi, we) in tiles:
+                count_all[:, :, hi:he, wi:we] += tile_weights
         for i in range(num_sigmas - 1):
             gamma = self._gamma(sf[i], num_sigmas)
             x_next = torch.zeros_like(x)
             count = torch.zeros_like(x)
             eps_noise = torch.randn_like(x)
-            kb = 1 if use_local_prompt else self.tile_batch
-            for j0 in range(0, len(tiles), kb):
+            if world > 1:
+                dist.broadcast(eps_noise, src=src, group=self.process_group)
+            for gi, j0 in enumerate(range(0, len(tiles), kb)):
+                if world > 1 and gi % world != rank:
+                    continue
                 grp = tiles[j0:j0 + kb]
                 k = len(grp)
                 if k == 1:
@@ -314,6 +336,9 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
                 for (hi, he, wi, we), _xt in zip(grp, outs):
                     x_next[:, :, hi:he, wi:we] += _xt * tile_weights
                     count[:, :, hi:he, wi:we] += tile_weights
+            if world > 1:
+                dist.all_reduce(x_next, op=dist.ReduceOp.SUM, group=self.process_group)
+                count = count_all
             x_next /= count
             x = x_next
         return x
