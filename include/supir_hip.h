@@ -148,6 +148,14 @@ int supir_conv3x3_smallcout(const void* x, const void* w, const float* bias, flo
 int supir_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
                          long HW, float in_scale, void* stream);
 
+/* One level of the colour-fix wavelet decomposition on fp32 planes [planes][H][W] (planes = N*3):
+ *   low = depthwise 3x3 blur of img, kernel [[1,2,1],[2,4,2],[1,2,1]]/16, dilation `radius`, replicate padding;
+ *   high = (first ? 0 : high) + (img - low).
+ * img / low / high must be three distinct buffers.  Replaces the F.conv2d(F.pad(..., 'replicate'), groups=3, dilation=radius)
+ * of wavelet_blur / wavelet_decomposition, SUPIR/utils/colorfix.py:73-107 (called from SUPIR_model.py:129-131). */
+int supir_wavelet_level(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
+                        void* stream);
+
 /* Touch one dword per 128-byte line of [p, p+bytes) (a weight matrix) so that it is in flight through the memory-side
  * cache before the kernel that consumes it starts; launched a few ops ahead on a separate stream. `sink`: any 4 writable
  * device bytes (never written in practice). No reference counterpart: the reference re-reads fp32 weights through

@@ -31,6 +31,7 @@ SIGNATURES = {
     "supir_conv3x3_smallcin": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "supir_conv3x3_smallcout": [P, P, P, P, I, I, I, I, I, I, P],
     "supir_pointwise_nchw": [P, P, P, P, I, I, I, L, F, P],
+    "supir_wavelet_level": [P, P, P, I, I, I, I, I, P],
     "supir_gemm_tile_for": [I, I, I],
     "supir_prefetch": [P, c_size_t, P, P],
     "supir_set_next_prefetch": [P, c_size_t],

@@ -184,4 +184,10 @@ int supir_pointwise_nchw(const float* x, const float* w, const float* bias, floa
     return supir_pointwise_nchw_launch(x, w, bias, out, B, Cin, Cout, HW, in_scale, (hipStream_t)stream);
 }
 
+int supir_wavelet_level(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
+                        void* stream) {
+    if (!img || !low || !high) return SUPIR_ERR_ARG;
+    return supir_wavelet_level_launch(img, low, high, planes, H, W, radius, first, (hipStream_t)stream);
+}
+
 }  // extern "C"

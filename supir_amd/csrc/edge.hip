@@ -9,6 +9,7 @@
 //   conv3x3_smallcout: bf16 NHWC [B,H,W,Cin] -> fp32 NCHW [B,Cout<=8,H,W]   UNet out.2 (320->4), VAE encoder conv_out
 //                      (512->8), VAE decoder conv_out (128->3)               (openaimodel.py:951, model.py:563,694)
 //   pointwise_nchw   : fp32 NCHW 1x1 conv with <= 8 channels                 quant_conv / post_quant_conv
+//   wavelet_level    : one level of the colour-fix wavelet decomposition (fp32 NCHW)   SUPIR/utils/colorfix.py:73-119
 //                                                                            (sgm/models/autoencoder.py:297-298)
 // All three are HBM / latency bound (a few MFLOP..GFLOP); none is worth MFMA.
 #include "kernels.h"
@@ -233,3 +234,36 @@ int supir_prefetch_launch(const void* p, size_t bytes, void* sink, hipStream_t s
     SUPIR_LAUNCH(prefetch_lines_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)p, lines, (uint32_t*)sink);
     return SUPIR_LAUNCH_STATUS();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// One level of wavelet_decomposition (SUPIR/utils/colorfix.py:73-107): low = blur_r(img) with the fixed 3x3 kernel
+// [[1,2,1],[2,4,2],[1,2,1]]/16 applied depthwise at dilation r on a replicate-padded image (== clamped taps), and
+// high (+)= img - low.  fp32 planes [planes][H][W]; HBM-trivial: 1 read + 2 writes (+1 read-modify-write) per pixel.
+__global__ __launch_bounds__(256) void wavelet_level_kernel(const float* __restrict__ img, float* __restrict__ low,
+                                                             float* __restrict__ high, int H, int W, int r, int first) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const float* p = img + plane;
+    const int ym = y - r > 0 ? y - r : 0, yp = y + r < H - 1 ? y + r : H - 1;
+    const int xm = x - r > 0 ? x - r : 0, xp = x + r < W - 1 ? x + r : W - 1;
+    const float* r0 = p + (size_t)ym * W;
+    const float* r1 = p + (size_t)y * W;
+    const float* r2 = p + (size_t)yp * W;
+    const float c = r1[x];
+    const float corners = (r0[xm] + r0[xp]) + (r2[xm] + r2[xp]);
+    const float edges = (r0[x] + r2[x]) + (r1[xm] + r1[xp]);
+    const float lo = 0.0625f * corners + 0.125f * edges + 0.25f * c;
+    const size_t o = plane + (size_t)y * W + x;
+    low[o] = lo;
+    high[o] = (first ? 0.f : high[o]) + (c - lo);
+}
+
+int supir_wavelet_level_launch(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
+                               hipStream_t st) {
+    if (planes <= 0 || H <= 0 || W <= 0 || radius <= 0 || planes > 65535 || H > 65535) return SUPIR_ERR_SHAPE;
+    if (img == low || img == high || low == high) return SUPIR_ERR_ARG;
+    SUPIR_LAUNCH(wavelet_level_kernel, dim3((W + 255) / 256, H, planes), dim3(256), 0, st, img, low, high, H, W, radius, first);
+    return SUPIR_LAUNCH_STATUS();
+}
+

@@ -77,4 +77,6 @@ int supir_conv3x3_smallcout_launch(const bf16_t* x, const bf16_t* w, const float
                                    int W, int Cout, int ldx, hipStream_t st);
 int supir_pointwise_nchw_launch(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
                                 long HW, float in_scale, hipStream_t st);
+int supir_wavelet_level_launch(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
+                               hipStream_t st);
 int supir_prefetch_launch(const void* p, size_t bytes, void* sink, hipStream_t st);

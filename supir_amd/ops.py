@@ -578,3 +578,22 @@ def pointwise_nchw(x, w, bias, in_scale=1.0):
                                   _stream())
     _lib.check(rc, "supir_pointwise_nchw")
     return out
+
+
+def wavelet_decomposition(img, levels=5):
+    """(high, low) of SUPIR/utils/colorfix.py:96-107 on fp32 [N,3,H,W]: `levels` launches of supir_wavelet_level (radius 2^i),
+    ping-ponging two low-pass buffers; `high` accumulates img_i - low_i in place."""
+    lib = _lib.load()
+    _check_dev(img)
+    assert img.dtype == torch.float32 and img.dim() == 4
+    cur = img.contiguous()
+    N, C, H, W = cur.shape
+    high = torch.empty_like(cur)
+    bufs = [torch.empty_like(cur), torch.empty_like(cur)]
+    for i in range(levels):
+        low = bufs[i & 1]
+        rc = lib.supir_wavelet_level(cur.data_ptr(), low.data_ptr(), high.data_ptr(), N * C, H, W, 2 ** i, int(i == 0),
+                                     _stream())
+        _lib.check(rc, "supir_wavelet_level")
+        cur = low
+    return high, cur

@@ -391,3 +391,54 @@ def test_next_weight_prefetch_is_read_only(nbytes, tile):
     assert torch.equal(nxt, nxt_copy)
     assert lib.supir_set_next_prefetch(None, 128) != 0      # bytes without a pointer is an argument error
     assert lib.supir_set_next_prefetch(None, 0) == 0
+
+
+def _wavelet_ref(img, levels=5):
+    """fp32 torch restatement of SUPIR/utils/colorfix.py:73-107 (replicate pad + depthwise dilated 3x3 blur)."""
+    k = torch.tensor([[0.0625, 0.125, 0.0625], [0.125, 0.25, 0.125], [0.0625, 0.125, 0.0625]], dtype=torch.float32)
+    k = k[None, None].repeat(3, 1, 1, 1)
+    img = img.double().cpu()
+    k = k.double()
+    high = torch.zeros_like(img)
+    low = img
+    for i in range(levels):
+        r = 2 ** i
+        low = F.conv2d(F.pad(img, (r,) * 4, mode="replicate"), k, groups=3, dilation=r)
+        high = high + (img - low)
+        img = low
+    return high, low
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (2, 3, 40, 72), (1, 3, 7, 5), (1, 3, 257, 300), (1, 3, 1, 1)])
+def test_wavelet_decomposition(shape):
+    """supir_wavelet_level x5 vs an fp64 torch restatement of the reference's conv-based decomposition (fp32 tolerance 1e-5;
+    images smaller than the largest radius exercise the clamped == replicate-padded taps)."""
+    x = rnd(*shape, seed=11)
+    high, low = ops.wavelet_decomposition(x)
+    rh, rl = _wavelet_ref(x)
+    assert torch.isfinite(high).all() and torch.isfinite(low).all()
+    for out, ref in ((high, rh), (low, rl)):
+        ref = ref.to(out.device)
+        err = (out.double() - ref).abs().max().item()
+        assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
+    # reconstruction identity of the decomposition itself: high + low == img
+    assert (high + low - x).abs().max().item() <= 1e-5
+
+
+def test_wavelet_reconstruction_vs_reference_golden():
+    from supir_amd.utils.colorfix import wavelet_reconstruction
+    from tests.helpers import golden, synth_tensor
+    g = golden()
+    out = wavelet_reconstruction(synth_tensor("wa", (1, 3, 64, 64)).to(DEV), synth_tensor("wb", (1, 3, 64, 64)).to(DEV))
+    ref = g["wavelet"].to(DEV)
+    assert ((out - ref).norm() / ref.norm()).item() <= 1e-5
+
+
+def test_wavelet_level_rejects_aliased_buffers():
+    from supir_amd import _lib
+    lib = _lib.load()
+    a = rnd(1, 3, 8, 8)
+    b = torch.empty_like(a)
+    assert lib.supir_wavelet_level(a.data_ptr(), a.data_ptr(), b.data_ptr(), 3, 8, 8, 1, 1, None) != 0
+    assert lib.supir_wavelet_level(a.data_ptr(), b.data_ptr(), b.data_ptr(), 3, 8, 8, 1, 1, None) != 0
+    assert lib.supir_wavelet_level(a.data_ptr(), b.data_ptr(), None, 3, 8, 8, 1, 1, None) != 0
