@@ -277,10 +277,12 @@ def main():
             "metric": "1024px 50-step EDM denoise images/sec", "value": n_img / dt, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: 1xMI355X {P}x{P}, {args.edm_steps} EDM steps (RestoreEDMSampler, s_churn 5, "
+            "config": {"workload": ("configs[1]" if world == 1 else f"configs[1] on each of {world} ranks (BASELINE configs[3] shape: "
+                                    f"independent images, one per GPU)") + f": {world}xMI355X {P}x{P}, {args.edm_steps} EDM steps (RestoreEDMSampler, s_churn 5, "
                                    f"linear CFG 1.0->4.0), bf16 MFMA UNet+GLVControl+VAE, SUPIR-v0 config, 1 image per GPU per step, "
                                    f"random-init weights", "edm_steps": args.edm_steps, "resolution": P,
-                       "images_per_gpu_per_step": ipg, "hip_graph": not args.no_graph,
+                       "images_per_gpu_per_step": ipg, "parallelism": f"dp{world} (replicated weights, no collective inside a sample)",
+                       "hip_graph": not args.no_graph,
                        "two_stream_overlap": bool(model.model.overlap_branches)},
             "roofline": roofline, "cpu_baseline": cpu,
             "output_finite": finite, "weight_fill_s": round(t_fill, 2), "weight_broadcast_s": round(t_bcast, 2),
