@@ -301,17 +301,23 @@ def restore_edm_step(denoise_fn, x, sigma, next_sigma, gamma, cond, uc, x_center
 
 
 def restore_edm_sample(denoise_fn, x, cond, uc, x_center, noises, *, num_steps, s_churn, s_noise, restore_cfg,
-                       scale=1.0, scale_min=4.0, control_scale=1.0, s_tmin=0.0, s_tmax=float("inf")):
-    """RestoreEDMSampler.__call__ + prepare_sampling_loop (sampling.py:45-56, 572-597). noises[i] = churn noise of step i."""
+                       scale=1.0, scale_min=4.0, control_scale=1.0, s_tmin=0.0, s_tmax=float("inf"),
+                       use_linear_control_scale=False, control_scale_start=0.0):
+    """RestoreEDMSampler.__call__ + prepare_sampling_loop (sampling.py:45-56, 572-597). noises[i] = churn noise of step i.
+    use_linear_control_scale (sampling.py:557-559): the control scale of a step is interpolated on sigma / sigma_max between
+    `control_scale` (sigma -> 0) and `control_scale_start` (sigma = sigma_max)."""
     sigmas = torch.cat([ddpm_sigmas(num_steps, device=x.device), x.new_zeros([1])])
     x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
     n = len(sigmas)
     s_in = x.new_ones([x.shape[0]])
     for i in range(n - 1):
         gamma = min(s_churn / (n - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0
+        cs = control_scale
+        if use_linear_control_scale:
+            cs = (float(sigmas[i]) / SIGMA_MAX) * (control_scale_start - control_scale) + control_scale
         x = restore_edm_step(denoise_fn, x, s_in * sigmas[i], s_in * sigmas[i + 1], gamma, cond, uc, x_center,
                              noises[i] if noises is not None else None, s_noise=s_noise, restore_cfg=restore_cfg,
-                             scale=scale, scale_min=scale_min, control_scale=control_scale)
+                             scale=scale, scale_min=scale_min, control_scale=cs)
     return x
 
 
@@ -630,3 +636,17 @@ def vae_tiled_forward(sd, z, p, tile_size, is_decoder):
         m = [ob[i] - padded[i] for i in range(4)]
         res[:, :, ob[2]:ob[3], ob[0]:ob[1]] = o[:, :, m[2]:o.size(2) + m[3], m[0]:o.size(3) + m[1]]
     return res
+
+
+def adaptive_instance_normalization(content, style, eps=1e-5):
+    """adaptive_instance_normalization + calc_mean_std (SUPIR/utils/colorfix.py:45-70): per (n, c) mean and UNBIASED variance
+    (+eps) over the pixels; content is whitened with its own statistics and re-coloured with the style's."""
+    n, c = content.shape[:2]
+
+    def mean_std(t):
+        v = t.reshape(n, c, -1)
+        return v.mean(dim=2).view(n, c, 1, 1), (v.var(dim=2) + eps).sqrt().view(n, c, 1, 1)
+    sm, ss = mean_std(style)
+    cm, cs = mean_std(content)
+    return (content - cm) / cs * ss + sm
+

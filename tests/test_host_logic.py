@@ -271,3 +271,32 @@ def test_weight_prefetch_plan_is_one_shot_per_op_and_wraps(monkeypatch):
         assert calls == []
     finally:
         ops.set_prefetch(None)
+
+
+@pytest.mark.parametrize("name,steps,rcfg,cs,cs0", [("lin_cs_12", 12, 4.0, 1.0, 0.0), ("lin_cs_8", 8, -1.0, 0.8, 0.3)])
+def test_restore_edm_sampler_linear_control_scale_vs_reference(name, steps, rcfg, cs, cs0):
+    """batchify_sample's use_linear_control_scale / control_scale_start options (SUPIR_model.py:80-136 -> sampling.py:557-559):
+    the product sampler vs the reference run stored by oracle/gen_golden_extra.py."""
+    import os
+    from tests.helpers import GOLDEN_DIR
+    ge = torch.load(os.path.join(GOLDEN_DIR, "golden_extra.pt"), map_location="cpu", weights_only=False)
+    c, uc = _io()
+    den = S.DiscreteDenoiserWithControl()
+    smp = S.RestoreEDMSampler(num_steps=steps, s_churn=5, s_noise=1.01, restore_cfg=rcfg, device="cpu",
+                              guider_config={"target": "sgm.modules.diffusionmodules.guiders.LinearCFG",
+                                             "params": {"scale": 1.0, "scale_min": 4.0}})
+    with _Noise([synth_tensor(f"{name}.eps{i}", (1, 4, 16, 16)) for i in range(steps)]):
+        out = smp(lambda i, s, cc, s_: den(_fake_net, i, s, cc, s_), synth_tensor("noised_z", (1, 4, 16, 16)).clone(), cond=c,
+                  uc=uc, x_center=synth_tensor("x_center", (1, 4, 16, 16)), control_scale=cs, use_linear_control_scale=True,
+                  control_scale_start=cs0)
+    assert rel_l2(out, ge["sampler_" + name]) <= 5e-5
+
+
+def test_adain_colour_fix_vs_reference():
+    """color_fix_type='AdaIn' (SUPIR_model.py:132-134): two reductions + an affine map, plain torch ops in the product too."""
+    import os
+    from supir_amd.utils.colorfix import adaptive_instance_normalization
+    from tests.helpers import GOLDEN_DIR
+    ge = torch.load(os.path.join(GOLDEN_DIR, "golden_extra.pt"), map_location="cpu", weights_only=False)
+    a, b = synth_tensor("wa", (2, 3, 24, 40)), synth_tensor("wb", (2, 3, 24, 40), scale=0.5) + 0.2
+    assert rel_l2(adaptive_instance_normalization(a, b), ge["adain"]) <= 2e-6

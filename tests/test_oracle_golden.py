@@ -173,3 +173,26 @@ def test_tiled_vae(sd, g):
         assert rel_l2(dec, full) > 1e-3
     assert O.vae_split_tiles(512, 512, 64, 11, True)[0][:2] == [[0, 86, 0, 86], [64, 150, 0, 86]]
     assert len(O.vae_split_tiles(4096, 4096, 512, 32, False)[0]) == 64
+
+
+def _extra():
+    import os
+    from tests.helpers import GOLDEN_DIR
+    return torch.load(os.path.join(GOLDEN_DIR, "golden_extra.pt"), map_location="cpu", weights_only=False)
+
+
+@pytest.mark.parametrize("name,steps,rcfg,cs,cs0", [("lin_cs_12", 12, 4.0, 1.0, 0.0), ("lin_cs_8", 8, -1.0, 0.8, 0.3)])
+def test_sampler_linear_control_scale(name, steps, rcfg, cs, cs0):
+    """use_linear_control_scale / control_scale_start (sampling.py:557-559) vs the reference run (oracle/gen_golden_extra.py)."""
+    c, uc, xc, x0 = _sampler_io()
+    table = O.denoiser_table()
+    noises = [synth_tensor(f"{name}.eps{i}", (1, 4, 16, 16)) for i in range(steps)]
+    den = lambda xin, s, cc, s_: O.discrete_denoiser_with_control(_fake_net, table, xin, s, cc, s_)
+    out = O.restore_edm_sample(den, x0.clone(), c, uc, xc, noises, num_steps=steps, s_churn=5, s_noise=1.01, restore_cfg=rcfg,
+                               scale=1.0, scale_min=4.0, control_scale=cs, use_linear_control_scale=True, control_scale_start=cs0)
+    assert rel_l2(out, _extra()["sampler_" + name]) <= 5e-5
+
+
+def test_adain():
+    a, b = synth_tensor("wa", (2, 3, 24, 40)), synth_tensor("wb", (2, 3, 24, 40), scale=0.5) + 0.2
+    assert rel_l2(O.adaptive_instance_normalization(a, b), _extra()["adain"]) <= 2e-6
