@@ -19,6 +19,7 @@ class ControlWrapper(nn.Module):
         self.dtype = dtype
         self._graph_on = False
         self._graphs = {}
+        self._cs_seen = {}             # per input shape: the control scales graphs were asked for (see _forward_graph)
         self.overlap_branches = True   # GLVControl || UNet encoder on two HIP streams
         # Weight prefetch inside captured graphs: op i's GEMM kernel touches the weight of op i+distance on its way out
         # (ops.WeightPrefetch, supir_set_next_prefetch).  The cold-weight penalty is +25..40 % per GEMM (tools/cold_probe.py).
@@ -86,12 +87,20 @@ class ControlWrapper(nn.Module):
         self._graph_on = bool(on)
         if not on:
             self._graphs.clear()
+            self._cs_seen.clear()
 
     def _forward_graph(self, x, t, c, control_scale):
         ctx, vec, ctl = c["crossattn"], c["vector"], c["control"]
         key = (tuple(x.shape), float(control_scale), tuple(ctx.shape), tuple(vec.shape))
         g = self._graphs.get(key)
         if g is None:
+            # control_scale is a launch argument baked into the captured kernels.  With use_linear_control_scale
+            # (sampling.py:557-559) it changes on every step: capturing a graph per value would cost three network calls per
+            # step, so from the third distinct value on such calls run eagerly (the constant-scale case never gets here).
+            seen = self._cs_seen.setdefault((key[0], key[2], key[3]), set())
+            seen.add(key[1])
+            if len(seen) > 2:
+                return self._forward_eager(x, t, c, control_scale)
             if len(self._graphs) >= 4:
                 self._graphs.clear()
             sx, st, sc = x.clone(), t.clone(), ctl.clone()

@@ -300,3 +300,29 @@ def test_adain_colour_fix_vs_reference():
     ge = torch.load(os.path.join(GOLDEN_DIR, "golden_extra.pt"), map_location="cpu", weights_only=False)
     a, b = synth_tensor("wa", (2, 3, 24, 40)), synth_tensor("wb", (2, 3, 24, 40), scale=0.5) + 0.2
     assert rel_l2(adaptive_instance_normalization(a, b), ge["adain"]) <= 2e-6
+
+
+def test_graph_mode_runs_eagerly_when_control_scale_keeps_changing():
+    """ControlWrapper._forward_graph: a third distinct control_scale for the same shapes (use_linear_control_scale) must not
+    trigger yet another capture; the call is served by the eager path (exercised here with stand-in CPU modules)."""
+    from supir_amd.modules.wrappers import ControlWrapper
+
+    class Ctl(torch.nn.Module):
+        def forward(self, x, timesteps, xt, context=None, y=None, **kw):
+            return [xt + x]
+
+    class Net(torch.nn.Module):
+        def forward(self, x, timesteps=None, context=None, y=None, control=None, control_scale=1, **kw):
+            return x * 0.5 + control[0] * float(control_scale)
+
+    w = ControlWrapper(Net())
+    w.load_control_model(Ctl())
+    x, t = torch.ones(2, 4, 8, 8), torch.zeros(2, dtype=torch.int64)
+    c = {"crossattn": torch.zeros(2, 77, 8), "vector": torch.zeros(2, 16), "control": torch.full((2, 4, 8, 8), 2.0)}
+    shape_key = (tuple(x.shape), tuple(c["crossattn"].shape), tuple(c["vector"].shape))
+    w._cs_seen[shape_key] = {1.0, 0.9}                     # two scales already captured for these shapes
+    out = w._forward_graph(x, t, c, 0.8)                   # third value: eager, no capture attempted (this box has no GPU)
+    assert torch.allclose(out, x * 0.5 + (x + 2.0) * 0.8) and out.dtype == torch.float32
+    assert w._graphs == {} and w._cs_seen[shape_key] == {1.0, 0.9, 0.8}
+    w.enable_graph(False)
+    assert w._cs_seen == {}
