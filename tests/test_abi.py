@@ -44,3 +44,15 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     assert rc == -1
     rc = lib.supir_layernorm(None, None, None, None, 4, 64, 64, 64, 1e-5, None)
     assert rc == -1
+
+
+def test_new_entry_points_validate_arguments_without_a_gpu():
+    """supir_set_next_prefetch / supir_wavelet_level: argument errors are reported before any HIP call."""
+    lib = _lib.load()
+    assert lib.supir_set_next_prefetch(None, 4096) == -1          # bytes without a pointer
+    assert lib.supir_set_next_prefetch(None, 0) == 0              # cancel is always fine
+    assert lib.supir_wavelet_level(None, None, None, 3, 8, 8, 1, 1, None) == -1
+    fake = 0x10000                                                  # never dereferenced: validation comes first
+    assert lib.supir_wavelet_level(fake, fake, fake + 4096, 3, 8, 8, 1, 1, None) == -1      # img aliases low
+    assert lib.supir_wavelet_level(fake, fake + 4096, fake + 8192, 3, 8, 8, 0, 1, None) == -2   # radius 0: shape error
+    assert lib.supir_wavelet_level(fake, fake + 4096, fake + 8192, 70000, 8, 8, 1, 1, None) == -2   # planes > grid limit
