@@ -114,7 +114,9 @@ def _gn_workspace(B, device):
 # The GEMM kernel has four tile shapes; which one wins depends on how the (M, N) grid quantises onto 256 CUs and on K.
 # "Measure, don't guess": the first time a problem shape is seen (outside graph capture) every candidate is timed with HIP
 # events on the launch stream and the winner is cached for the life of the process.  All tiles accumulate K in the same
-# order, so the choice never changes a result bit.
+# order, so the choice never changes a bit of a GEMM's own output; the row statistics a producer GEMM emits for a folded
+# LayerNorm are summed per column tile, so THEIR fp32 summation order (and, through bf16 rounding flips, the network output at
+# its noise floor) can differ between two processes that picked different tiles.  Within a process results are reproducible.
 import os as _os
 
 _TUNE = {}
