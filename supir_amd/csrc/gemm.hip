@@ -48,27 +48,38 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // waves per SIMD the register allocator must leave room for: as many workgroups as the LDS ring lets a CU hold
-constexpr int gemm_min_waves(int BM, int BN, int WM, int WN, int S) {
-    int blocks = 163840 / (S * (BM + BN) * 128 + 256);
+constexpr int gemm_min_waves(int BM, int BN, int WM, int WN, int S, int KS) {
+    int blocks = 163840 / (KS * S * (BM + BN) * 128 + 256);
     if (blocks < 1) blocks = 1;
-    int w = blocks * WM * WN / 4;
+    int w = blocks * WM * WN * KS / 4;
     return w < 1 ? 1 : (w > 6 ? 6 : w);
 }
 
-template <int BM, int BN, int WM, int WN, int S, bool CONV, bool TRANS>
-__global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) void gemm_bf16_kernel(const GemmArgs p) {
+// KS > 1 (experimental, tile 7 only; NOT selected by any heuristic or autotune list until it has been validated and measured on
+// hardware): KS groups of WM x WN waves share one output tile and take alternate K steps from their own LDS rings; the partial
+// accumulators are exchanged through LDS after the loop (group g keeps row block i == g) and each group runs the epilogue of its
+// row block.  Meant for the M = 2048 shapes: 160 tiles of 128x128 on 256 CUs leave one 4-wave workgroup per CU, i.e. one wave per
+// SIMD with nothing to overlap LDS / load-issue latency with; two groups double that and halve the serial K loop.
+template <int BM, int BN, int WM, int WN, int S, bool CONV, bool TRANS, int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S, KS)) void gemm_bf16_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = 64 * WM * WN;          // threads: WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile
+    constexpr int NT = 64 * WM * WN;          // threads of one K group: WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile
     constexpr int RPL = NT / 8;               // tile rows staged per load instruction of the workgroup
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_LOADS = BM / RPL, B_LOADS = BN / RPL, LOADS = A_LOADS + B_LOADS;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     // epilogue scratch carved out of the (then idle) ring: row statistics < 16 KB, bias / column sums at 16 KB, C staging at 20 KB
-    static_assert(20480 + WM * WN * 32 * (WTN * 2 + 16) <= 2 * STAGE, "epilogue scratch must fit the smallest LDS ring");
+    static_assert(20480 + WM * WN * KS * 32 * (WTN * 2 + 16) <= 2 * KS * STAGE, "epilogue scratch must fit the smallest LDS ring");
+    static_assert(KS == 1 || (KS == 2 && MI == 2 && !CONV && !TRANS), "split-K groups: plain GEMM, one 32-row block per group");
+    static_assert(KS == 1 || WM * WN * NI * 16 * 64 * 4 * KS <= S * STAGE, "split-K exchange buffer must fit ring 0");
     static_assert(WM * BM * 0 + WN * BM * 8 <= 16384 && 16384 + 2 * BN * 4 <= 20480, "epilogue scratch regions overlap");
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = KS > 1 ? (int)threadIdx.x / NT : 0;                 // K group of this wave (wave-uniform)
+    const int tid = KS > 1 ? (int)threadIdx.x - kg * NT : (int)threadIdx.x;   // thread / wave index INSIDE the group
+    const int lane = tid & 63, wave = tid >> 6;
+    const int bwave = KS > 1 ? (int)(threadIdx.x >> 6) : wave;        // wave index inside the workgroup
+    const int ring_off = KS > 1 ? kg * (S * STAGE) : 0;                // this group's LDS ring
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
 
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
     const int VH = p.up ? 2 * p.H : p.H, VW = p.up ? 2 * p.W : p.W;
     const bf16_t* zero = (const bf16_t*)g_zero_page;
 
-    int ld_k0 = 0, ld_cin0 = 0, ld_ky = 0, ld_kx = 0;  // position of the NEXT tile to stage
+    int ld_k0 = KS > 1 ? kg * 64 : 0, ld_cin0 = 0, ld_ky = 0, ld_kx = 0;  // position of the NEXT tile to stage
     // conv: the tap (ky, kx) only changes every Cin/64 K steps, so the gather address of each A row (or "padding": null ->
     // zero page) is computed once per tap, not once per load: the im2col arithmetic was ~800 of the 1800-1950 cycles a K step
     // of the 128x128 conv tile took (s_memtime; the plain GEMM's K step is ~1050)
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
     conv_set_tap();
     // one global->LDS instruction (q < A_LOADS: A rows, else W rows) of the tile at the current stage position
     auto stage_one = [&](int buf, int q) {
-        char* sA = smem + buf * STAGE;
+        char* sA = smem + ring_off + buf * STAGE;
         char* sB = sA + A_BYTES;
         if (q < A_LOADS) {
             const int j = q;
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
         }
     };
     auto stage_advance = [&]() {
-        ld_k0 += 64;
+        ld_k0 += 64 * KS;
         if constexpr (CONV) {
             ld_cin0 += 64;
             if (ld_cin0 == p.Cin) {
@@ -209,16 +220,16 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
     auto prefetch_next = [&]() {
         const unsigned pf_lines = p.pf_lines;
         if (pf_lines == 0) return;
-        const unsigned total_waves = gridDim.x * (NT / 64), gw = blockIdx.x * (NT / 64) + wave;
+        const unsigned total_waves = gridDim.x * (NT / 64 * KS), gw = blockIdx.x * (NT / 64 * KS) + bwave;
         const unsigned n_instr = (pf_lines + 63) >> 6;
         for (unsigned i = gw; i < n_instr; i += total_waves) {
             unsigned line = i * 64 + lane;
             line = line < pf_lines ? line : pf_lines - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.pf_ptr + (size_t)line * 128),
-                                             (__attribute__((address_space(3))) void*)(smem + S * STAGE), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + KS * S * STAGE), 4, 0, 0);
         }
     };
-    const int nk = p.K >> 6;
+    const int nk = (p.K >> 6) / KS;   // K steps of this group (the host only picks KS > 1 when K % (64 * KS) == 0)
 #ifdef SUPIR_GEMM_TIMELINE
     unsigned long long tl_wait = 0, tl_bar = 0, tl_issue = 0, tl_comp = 0;
     const unsigned long long tl_t0 = TL_NOW();
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
         const bool do_stage = kt + S - 1 < nk;
         const int sbuf = (kt + S - 1) % S;
         const int buf = kt % S;
-        const char* sA = smem + buf * STAGE;
+        const char* sA = smem + ring_off + buf * STAGE;
         const char* sB = sA + A_BYTES;
         constexpr int FB = (MI * NI >= 8) ? 1 : 2;   // fragment double buffering, unless the accumulators already fill the file
         bf16x8 af[FB][MI], bfr[FB][NI];
@@ -356,6 +367,39 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
         }
     }
     __syncthreads();   // LDS is reused below: every wave must be done with its last fragment reads
+    if constexpr (KS == 2) {
+        // Exchange of the K-partial accumulators (reduce-scatter over the two groups): group g keeps row block i == g and adds
+        // the other group's partial of it.  Layout [sender][wave][j][r][lane] fp32: lane-contiguous, conflict-free; 2 x 32 KB in
+        // ring 0, which is idle now.  acc[] is indexed with compile-time constants in both (wave-uniform) branches.
+        float* xch = (float*)smem;
+        const int w_off = wave * (NI * 16 * 64) + lane;
+        float* mine = xch + kg * (WM * WN * NI * 16 * 64) + w_off;
+        const float* theirs = xch + (1 - kg) * (WM * WN * NI * 16 * 64) + w_off;
+        if (kg == 0) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64] = acc[1][j][r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64] = acc[0][j][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][j][r] += theirs[(j * 16 + r) * 64];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[1][j][r] += theirs[(j * 16 + r) * 64];
+        }
+        __syncthreads();   // the epilogue scratch below overlays the exchange buffer
+    }
     float* s_bias = (float*)(smem + 16384);   // [BN] bias, [BN] LN column sums (the row-statistics scratch lives below 16 KB)
     float* s_cs = s_bias + BN;
     if constexpr (!TRANS) {
@@ -433,6 +477,9 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
             if constexpr (NI == 2) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
+                    if constexpr (KS > 1) {
+                        if (i != kg) continue;   // the other K group finishes this row block
+                    }
                     const int m = m0 + wm * WTM + i * 32 + l31;
                     const bool m_ok = m < p.M;
                     const float mu = ln_mean[i], rs = ln_rstd[i];
@@ -461,12 +508,15 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
         // bf16 output can go through a wave-private LDS block (row stride padded by 16 B) so that the global stores are
         // 16 B per lane and row-contiguous instead of 32 rows x 16 bytes per store instruction
         constexpr int C_RS = WTN * 2 + 16;
-        char* c_stage = smem + 20480 + wave * (32 * C_RS);
+        char* c_stage = smem + 20480 + bwave * (32 * C_RS);
         auto epilogue = [&](auto silu_c, auto mode_c) {
             constexpr bool SILU = decltype(silu_c)::value;
             constexpr int MODE = decltype(mode_c)::value;   // 0: bf16 direct, 1: fp32 direct, 2: bf16 via LDS
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
+                if constexpr (KS > 1) {
+                    if (i != kg) continue;   // the other K group finishes this row block
+                }
                 const int m = m0 + wm * WTM + i * 32 + l31;
                 const bool m_ok = m < p.M;
                 const int mc = m_ok ? m : p.M - 1;
@@ -572,7 +622,7 @@ __global__ __launch_bounds__(64 * WM * WN, gemm_min_waves(BM, BN, WM, WN, S)) vo
         if (p.rowstats_out) {
             // one slot per tile column: the WN wave columns are combined here in a fixed order (reproducible)
             __syncthreads();
-            for (int r = tid; r < BM; r += NT) {
+            for (int r = tid; r < (KS > 1 && kg > 0 ? 0 : BM); r += NT) {   // one K group writes the tile's slots
                 const int m = m0 + r;
                 if (m >= p.M) continue;
                 float sm = 0.f, sq = 0.f;
@@ -634,7 +684,7 @@ static void choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_byte
     }
 }
 
-template <int BM, int BN, int WM, int WN, int S, bool CONV, bool TRANS>
+template <int BM, int BN, int WM, int WN, int S, bool CONV, bool TRANS, int KS = 1>
 static int launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     {
@@ -643,20 +693,21 @@ static int launch_gemm(const GemmArgs& a_in, hipStream_t st) {
         choose_xcd_grid(a, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a_bytes, 2.0 * (double)a.N * a.K);
     }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    constexpr int smem = S * (BM + BN) * 128 + 256;   // ring + the prefetch scratch row
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, S, CONV, TRANS>;
+    constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // ring(s) + the prefetch scratch row
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, S, CONV, TRANS, KS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    SUPIR_LAUNCH(kern, dim3(tiles), dim3(64 * WM * WN), smem, st, a);
+    SUPIR_LAUNCH(kern, dim3(tiles), dim3(64 * WM * WN * KS), smem, st, a);
     return SUPIR_LAUNCH_STATUS();
 }
 
 // Tile table (index -> block tile, wave grid, per-wave tile):
 //   0: 128x128 2x2 (64x64)   1: 128x64 2x2 (64x32)   2: 64x128 2x2 (32x64)   3: 64x64 2x2 (32x32)
 //   4: 256x128 4x2 (64x64, 512 threads)   5: 256x256 2x4 (128x64, 512 threads)   6: 256x128 2x2 (128x64)
+//   7: 128x128 2x2 x 2 K groups (512 threads; experimental -- see the kernel comment; never chosen automatically)
 // Heuristic default: biggest of tiles 0-3 that still yields >= ~1 wave of workgroups over 256 CUs; the Python layer
 // autotunes over the whole table per problem shape.
 int supir_gemm_select_tile(int M, int N, int act, int force_tile) {
@@ -695,7 +746,13 @@ static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
         case 3: SUPIR_GEMM_CASE(64, 64, 2, 2)
         case 4: return launch_gemm<256, 128, 4, 2, 2, CONV, TRANS>(a, st);
         case 5: return launch_gemm<256, 256, 2, 4, 2, CONV, TRANS>(a, st);
-        default: return launch_gemm<256, 128, 2, 2, 2, CONV, TRANS>(a, st);
+        case 6: return launch_gemm<256, 128, 2, 2, 2, CONV, TRANS>(a, st);
+        default:
+            // tile 7 (experimental, explicit request only): 128x128 with two K groups; plain GEMM with K % 128 == 0, else tile 0
+            if constexpr (!CONV && !TRANS) {
+                if (a.K % 128 == 0 && a.act != 2) return launch_gemm<128, 128, 2, 2, 2, false, false, 2>(a, st);
+            }
+            SUPIR_GEMM_CASE(128, 128, 2, 2)
     }
 #undef SUPIR_GEMM_CASE
 }

@@ -62,7 +62,8 @@ def finish_timing(trace):
 
 def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
-    name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2"][t]
+    name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
+            "128,128,2x2x2k"][t]
     return f"gemm_bf16_kernel<{name},{'conv' if conv else 'plain'}{',T' if trans else ''}>"
 
 
@@ -274,7 +275,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
     return out
 
 
-_TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2)}
+_TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2)}
 MAX_SLOTS_PER = 32   # rowstats slot granularity: one slot per 32 output columns at the finest (64-wide tile, 2 wave columns)
 
 

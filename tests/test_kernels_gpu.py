@@ -442,3 +442,20 @@ def test_wavelet_level_rejects_aliased_buffers():
     assert lib.supir_wavelet_level(a.data_ptr(), a.data_ptr(), b.data_ptr(), 3, 8, 8, 1, 1, None) != 0
     assert lib.supir_wavelet_level(a.data_ptr(), b.data_ptr(), b.data_ptr(), 3, 8, 8, 1, 1, None) != 0
     assert lib.supir_wavelet_level(a.data_ptr(), b.data_ptr(), None, 3, 8, 8, 1, 1, None) != 0
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SUPIR_TEST_EXPERIMENTAL") != "1",
+                    reason="tile 7 (two K groups per workgroup) is written but not yet validated on hardware: opt in with "
+                           "SUPIR_TEST_EXPERIMENTAL=1 (run it under `timeout`)")
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2048, 1280, 5120), (300, 320, 640), (8192, 640, 640), (130, 136, 128)])
+def test_gemm_split_k_groups_experimental(M, N, K):
+    a = rnd(M, K).to(BF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
+    b = rnd(N, seed=2)
+    res = rnd(M, N, seed=3).to(BF)
+    ref = a.float() @ w.float().t() + b
+    check(ops.gemm(a, w, b, tile=7), ref, name="tile7")
+    check(ops.gemm(a, w, b, residual=res, act=1, alpha=0.5, tile=7), F.silu(ref) * 0.5 + res.float(), name="tile7 epilogue")
+    assert torch.equal(ops.gemm(a, w, b, tile=7), ops.gemm(a, w, b, tile=7))
+    out32 = ops.gemm(a, w, b, out_dtype=torch.float32, tile=7)
+    check(out32, ref, name="tile7 fp32")
