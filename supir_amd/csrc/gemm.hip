@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
     constexpr int WTM = BM / WM, WTN = BN / WN;
     // epilogue scratch carved out of the (then idle) ring: row statistics < 16 KB, bias / column sums at 16 KB, C staging at 20 KB
     static_assert(20480 + WM * WN * KS * 32 * (WTN * 2 + 16) <= 2 * KS * STAGE, "epilogue scratch must fit the smallest LDS ring");
-    static_assert(KS == 1 || (KS == 2 && MI == 2 && !CONV && !TRANS), "split-K groups: plain GEMM, one 32-row block per group");
+    static_assert(KS == 1 || (KS == 2 && MI == 2 && !CONV), "split-K groups: plain / transposed GEMM, one 32-row block per group");
     static_assert(KS == 1 || WM * WN * NI * 16 * 64 * 4 * KS <= S * STAGE, "split-K exchange buffer must fit ring 0");
     static_assert(WM * BM * 0 + WN * BM * 8 <= 16384 && 16384 + 2 * BN * 4 <= 20480, "epilogue scratch regions overlap");
 
@@ -424,6 +424,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
+                if constexpr (KS > 1) {
+                    if (i != kg) continue;   // the other K group finishes this row block
+                }
                 const int n = n0 + wn * WTN + j * 32 + l31;
                 const bool n_ok = n < p.N;
                 const float bz = t_bias[j], cs = t_cs[j];
@@ -748,9 +751,10 @@ static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
         case 5: return launch_gemm<256, 256, 2, 4, 2, CONV, TRANS>(a, st);
         case 6: return launch_gemm<256, 128, 2, 2, 2, CONV, TRANS>(a, st);
         default:
-            // tile 7 (experimental, explicit request only): 128x128 with two K groups; plain GEMM with K % 128 == 0, else tile 0
-            if constexpr (!CONV && !TRANS) {
-                if (a.K % 128 == 0 && a.act != 2) return launch_gemm<128, 128, 2, 2, 2, false, false, 2>(a, st);
+            // tile 7 (experimental, explicit request only): 128x128 with two K groups; plain / transposed GEMM with K % 128 == 0,
+            // else tile 0
+            if constexpr (!CONV) {
+                if (a.K % 128 == 0 && a.act != 2) return launch_gemm<128, 128, 2, 2, 2, false, TRANS, 2>(a, st);
             }
             SUPIR_GEMM_CASE(128, 128, 2, 2)
     }

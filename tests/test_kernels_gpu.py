@@ -459,3 +459,10 @@ def test_gemm_split_k_groups_experimental(M, N, K):
     assert torch.equal(ops.gemm(a, w, b, tile=7), ops.gemm(a, w, b, tile=7))
     out32 = ops.gemm(a, w, b, out_dtype=torch.float32, tile=7)
     check(out32, ref, name="tile7 fp32")
+    if M % 2 == 0:   # transposed (V-projection) epilogue: [B, N, Tpad]
+        B, T = 2, M // 2
+        Tp = (T + 63) // 64 * 64
+        vt = ops.gemm_t(a.view(B, T, K), w, None, B, T, Tp, tile=7)
+        ref_t = (a.float() @ w.float().t()).view(B, T, N).transpose(1, 2)
+        check(vt[:, :, :T], ref_t, name="tile7 transposed")
+        assert (vt[:, :, T:] == 0).all()
