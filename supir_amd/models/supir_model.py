@@ -88,7 +88,7 @@ class SUPIRModel(nn.Module):
                         use_linear_CFG=False, use_linear_control_scale=False, cfg_scale_start=1.0,
                         control_scale_start=0.0, cond=None, noises=None, return_intermediates=False, **kwargs):
         """SUPIR_model.py:80-136.  `cond=(c, uc)` bypasses the text conditioner; `noises` (dict with optional
-        'posterior', 'init') injects the RNG draws for parity runs (the sampler's churn noise comes from
+        'posterior', 'init', 'steps') injects the RNG draws for parity runs (otherwise the sampler's churn noise comes from
         torch.randn_like on the device generator exactly like the reference)."""
         assert color_fix_type in ["Wavelet", "AdaIn", "None"]
         N = len(x)
@@ -114,6 +114,8 @@ class SUPIRModel(nn.Module):
         _z = self.encode_first_stage_with_denoise(x, use_sample=False)
         x_stage1 = self.decode_first_stage(_z)
         z_stage1 = self.encode_first_stage(x_stage1, noise=noises.get("posterior"))
+        if cond is None:
+            assert len(x) == len(p)   # SUPIR_model.py:95
         if cond is not None:
             c, uc = dict(cond[0]), dict(cond[1])
             c["control"] = _z
@@ -121,7 +123,9 @@ class SUPIRModel(nn.Module):
         else:
             c, uc = self.prepare_condition(_z, p, p_p, n_p, N)
         denoiser = lambda inp, sigma, cc, cs: self.denoiser(self.model, inp, sigma, cc, cs, **kwargs)
-        noised_z = noises["init"].to(_z) if "init" in noises else torch.randn_like(_z)
+        noised_z = noises["init"].to(_z).clone() if "init" in noises else torch.randn_like(_z)
+        if "steps" in noises:   # parity runs: per-step churn noise instead of torch.randn_like (RestoreEDMSampler only)
+            self.sampler.injected_step_noises = list(noises["steps"])
         _samples = self.sampler(denoiser, noised_z, cond=c, uc=uc, x_center=z_stage1, control_scale=control_scale,
                                 use_linear_control_scale=use_linear_control_scale, control_scale_start=control_scale_start)
         samples = self.decode_first_stage(_samples)
@@ -155,5 +159,17 @@ class SUPIRModel(nn.Module):
                  "aesthetic_score": torch.tensor([9.0]).repeat(N, 1).to(_z.device), "control": _z}
         batch_uc = copy.deepcopy(batch)
         batch_uc["txt"] = [n_p for _ in p]
-        batch["txt"] = ["".join([_p, p_p]) for _p in p]
-        return self.conditioner.get_unconditional_conditioning(batch, batch_uc)
+        if not isinstance(p[0], list):
+            batch["txt"] = ["".join([_p, p_p]) for _p in p]
+            return self.conditioner.get_unconditional_conditioning(batch, batch_uc)
+        # local (per-tile) prompts, SUPIR_model.py:168-178: one cond per tile, a single uc (the tiled samplers' `cond` list)
+        assert len(p) == 1, "Support bs=1 only for local prompt conditioning."
+        c, uc = [], None
+        for i, p_tile in enumerate(p[0]):
+            batch["txt"] = ["".join([p_tile, p_p])]
+            if i == 0:
+                _c, uc = self.conditioner.get_unconditional_conditioning(batch, batch_uc)
+            else:
+                _c, _ = self.conditioner.get_unconditional_conditioning(batch, None)
+            c.append(_c)
+        return c, uc

@@ -212,9 +212,10 @@ class RestoreEDMSampler(BaseDiffusionSampler):
                  use_linear_control_scale=False, control_scale_start=0.0):
         x, s_in, sigmas, num_sigmas, cond, uc, sf = self.prepare_sampling_loop(x, cond, uc, num_steps)
         cond_cat = self.guider.prepare_cond(cond, uc)            # constant over the loop: concat once
+        inject = self.__dict__.pop("injected_step_noises", None)  # parity runs: the churn noise of every step, given
         for i in range(num_sigmas - 1):
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, self._gamma(sf[i], num_sigmas),
-                                  x_center, control_scale=control_scale, use_linear_control_scale=use_linear_control_scale,
+                                  x_center, eps_noise=None if inject is None else inject[i].to(x), control_scale=control_scale, use_linear_control_scale=use_linear_control_scale,
                                   control_scale_start=control_scale_start, cond_cat=cond_cat, sigma_f=sf[i],
                                   next_sigma_f=sf[i + 1])
         return x
@@ -263,6 +264,7 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None, x_center=None, control_scale=1.0,
                  use_linear_control_scale=False, control_scale_start=0.0):
         use_local_prompt = isinstance(cond, list)
+        self.__dict__["_rep_cache"] = {}   # the repeated-conditioning cache is per call (`static` below is rebuilt every call)
         b, _, h, w = x.shape
         tiles = _sliding_windows(h, w, self.tile_size, self.tile_stride)
         if self.tile_weights is None or self.tile_weights.device != x.device:

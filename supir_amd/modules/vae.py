@@ -60,8 +60,11 @@ class AttnBlock(nn.Module):
         if Tp == T:
             k = ops.gemm(n, self.k.w(), self.k.b32())
         else:
+            # the padded buffer's batch stride (Tp*C) differs from its dense row extent (T*C), so a [B, T, C] view of it is not
+            # a uniform-stride row matrix: project one batch element at a time (tiled-VAE tiles with B > 1 hit this)
             k = torch.zeros(B, Tp, C, dtype=BF16, device=n.device)
-            ops.gemm(n, self.k.w(), self.k.b32(), out=k[:, :T])
+            for b in range(B):
+                ops.gemm(n[b], self.k.w(), self.k.b32(), out=k[b, :T])
         vt = ops.gemm_t(n, self.v.w(), self.v.b32(), B, T, Tp)       # [B, C, Tp], zero padded
         o = torch.empty(B, T, C, dtype=BF16, device=n.device)
         for b in range(B):

@@ -19,7 +19,10 @@ class ControlWrapper(nn.Module):
         self.dtype = dtype
         self._graph_on = False
         self._graphs = {}
-        self._cs_seen = {}             # per input shape: the control scales graphs were asked for (see _forward_graph)
+        self._cs_miss = {}             # per input shape: consecutive calls that found no graph for their control scale
+        # what the SHARED step-independent buffers (text K / V^T of every cross-attention, label embedding) currently hold,
+        # per (context shape, vector shape): every graph of that shape and the eager path write the same buffers in place
+        self._resident = {}
         self.overlap_branches = True   # GLVControl || UNet encoder on two HIP streams
         # Weight prefetch inside captured graphs: op i's GEMM kernel touches the weight of op i+distance on its way out
         # (ops.WeightPrefetch, supir_set_next_prefetch).  The cold-weight penalty is +25..40 % per GEMM (tools/cold_probe.py).
@@ -80,6 +83,10 @@ class ControlWrapper(nn.Module):
             out = self.diffusion_model(x, timesteps=t, context=ctx, y=vec, control=control, control_scale=control_scale,
                                        **kwargs)
             self._warm = True   # weight / context caches are now built (they are filled on the calling stream)
+        if ctx is not None and vec is not None:
+            # this call (re)filled the shared text-K/V^T / label buffers with ITS conditioning: graphs of the same shape that
+            # were captured with another prompt must refresh before their next replay (_forward_graph checks this token)
+            self._resident[(tuple(ctx.shape), tuple(vec.shape))] = (ctx, ctx._version, vec, vec._version)
         return out.float()
 
     # ------------------------------------------------------------------ hipGraph replay
@@ -87,7 +94,7 @@ class ControlWrapper(nn.Module):
         self._graph_on = bool(on)
         if not on:
             self._graphs.clear()
-            self._cs_seen.clear()
+            self._cs_miss.clear()
 
     def _forward_graph(self, x, t, c, control_scale):
         ctx, vec, ctl = c["crossattn"], c["vector"], c["control"]
@@ -96,10 +103,11 @@ class ControlWrapper(nn.Module):
         if g is None:
             # control_scale is a launch argument baked into the captured kernels.  With use_linear_control_scale
             # (sampling.py:557-559) it changes on every step: capturing a graph per value would cost three network calls per
-            # step, so from the third distinct value on such calls run eagerly (the constant-scale case never gets here).
-            seen = self._cs_seen.setdefault((key[0], key[2], key[3]), set())
-            seen.add(key[1])
-            if len(seen) > 2:
+            # step, so after two CONSECUTIVE misses for a shape such calls run eagerly.  A hit resets the streak, so a new
+            # constant scale on a later image (1.0, then 0.9, then 0.8 ...) still gets its graph.
+            skey = (key[0], key[2], key[3])
+            self._cs_miss[skey] = self._cs_miss.get(skey, 0) + 1
+            if self._cs_miss[skey] > 2:
                 return self._forward_eager(x, t, c, control_scale)
             if len(self._graphs) >= 4:
                 self._graphs.clear()
@@ -127,14 +135,19 @@ class ControlWrapper(nn.Module):
                 if pf is not None:
                     pf.end()
             ops.set_prefetch(None)
-            g = [graph, sx, st, sc, out, ctx, ctx._version, vec, vec._version]
+            g = [graph, sx, st, sc, out]
             self._graphs[key] = g
+        else:
+            self._cs_miss[(key[0], key[2], key[3])] = 0
         graph, sx, st, sc, out = g[:5]
-        if g[5] is not ctx or g[6] != ctx._version or g[7] is not vec or g[8] != vec._version:
-            # new prompt / vector with the same shapes: refresh the static conditioning in place, keep the graph
+        rkey = (key[2], key[3])
+        res = self._resident.get(rkey)
+        if res is None or res[0] is not ctx or res[1] != ctx._version or res[2] is not vec or res[3] != vec._version:
+            # the shared buffers hold another prompt's K / V^T / label embedding (a new prompt, or another graph / an eager call
+            # of the same shape ran in between): refresh them in place, keep the graph
             self.control_model.refresh_static_conditioning(ctx, vec)
             self.diffusion_model.refresh_static_conditioning(ctx, vec)
-            g[5:9] = [ctx, ctx._version, vec, vec._version]
+            self._resident[rkey] = (ctx, ctx._version, vec, vec._version)
         sx.copy_(x)
         st.copy_(t)
         sc.copy_(ctl)

@@ -303,8 +303,9 @@ def test_adain_colour_fix_vs_reference():
 
 
 def test_graph_mode_runs_eagerly_when_control_scale_keeps_changing():
-    """ControlWrapper._forward_graph: a third distinct control_scale for the same shapes (use_linear_control_scale) must not
-    trigger yet another capture; the call is served by the eager path (exercised here with stand-in CPU modules)."""
+    """ControlWrapper._forward_graph: after two consecutive misses for a shape (use_linear_control_scale: a new control_scale
+    on every step) the next new value must not trigger yet another capture; the call is served by the eager path (exercised
+    here with stand-in CPU modules).  A hit resets the streak; enable_graph(False) clears it."""
     from supir_amd.modules.wrappers import ControlWrapper
 
     class Ctl(torch.nn.Module):
@@ -320,9 +321,11 @@ def test_graph_mode_runs_eagerly_when_control_scale_keeps_changing():
     x, t = torch.ones(2, 4, 8, 8), torch.zeros(2, dtype=torch.int64)
     c = {"crossattn": torch.zeros(2, 77, 8), "vector": torch.zeros(2, 16), "control": torch.full((2, 4, 8, 8), 2.0)}
     shape_key = (tuple(x.shape), tuple(c["crossattn"].shape), tuple(c["vector"].shape))
-    w._cs_seen[shape_key] = {1.0, 0.9}                     # two scales already captured for these shapes
-    out = w._forward_graph(x, t, c, 0.8)                   # third value: eager, no capture attempted (this box has no GPU)
+    w._cs_miss[shape_key] = 2                              # two consecutive new scales were already captured for these shapes
+    out = w._forward_graph(x, t, c, 0.8)                   # third in a row: eager, no capture attempted (this box has no GPU)
     assert torch.allclose(out, x * 0.5 + (x + 2.0) * 0.8) and out.dtype == torch.float32
-    assert w._graphs == {} and w._cs_seen[shape_key] == {1.0, 0.9, 0.8}
+    assert w._graphs == {} and w._cs_miss[shape_key] == 3
+    # the eager call left ITS conditioning in the shared buffers: recorded, so a graph of the same shape refreshes before replay
+    assert w._resident[(tuple(c["crossattn"].shape), tuple(c["vector"].shape))][0] is c["crossattn"]
     w.enable_graph(False)
-    assert w._cs_seen == {}
+    assert w._cs_miss == {}
