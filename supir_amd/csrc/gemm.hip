@@ -668,7 +668,7 @@ static bool xcd_grid_enabled() {
 }
 
 // choose the XCD partition for a tiles_m x tiles_n grid (see the kernel comment); a_bytes / w_bytes = operand footprints
-static void choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes) {
+void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes) {
     a.gm = a.gn = 0;
     if (!xcd_grid_enabled() || ((tiles_m * tiles_n) & 7)) return;
     const double c_bytes = 2.0 * (double)a.M * a.N / 8.0;   // each XCD also write-allocates its share of the output
@@ -693,7 +693,7 @@ static int launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     {
         const double a_bytes = CONV ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin
                                     : 2.0 * (double)a.M * a.K;
-        choose_xcd_grid(a, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a_bytes, 2.0 * (double)a.N * a.K);
+        supir_choose_xcd_grid(a, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a_bytes, 2.0 * (double)a.N * a.K);
     }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // ring(s) + the prefetch scratch row
@@ -804,6 +804,10 @@ int supir_gemm_launch(const GemmArgs& a_in, bool conv, hipStream_t st, int force
         a.order = cost_n_fast < cost_m_fast ? 1 : 0;
     }
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return SUPIR_ERR_ARG;
+    if (force_tile >= 32) {   // the 16x16x32-MFMA, 256-workgroup tiles (gemm16.hip): exact shapes only, plain GEMM only
+        if (conv) return SUPIR_ERR_SHAPE;
+        return supir_gemm16_launch(a, st, force_tile);
+    }
     if (a.K % 64 != 0 || a.N % 4 != 0 || a.lda % 8 != 0) return SUPIR_ERR_SHAPE;
     if (conv && (a.Cin % 64 != 0 || a.K != 9 * a.Cin)) return SUPIR_ERR_SHAPE;
     if (a.act == 2 && (a.N % 128 != 0 || a.out_mode != 0 || a.res || a.rowbias)) return SUPIR_ERR_SHAPE;

@@ -61,6 +61,8 @@ def finish_timing(trace):
 
 
 def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
+    if tile is not None and tile >= 32:
+        return f"gemm16_kernel<128,{80 if tile == 32 else 160},2k{',T' if trans else ''}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
             "128,128,2x2x2k"][t]
@@ -263,10 +265,15 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
     if tile == -1:
         key = ("gemm", M, N, K, act, om)
+        ok = (lda % 8 == 0 and out.data_ptr() % 16 == 0 and (residual is None or ldr % 4 == 0)
+              and (rowbias is None or ld_rb % 4 == 0))
+        cands = _gemm_candidates(M, N, K, act, om, ldc, epilogue_ok=ok)
         if residual is not None and residual.data_ptr() == out.data_ptr():
             tile = _TUNE.get(key, -1)   # in-place accumulate: re-launching would change the data, only reuse a known winner
         else:
-            tile = _autotune(key, (0, 2, 4, 5, 6) if act == 2 else (0, 1, 2, 3, 4, 5, 6), launch)
+            tile = _autotune(key, cands, launch)
+        if tile >= 32 and tile not in cands:   # a winner cached for this shape under friendlier strides
+            tile = -1
     _pf(w)
     ev = _ev()
     rc = launch(tile)
@@ -275,7 +282,23 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
     return out
 
 
-_TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2)}
+_TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
+               32: (80, 1), 33: (160, 2)}
+USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc/gemm16.hip) in the autotune lists
+
+
+def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True):
+    """Tile candidates for the autotuner.  Tiles 32 / 33 (128 x 80 / 128 x 160, 16x16x32 MFMA, two K groups: exactly 256
+    workgroups on the M = 2048, N = 1280 k shapes) take exact shapes only -- the same predicate as supir_gemm16_supported."""
+    base = (0, 2, 4, 5, 6) if act == 2 else (0, 1, 2, 3, 4, 5, 6)
+    if not USE_GEMM16 or act == 2 or om == 1 or M % 128 or K % 128 or ln_slots > 32 or not epilogue_ok:
+        return base
+    if om == 2 and ldc % 4:
+        return base
+    if om == 0 and ldc % 8:
+        return base
+    extra = tuple(t for t, bn in ((32, 80), (33, 160)) if N % bn == 0)
+    return base + extra
 MAX_SLOTS_PER = 32   # rowstats slot granularity: one slot per 32 output columns at the finest (64-wide tile, 2 wave columns)
 
 
@@ -345,10 +368,15 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
 
     if tile == -1:
         key = ("gemm", M, N, K, act, om)
+        ok = (lda % 8 == 0 and out.data_ptr() % 16 == 0 and (residual is None or ldr % 4 == 0)
+              and (trans is None or rpb % 4 == 0))
+        cands = _gemm_candidates(M, N, K, act, om, ldc, ln_slots=ln_slots, epilogue_ok=ok)
         if residual is not None and residual.data_ptr() == out.data_ptr():
             tile = _TUNE.get(key, -1)
         else:
-            tile = _autotune(key, (0, 2, 4, 5, 6) if act == 2 else (0, 1, 2, 3, 4, 5, 6), launch)
+            tile = _autotune(key, cands, launch)
+        if tile >= 32 and tile not in cands:
+            tile = -1
     _pf(w)
     ev = _ev()
     rc = launch(tile)
@@ -356,7 +384,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
     _rec("gemm_t" if trans is not None else "gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act,
          tile=tile)
     if emit_stats:
-        t_used = (tile & 7) if tile >= 0 else lib.supir_gemm_tile_for(M, N, act)
+        t_used = tile if tile >= 32 else (tile & 7) if tile >= 0 else lib.supir_gemm_tile_for(M, N, act)
         bn, _ = _TILE_BN_WN[t_used]
         return out, RowStats(stats, (N + bn - 1) // bn, rs_ld)
     return out
@@ -372,12 +400,21 @@ def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
     if out is None:
         out = torch.zeros(B, N, Tpad, dtype=BF16, device=a.device) if Tpad != T else \
             torch.empty(B, N, Tpad, dtype=BF16, device=a.device)
+
+    def launch(t):
+        return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, Tpad, _p(bias), 0, 0, T, 0, 0, 0, 2,
+                                   1.0, t, _stream())
+
+    if tile == -1:
+        cands = _gemm_candidates(M, N, K, 0, 2, Tpad, epilogue_ok=(lda % 8 == 0 and T % 4 == 0))
+        tile = _autotune(("gemm", M, N, K, 0, 2), cands, launch)
+        if tile >= 32 and tile not in cands:
+            tile = -1
     _pf(w)
     ev = _ev()
-    rc = lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, Tpad, _p(bias), 0, 0, T, 0, 0, 0, 2,
-                             1.0, tile, _stream())
+    rc = launch(tile)
     _lib.check(rc, "supir_gemm_bf16(T)")
-    _rec("gemm_t", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev, M=M, N=N, K=K, act=0)
+    _rec("gemm_t", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev, M=M, N=N, K=K, act=0, tile=tile)
     return out
 
 

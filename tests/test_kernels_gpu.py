@@ -466,3 +466,93 @@ def test_gemm_split_k_groups_experimental(M, N, K):
         ref_t = (a.float() @ w.float().t()).view(B, T, N).transpose(1, 2)
         check(vt[:, :, :T], ref_t, name="tile7 transposed")
         assert (vt[:, :, T:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------ tiles 32 / 33 (csrc/gemm16.hip)
+G16_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (8192, 640, 640), (128, 80, 128), (256, 160, 384),
+              (384, 320, 256)]
+
+
+@pytest.mark.parametrize("M,N,K", G16_SHAPES)
+@pytest.mark.parametrize("tile", [32, 33])
+def test_gemm16_plain_and_epilogues(M, N, K, tile):
+    """128 x 80 / 128 x 160 tiles (v_mfma_f32_16x16x32_bf16, two K groups per workgroup): plain, residual + alpha, row bias +
+    SiLU, strided operands, run-to-run bitwise equality."""
+    if N % (80 if tile == 32 else 160):
+        pytest.skip("tile needs N % BN == 0")
+    a = rnd(M, K).to(BF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N, seed=2)
+    base = a.float() @ w.float().T + bias
+    out = ops.gemm(a, w, bias, tile=tile)
+    check(out, base, name=f"gemm16{(M, N, K)} tile{tile}")
+    assert torch.equal(out, ops.gemm(a, w, bias, tile=tile))
+    check(ops.gemm(a, w, None, tile=tile), a.float() @ w.float().T, name="no bias")
+    res = rnd(M, N, seed=3).to(BF)
+    check(ops.gemm(a, w, bias, residual=res, alpha=0.5, tile=tile), 0.5 * base + res.float(), name="res+alpha")
+    Bt = 2
+    rb = rnd(Bt, N, seed=4).to(BF)
+    out = ops.gemm(a, w, bias, rowbias=rb, rows_per_batch=M // Bt, act=1, tile=tile)
+    check(out, F.silu(base + rb.float().repeat_interleave(M // Bt, 0)), name="rowbias+silu")
+    if M <= 2048:
+        wide = rnd(M, K + 64).to(BF)
+        cbuf = torch.zeros(M, N + 128, dtype=BF, device=DEV)
+        ops.gemm(wide[:, 64:], w, bias, out=cbuf[:, 128:], tile=tile)
+        check(cbuf[:, 128:], wide[:, 64:].float() @ w.float().T + bias, name="strided")
+        assert cbuf[:, :128].abs().max().item() == 0.0
+        # in-place residual accumulate (the transformer's x += f(x) form)
+        acc = res.clone()
+        ops.gemm(a, w, bias, residual=acc, out=acc, tile=tile)
+        check(acc, base + res.float(), name="in-place residual")
+
+
+@pytest.mark.parametrize("B,T,N,K", [(2, 1024, 1280, 1280), (2, 4096, 640, 640), (1, 128, 160, 128)])
+@pytest.mark.parametrize("tile", [32, 33])
+def test_gemm16_transposed(B, T, N, K, tile):
+    a = rnd(B * T, K).to(BF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N, seed=2)
+    out = ops.gemm_t(a, w, bias, B, T, T, tile=tile)
+    ref = (a.float() @ w.float().T + bias).view(B, T, N).permute(0, 2, 1)
+    check(out, ref, name="gemm16_t")
+
+
+@pytest.mark.parametrize("M,C,N", [(2048, 1280, 2560), (8192, 640, 640), (256, 320, 640)])
+@pytest.mark.parametrize("ptile,ctile", [(32, 32), (33, 33), (32, 0), (3, 32), (0, 33)])
+def test_gemm16_layernorm_folding(M, C, N, ptile, ctile):
+    """Row statistics emitted by / consumed from the 16x16x32 tiles, mixed with the 32x32x16 tiles on the other side."""
+    from supir_amd.weights import fold_layernorm
+    a = rnd(M, C).to(BF)
+    wp = rnd(C, C, scale=C ** -0.5, seed=1).to(BF)
+    res = (rnd(M, C, seed=3) * 2 + 0.5).to(BF)
+    x, st = ops.gemm_ln(a, wp, None, residual=res, emit_stats=True, tile=ptile)
+    check(x, a.float() @ wp.float().T + res.float(), name="producer")
+    xs = x.float()
+    tot = st.buf[:, :st.slots].sum(dim=1)
+    check(tot[:, 0], xs.sum(-1), rel=1e-4, name="rowsum")
+    check(tot[:, 1], (xs * xs).sum(-1), rel=1e-4, name="rowsq")
+    gamma, beta = rnd(C, seed=4) * 0.2 + 1.0, rnd(C, seed=5) * 0.2
+    w = rnd(N, C, scale=C ** -0.5, seed=6)
+    bias = rnd(N, seed=7)
+    wf, cs, bf_ = fold_layernorm(w, bias, gamma, beta)
+    ref = F.layer_norm(xs, (C,), gamma, beta, 1e-5) @ w.to(BF).float().T + bias
+    out = ops.gemm_ln(x, wf, bf_, ln=st, colsum=cs, tile=ctile)
+    check(out, ref, rel=6e-3, name="ln-fold")
+    B, T = 2, M // 2
+    outt = ops.gemm_ln(x, wf, bf_, ln=st, colsum=cs, trans=(B, T, T), tile=ctile)
+    check(outt, ref.view(B, T, N).permute(0, 2, 1), rel=6e-3, name="ln-fold-T")
+    fin = ops.rowstats_finalize(st, C, 1e-5)
+    out2 = ops.gemm_ln(x, wf, bf_, ln=fin, colsum=cs, tile=ctile)
+    check(out2, ref, rel=6e-3, name="ln-fold finalised stats")
+
+
+def test_gemm16_rejects_inexact_shapes():
+    from supir_amd import _lib
+    a = rnd(200, 128).to(BF)
+    w = rnd(80, 128, seed=1).to(BF)
+    with pytest.raises(_lib.SupirHipError):
+        ops.gemm(a, w, None, tile=32)          # M % 128 != 0
+    a = rnd(128, 128).to(BF)
+    w = rnd(96, 128, seed=1).to(BF)
+    with pytest.raises(_lib.SupirHipError):
+        ops.gemm(a, w, None, tile=32)          # N % 80 != 0

@@ -89,9 +89,15 @@ def test_control_features_and_wrapper_vs_reference_golden(wrap, g):
     with torch.no_grad():
         hs = wrap.control_model(x=cond["control"], timesteps=t, xt=x, context=cond["crossattn"], y=cond["vector"])
         assert len(hs) == 10
-        for h, d in zip(hs, g["control_digest"]):
+        for i, (h, d) in enumerate(zip(hs, g["control_digest"])):
             assert list(h.shape) == d["shape"]
             assert abs(h.float().std().item() - d["std"]) <= 2e-2 * d["std"]
+            # element-wise: the first / last 32 values of the reference's feature map (flattened NCHW order), rel-L2 on the 64
+            # stored values against the map's own scale (tests/test_parity_production_gpu.py checks all 10 maps in full against
+            # the oracle at latent 64^2)
+            f = h.float().contiguous().flatten().cpu()
+            got, want = torch.cat([f[:32], f[-32:]]), torch.cat([d["head"], d["tail"]])
+            assert (got - want).norm().item() <= 2.5e-2 * d["std"] * 8.0, (i, (got - want).norm().item(), d["std"])   # 8 = sqrt(64)
         eps = wrap(x, t, cond, 1.0)
         assert eps.dtype == torch.float32 and tuple(eps.shape) == (B, 4, 16, 16)
         e1 = rel_l2(eps, g["wrapper_eps"])
