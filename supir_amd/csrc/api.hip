@@ -41,7 +41,7 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 33) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 35) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
@@ -60,7 +60,7 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
                        float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                        const float* ln_colsum, float ln_eps, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 33) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 35) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
     if (rowstats_out && (out_mode != 0 || act == 2 || rs_ld <= 0)) return SUPIR_ERR_ARG;
@@ -75,7 +75,7 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
     if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0))) return SUPIR_ERR_SHAPE;
     if (rowstats_out) {  // the slot index is tile_n * waves_n + wave_n: the caller's rs_ld must cover the tile actually used
         const int sel = supir_gemm_select_tile(M, N, act, tile < 0 ? -1 : (tile & 7));
-        const int bn = tile == 32 ? 80 : tile == 33 ? 160 : (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
+        const int bn = (tile == 32 || tile == 35) ? 80 : (tile == 33 || tile == 34) ? 160 : (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
         if ((N + bn - 1) / bn > rs_ld || (rs_ld & 1)) return SUPIR_ERR_ARG;
     }
     take_prefetch(a);

@@ -1,44 +1,60 @@
-// bf16 MFMA GEMM for the M = 2048-token shapes of the 32x32-latent transformer stacks (tiles 32 / 33 of the tile table).
+// bf16 MFMA GEMM on v_mfma_f32_16x16x32_bf16 for the shapes whose tile grid can be made EXACTLY a multiple of the 256 CUs
+// (tiles 32..35 of the tile table).
 //
-//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )      same contract as gemm.hip, for M % 128 == 0, N % BN == 0, K % 128 == 0
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )      same contract as gemm.hip, for M % BM == 0, N % BN == 0, K % (64 KS) == 0
 //
-// Why a second kernel: 70 % of the GEMM launches of a 1024^2 step have M = 2048 and N = 1280 (to_q / to_out / ff.net.2 /
+// Why a second kernel family.  70 % of the GEMM launches of a 1024^2 step have M = 2048 and N = 1280 (to_q / to_out / ff.net.2 /
 // proj_in / proj_out of the 1280-wide SpatialTransformers, sgm/modules/attention.py:100-106,213-219,587,611).  On the
 // 32x32x16 tiles of gemm.hip that is 160 tiles of 128x128 (96 of 256 CUs idle) or 640 tiles of 64x64 (2.5 waves of workgroups,
-// twice the L1 traffic per FLOP); measured hot: 17.4 / 14.6 us = 385-460 TFLOP/s whatever the tile.  What bounds a CU here
-// is its global->LDS fill rate (64 B/clk): a tile of area a needs (BM + BN) * 128 B per K step, so the right tile is the
-// squarest one that gives EXACTLY one workgroup per CU: 2048 x 1280 / 256 = 128 x 80.  80 = 5 x 16, hence
-// v_mfma_f32_16x16x32_bf16 (same FLOP rate as the 32x32x16 form).  N = 2560 (fused to_q|to_k) -> 128 x 160, also 256 tiles.
+// twice the L1 traffic per FLOP); measured hot: 17.4 / 14.6 us = 385-460 TFLOP/s whatever the tile.  What bounds a CU is its
+// global->LDS fill rate (64 B/clk) and the bytes it can keep in flight (its LDS): a tile needs (BM + BN) * 128 B per K step, so
+// the right tile is the squarest one that gives exactly one workgroup per CU: 2048 x 1280 / 256 = 128 x 80.  80 = 5 x 16, hence
+// the 16x16x32 MFMA (same FLOP rate as 32x32x16).  N = 2560 (fused to_q|to_k) -> 128 x 160; the GEGLU projection
+// (2048 x 10240, attention.py:87) -> 256 x 160 = 512 workgroups = two full rounds.
 //
-//  * 512 threads = two K groups of four waves: group g takes K steps g, g+2, ... from its own 2-deep LDS ring, so every SIMD
+//  tile  BM x BN    waves          K groups  ring   LDS      used for
+//   32   128 x  80  4x1 per group     2       2   104 KB   M = 2048, N = 1280 (also N = 640 at M = 8192)
+//   33   128 x 160  2x2 per group     2       2   144 KB   N = 2560, M = 8192 x N = 640
+//   34   256 x 160  8x1               1       3   156 KB   N = 10240 (GEGLU epilogue: value / gate interleaved per 16 rows of W)
+//   35   128 x  80  4x1 per group     2       3   156 KB   tile 32 with a 3-deep ring (two K steps of loads in flight per group)
+//
+//  * 512 threads.  KS = 2: two K groups of four waves, group g takes K steps g, g+2, ... from its own LDS ring, so every SIMD
 //    holds two waves (one per group) whose load issue / LDS reads / MFMAs interleave; the partial accumulators are
 //    reduce-scattered through LDS after the loop (group g finishes token-fragment rows [g*MI/2, (g+1)*MI/2)) and both groups
-//    run the epilogue on their half;
+//    run the epilogue on their half.  KS = 1: eight waves on one ring;
 //  * global -> LDS by global_load_lds_dwordx4, 8 rows (1 KB) per wave instruction, source-side XOR swizzle
 //    (chunk ^= (row >> 1) & 7), undone by the ds_read_b128 fragment reads: conflict-free for the 16-row x 4-chunk
-//    fragment of the 16x16x32 MFMA as well (checked per ds_read_b128 lane group);
+//    fragment of the 16x16x32 MFMA (checked per ds_read_b128 lane group); S-deep ring, ONE raw s_barrier per K step, counted
+//    vmcnt for S = 3 (every wave issues the same number of loads per stage);
 //  * operands swapped (a = W rows, b = A rows): a lane ends with 4 consecutive channels of one token; the fused epilogue
-//    is the one of gemm.hip (bias, LayerNorm fold / row statistics, row bias, residual, SiLU, alpha; bf16 output staged
+//    is the one of gemm.hip (bias, LayerNorm fold / row statistics, row bias, residual, SiLU, GEGLU, alpha; bf16 output staged
 //    through LDS for 16-byte row-contiguous stores); the transposed (V^T) variant swaps the operands back so that a lane
 //    holds 4 consecutive tokens of one channel;
-//  * exact shapes only (the dispatcher falls back to gemm.hip otherwise): no bounds checks anywhere in the kernel.
+//  * exact shapes only (the dispatcher refuses anything else): no bounds checks anywhere in the kernel.
 #include "kernels.h"
 #include <type_traits>
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int BN, int WM, int WN, bool TRANS>
+template <int N>
+__device__ __forceinline__ void g16_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 128, KS = 2, S = 2, NTG = 256;
+    constexpr int NW = WM * WN;                          // waves per K group
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, RING = S * STAGE_BYTES;
-    constexpr int A_Q = BM / 32;                       // 8-row chunks of A per wave and K step (chunk id = wave + 4 q)
-    constexpr int B_CH = BN / 8, B_Q = (B_CH + 3) / 4;   // chunks of W per tile / per wave (the last q may be partial)
-    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, MIH = MI / 2;
-    static_assert(WM * WN == 4 && MI >= 2 && (MI & 1) == 0 && BN % 16 == 0 && WTN % 16 == 0, "tile / wave grid");
+    constexpr int A_Q = BM / 8 / NW;                     // 8-row chunks of A per wave and K step (chunk id = wave + NW q)
+    constexpr int B_CH = BN / 8, B_Q = (B_CH + NW - 1) / NW;   // chunks of W per tile / per wave (the last q may be partial)
+    constexpr int LOADS = A_Q + B_Q;                     // global->LDS instructions per wave and stage
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, MIH = MI / KS;
+    static_assert(NW * KS == 8 && (BM / 8) % NW == 0 && (NW & 1) == 0, "512 threads; A chunks divide over the waves");
+    static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3), "tile / wave grid");
     // epilogue LDS map (the rings are idle by then): [0, XCH) K-group exchange, then per-wave C staging, bias / column sums,
     // row-statistics scratch
-    constexpr int XCH_HALF = 4 * MIH * NI * 4 * 64 * 4;          // bytes one group sends
+    constexpr int XCH_HALF = KS == 2 ? NW * MIH * NI * 4 * 64 * 4 : 0;   // bytes one group sends
     constexpr int XCH = 2 * XCH_HALF;
     constexpr int C_RS = WTN * 2 + 16;                         // staged row stride (bytes): 16-byte pad against bank conflicts
     constexpr int C_STAGE = 16 * C_RS;                         // one 16-token block per wave
@@ -47,10 +63,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
 
     // wave-uniform ids as scalars (readfirstlane): LDS destinations / branches on them stay on the scalar unit
     const int bwave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // wave inside the workgroup, 0..7
-    const int kg = bwave >> 2;                         // K group
-    const int wave = bwave & 3;                        // wave inside the group
-    const int tid = (int)threadIdx.x & 255;
-    const int lane = tid & 63;
+    const int kg = KS == 2 ? bwave >> 2 : 0;           // K group
+    const int wave = KS == 2 ? bwave & 3 : bwave;      // wave inside the group
+    const int lane = (int)threadIdx.x & 63;
+    const int tid = wave * 64 + lane;                  // thread inside the group
     const int wm = wave / WN, wn = wave % WN;
     const int quad = lane >> 4, l15 = lane & 15;
     char* ring = smem + kg * RING;
@@ -73,25 +89,29 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- loader: wave w stages the 8-row chunks w, w+4, w+8, ... of A and of W; lane -> row lane>>3, physical 16-B chunk lane&7.
-    // chunk ids of one wave all have the parity of w, so the swizzle ((row >> 1) & 7 with row = 8*chunk + lane>>3) is fixed per lane
+    // ---- loader: wave w stages the 8-row chunks w, w+NW, w+2NW, ... of A and of W; lane -> row lane>>3, physical 16-B chunk lane&7.
+    // NW is even, so the chunk ids of one wave all have the parity of w and the swizzle ((row >> 1) & 7 with row = 8*chunk + lane>>3)
+    // is fixed per lane
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
     const bf16_t* a_src = p.A + (size_t)(m0 + wave * 8 + lrow) * p.lda + lchunk * 8 + kg * 64;
     const bf16_t* b_src = p.Wt + (size_t)(n0 + wave * 8 + lrow) * p.K + lchunk * 8 + kg * 64;
-    const size_t a_qstride = (size_t)32 * p.lda, b_qstride = (size_t)32 * p.K;
-    // one global->LDS instruction: q < A_Q -> A chunk wave + 4q, else W chunk wave + 4(q - A_Q) (skipped when beyond the tile)
+    const size_t a_qstride = (size_t)(8 * NW) * p.lda, b_qstride = (size_t)(8 * NW) * p.K;
+    // one global->LDS instruction: q < A_Q -> A chunk wave + NW q, else W chunk wave + NW (q - A_Q).  A wave whose last W chunk
+    // would fall beyond the tile skips it when the ring is drained with vmcnt(0) (S == 2); with counted waits (S == 3) it re-loads
+    // its first W chunk instead (same bytes to the same place), so that every wave has the same number of loads in flight
     auto stage_one = [&](int buf, int q) {
         char* sA = ring + buf * STAGE_BYTES;
         if (q < A_Q) {
-            glds16(a_src + q * a_qstride, sA + (wave + 4 * q) * 1024);
+            glds16(a_src + q * a_qstride, sA + (wave + NW * q) * 1024);
         } else {
             const int qb = q - A_Q;
-            if ((B_CH % 4 == 0) || qb < B_Q - 1 || wave < (B_CH & 3))
-                glds16(b_src + qb * b_qstride, sA + A_BYTES + (wave + 4 * qb) * 1024);
+            if ((B_CH % NW == 0) || qb < B_Q - 1 || wave < (B_CH % NW))
+                glds16(b_src + qb * b_qstride, sA + A_BYTES + (wave + NW * qb) * 1024);
+            else if (S > 2)
+                glds16(b_src, sA + A_BYTES + wave * 1024);
         }
     };
-    constexpr int LOADS = A_Q + B_Q;
     auto stage_advance = [&]() {
         a_src += 64 * KS;
         b_src += 64 * KS;
@@ -117,13 +137,16 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     const int a_row_off = (wm * WTM + l15) * 128;
     const int b_row_off = A_BYTES + (wn * WTN + l15) * 128;
 
-    const int nk = (p.K >> 6) / KS;   // K steps of this group
+    const int nk = (p.K >> 6) / KS;   // K steps of this group (>= S - 1: dispatcher)
 #pragma unroll
-    for (int q = 0; q < LOADS; ++q) stage_one(0, q);
-    stage_advance();
+    for (int s = 0; s < S - 1; ++s) {
+#pragma unroll
+        for (int q = 0; q < LOADS; ++q) stage_one(s, q);
+        stage_advance();
+    }
 
     // LayerNorm folding: mean / rstd of the token rows this wave finishes after the K-group exchange (token fragments
-    // i = kg*MIH + h).  Fetched and reduced HERE, under the first tile's load latency, not in the epilogue (a chain of dependent
+    // i = kg*MIH + h).  Fetched and reduced HERE, under the first tiles' load latency, not in the epilogue (a chain of dependent
     // L2 / fabric round trips there).  The four lanes that share a token (one per quad) take a contiguous quarter of the
     // producer's slots each -- all loads issued before the first use -- and combine by two xor shuffles (fixed order).
     float ln_mean[MIH], ln_rstd[MIH];
@@ -171,14 +194,16 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
         }
     }
 
-    // one K step; STAGE: also issue the next tile's global->LDS loads, spread over the two 32-wide K slices
-    auto kstep = [&](int kt, auto stage_c) {
+    // one K step.  STAGE: also issue the global->LDS loads of tile kt + S - 1 (into the buffer step kt - 1 just finished reading),
+    // spread over the two 32-wide K slices; INFLIGHT: younger stages that may stay outstanding across this step's barrier
+    int buf = 0, sbuf = S - 1;   // ring positions of the tile being read / being staged (kept modulo S without a division)
+    auto kstep = [&](auto stage_c, auto inflight_c) {
         constexpr bool STAGE = decltype(stage_c)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int INFLIGHT = decltype(inflight_c)::value;
+        g16_wait_vmcnt<INFLIGHT * LOADS>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int sbuf = (kt + 1) & 1;
-        const char* sT = ring + (kt & 1) * STAGE_BYTES;
+        const char* sT = ring + buf * STAGE_BYTES;
         bf16x8 af[2][MI], bfr[2][NI];
         auto read_frags = [&](int kk, int slot) {
             const int coff = ((4 * kk + quad) ^ sw) * 16;
@@ -207,14 +232,25 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (STAGE) stage_advance();
+        buf = buf + 1 == S ? 0 : buf + 1;
+        sbuf = sbuf + 1 == S ? 0 : sbuf + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    for (int kt = 0; kt < nk - 1; ++kt) kstep(kt, std::true_type{});
-    kstep(nk - 1, std::false_type{});
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    for (int kt = 0; kt + S - 1 < nk; ++kt) kstep(T_{}, std::integral_constant<int, S - 2>{});
+    if constexpr (S == 3) kstep(F_{}, std::integral_constant<int, 1>{});
+    kstep(F_{}, std::integral_constant<int, 0>{});
 
     // ------------------------------------------------------------------ epilogue
     __syncthreads();   // every wave is done with its last fragment reads: the rings are scratch from here on
-    {
+    if constexpr (!TRANS) {
+        if (kg == 0 && tid < BN) {
+            ((float*)(smem + OFF_BIAS))[tid] = pre_bias;
+            ((float*)(smem + OFF_BIAS))[BN + tid] = pre_cs;
+        }
+    }
+    if constexpr (KS == 2) {
         // reduce-scatter of the K partials: group g keeps token fragments [g*MIH, (g+1)*MIH) and adds the other group's partial.
         // layout [sender][wave][h][j][r][lane] fp32: lane-contiguous, conflict-free
         float* xch = (float*)smem;
@@ -236,12 +272,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mine[((h * NI + j) * 4 + r) * 64] = acc[h][j][r];
         }
-        if constexpr (!TRANS) {
-            if (kg == 0 && tid < BN) {
-                ((float*)(smem + OFF_BIAS))[tid] = pre_bias;
-                ((float*)(smem + OFF_BIAS))[BN + tid] = pre_cs;
-            }
-        }
         __syncthreads();
         if (kg == 0) {
 #pragma unroll
@@ -258,8 +288,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[MIH + h][j][r] += theirs[((h * NI + j) * 4 + r) * 64];
         }
+    } else {
+        __syncthreads();   // bias / column sums are in LDS
     }
-    // from here on the wave's data is fin[h][j] = acc[kg*MIH + h][j] (compile-time indices in both wave-uniform branches)
+    // from here on the wave's data is acc[kg*MIH + h][j], h < MIH (compile-time indices in both wave-uniform branches)
     auto prefetch_next = [&]() {
         const unsigned pf_lines = p.pf_lines;
         if (pf_lines == 0) return;
@@ -272,6 +304,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                                              (__attribute__((address_space(3))) void*)(smem + KS * RING), 4, 0, 0);
         }
     };
+    using K0_ = std::integral_constant<int, 0>;
+    using K1_ = std::integral_constant<int, 1>;
 
     if constexpr (TRANS) {
         // D[i = token][j = channel]: lane owns channel l15 of fragment j, tokens 4*quad + r of fragment i -> 4 consecutive tokens
@@ -301,14 +335,61 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                 }
             }
         };
-        if (kg == 0) run(std::integral_constant<int, 0>{});
-        else run(std::integral_constant<int, 1>{});
+        if (kg == 0) run(K0_{});
+        else if constexpr (KS == 2) run(K1_{});
         prefetch_next();
         return;
     } else {
         const float* s_bias = (const float*)(smem + OFF_BIAS);
         const float* s_cs = s_bias + BN;
         char* c_stage = smem + OFF_CST + bwave * C_STAGE;
+        // 16-byte pieces of a staged [16][COLS] bf16 block -> row-contiguous global stores
+        auto flush_block = [&](int row_base, int col_base, auto cols_c) {
+            constexpr int COLS = decltype(cols_c)::value;
+            constexpr int PPR = COLS / 8, PIECES = 16 * PPR;
+#pragma unroll
+            for (int rr = 0; rr < (PIECES + 63) / 64; ++rr) {
+                const int id = rr * 64 + lane;
+                if (PIECES % 64 == 0 || id < PIECES) {
+                    const int row = id / PPR, ch = id - row * PPR;
+                    const f32x4 piece = *(const f32x4*)(c_stage + row * C_RS + ch * 16);
+                    *(f32x4*)((bf16_t*)p.C + (size_t)(row_base + row) * p.ldc + col_base + ch * 8) = piece;
+                }
+            }
+        };
+        if (p.act == 2) {
+            // GEGLU: W rows interleaved [16 value | 16 gate]: fragment pair (2 jp, 2 jp + 1) = (value, gate) of 16 output columns
+            if constexpr ((NI & 1) == 0) {
+                auto run = [&](auto kg_c) {
+                    constexpr int KG = decltype(kg_c)::value;
+#pragma unroll
+                    for (int h = 0; h < MIH; ++h) {
+                        const int mrow = wm * WTM + (KG * MIH + h) * 16;
+                        const float mu = ln_mean[h], rs = ln_rstd[h];
+#pragma unroll
+                        for (int jp = 0; jp < NI / 2; ++jp) {
+                            const int nl = wn * WTN + jp * 32 + 4 * quad;
+                            const f32x4 bv = *(const f32x4*)(s_bias + nl), bg = *(const f32x4*)(s_bias + nl + 16);
+                            const f32x4 cv = *(const f32x4*)(s_cs + nl), cg = *(const f32x4*)(s_cs + nl + 16);
+                            float r[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = rs * (acc[KG * MIH + h][2 * jp][e] - mu * cv[e]) + bv[e];
+                                const float g = rs * (acc[KG * MIH + h][2 * jp + 1][e] - mu * cg[e]) + bg[e];
+                                r[e] = v * gelu_f(g);
+                            }
+                            const u32x2 o = {f2bf_pk(r[0], r[1]), f2bf_pk(r[2], r[3])};
+                            *(u32x2*)(c_stage + l15 * C_RS + (jp * 16 + 4 * quad) * 2) = o;
+                        }
+                        flush_block(m0 + mrow, (n0 >> 1) + wn * (WTN / 2), std::integral_constant<int, WTN / 2>{});
+                    }
+                };
+                if (kg == 0) run(K0_{});
+                else if constexpr (KS == 2) run(K1_{});
+            }
+            prefetch_next();
+            return;
+        }
         auto run = [&](auto kg_c, auto silu_c) {
             constexpr int KG = decltype(kg_c)::value;
             constexpr bool SILU = decltype(silu_c)::value;
@@ -352,17 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                     rsq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
                     *(u32x2*)(c_stage + l15 * C_RS + (j * 16 + 4 * quad) * 2) = o;
                 }
-                // the wave's 16 x WTN block is row-major in LDS now: 16-byte pieces, row-contiguous global stores
-                constexpr int PPR = WTN / 8, PIECES = 16 * PPR;
-#pragma unroll
-                for (int rr = 0; rr < (PIECES + 63) / 64; ++rr) {
-                    const int id = rr * 64 + lane;
-                    if (PIECES % 64 == 0 || id < PIECES) {
-                        const int row = id / PPR, ch = id - row * PPR;
-                        const f32x4 piece = *(const f32x4*)(c_stage + row * C_RS + ch * 16);
-                        *(f32x4*)((bf16_t*)p.C + (size_t)(m0 + mrow + row) * p.ldc + n0 + wn * WTN + ch * 8) = piece;
-                    }
-                }
+                flush_block(m0 + mrow, n0 + wn * WTN, std::integral_constant<int, WTN>{});
                 if (p.rowstats_out) {
                     rsum += __shfl_xor(rsum, 16, 64);
                     rsq += __shfl_xor(rsq, 16, 64);
@@ -382,14 +453,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                 }
             }
         };
-        using T_ = std::true_type;
-        using F_ = std::false_type;
-        using K0_ = std::integral_constant<int, 0>;
-        using K1_ = std::integral_constant<int, 1>;
         if (kg == 0) {
             if (p.act == 1) run(K0_{}, T_{});
             else run(K0_{}, F_{});
-        } else {
+        } else if constexpr (KS == 2) {
             if (p.act == 1) run(K1_{}, T_{});
             else run(K1_{}, F_{});
         }
@@ -413,27 +480,31 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     }
 }
 
-template <int BN, int WM, int WN, bool TRANS>
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS>
 static int launch_gemm16(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
-    supir_choose_xcd_grid(a, a.M / 128, a.N / BN, 2.0 * (double)a.M * a.K, 2.0 * (double)a.N * a.K);
-    constexpr int smem = 2 * 2 * (128 + BN) * 128 + 256;   // two rings of two stages + the prefetch scratch row
-    auto kern = gemm16_kernel<BN, WM, WN, TRANS>;
+    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, 2.0 * (double)a.M * a.K, 2.0 * (double)a.N * a.K);
+    constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // the ring(s) + the prefetch scratch row
+    static_assert(smem <= 163840, "LDS");
+    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    SUPIR_LAUNCH(kern, dim3((a.M / 128) * (a.N / BN)), dim3(512), smem, st, a);
+    SUPIR_LAUNCH(kern, dim3((a.M / BM) * (a.N / BN)), dim3(512), smem, st, a);
     return SUPIR_LAUNCH_STATUS();
 }
 
-// tiles 32 (128 x 80) and 33 (128 x 160); returns SUPIR_ERR_SHAPE when the problem is not an exact fit (the caller falls back)
+// tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile) {
-    const int bn = tile == 32 ? 80 : 160;
-    if (tile != 32 && tile != 33) return false;
-    if (a.M % 128 || a.N % bn || a.K % 128 || a.lda % 8) return false;
-    if (a.act == 2 || a.out_mode == 1 || a.ln_slots > 32) return false;
+    if (tile < 32 || tile > 35) return false;
+    const int bm = tile == 34 ? 256 : 128, bn = (tile == 32 || tile == 35) ? 80 : 160;
+    const int ks = tile == 34 ? 1 : 2, s = (tile == 34 || tile == 35) ? 3 : 2;
+    if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
+    if (a.out_mode == 1 || a.ln_slots > 32) return false;
+    if (a.act == 2)
+        return tile == 34 && a.out_mode == 0 && !a.res && !a.rowbias && !a.rowstats_out && a.ldc % 8 == 0 && (((size_t)a.C) & 15) == 0;
     if (a.out_mode == 2) return a.rows_per_batch % 4 == 0 && a.ldc % 4 == 0 && !a.res && !a.rowbias && a.act == 0;
     if (a.ldc % 8 || (((size_t)a.C) & 15)) return false;
     if ((a.res && a.ldr % 4) || (a.rowbias && a.ld_rb % 4)) return false;
@@ -442,6 +513,11 @@ bool supir_gemm16_supported(const GemmArgs& a, int tile) {
 
 int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile) {
     if (!supir_gemm16_supported(a, tile)) return SUPIR_ERR_SHAPE;
-    if (a.out_mode == 2) return tile == 32 ? launch_gemm16<80, 4, 1, true>(a, st) : launch_gemm16<160, 2, 2, true>(a, st);
-    return tile == 32 ? launch_gemm16<80, 4, 1, false>(a, st) : launch_gemm16<160, 2, 2, false>(a, st);
+    const bool t = a.out_mode == 2;
+    switch (tile) {
+        case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(a, st);
+        case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(a, st);
+        case 34: return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true>(a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false>(a, st);
+        default: return t ? launch_gemm16<128, 80, 4, 1, 2, 3, true>(a, st) : launch_gemm16<128, 80, 4, 1, 2, 3, false>(a, st);
+    }
 }

@@ -100,14 +100,17 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = Linear(dim_in, dim_out * 2)
         object.__setattr__(self, "_il", Prep())
+        object.__setattr__(self, "_il16", Prep())
 
-    def w_interleaved(self):
-        return self._il.get((self.proj.weight, self.proj.bias),
-                            lambda: Wt.interleave_geglu(Wt.linear_w(self.proj.weight), Wt.f32(self.proj.bias)))
+    def w_interleaved(self, block=32):
+        """value / gate rows interleaved per `block` rows: 32 for the gemm.hip tiles, 16 for tile 34 of gemm16.hip."""
+        prep = self._il if block == 32 else self._il16
+        return prep.get((self.proj.weight, self.proj.bias),
+                        lambda: Wt.interleave_geglu(Wt.linear_w(self.proj.weight), Wt.f32(self.proj.bias), block))
 
     def forward(self, x):
         w, b = self.w_interleaved()
-        return ops.gemm(tokens_bf16(x), w, b, act=2)
+        return ops.gemm(tokens_bf16(x), w, b, act=2, alt16=self.w_interleaved(16) if ops.USE_GEMM16 else None)
 
 
 class FeedForward(nn.Module):
@@ -156,7 +159,9 @@ class BasicTransformerBlock(nn.Module):
             gw, gc, gb = Wt.fold_layernorm(ff.proj.weight, ff.proj.bias, n3.weight, n3.bias)
             gwi, gbi = Wt.interleave_geglu(gw, gb)
             _, gci = Wt.interleave_geglu(gw, gc)
-            return dict(qk=qk, v=v, q2=q2, geglu=(gwi, gci, gbi))
+            gw16, gb16 = Wt.interleave_geglu(gw, gb, 16)      # tile 34 (csrc/gemm16.hip) pairs value / gate per 16 rows
+            _, gc16 = Wt.interleave_geglu(gw, gc, 16)
+            return dict(qk=qk, v=v, q2=q2, geglu=(gwi, gci, gbi), geglu16=(gw16, gc16, gb16))
 
         return self._fold.get(srcs, build)
 
@@ -189,7 +194,7 @@ class BasicTransformerBlock(nn.Module):
         if FINALIZE_STATS:
             stats = ops.rowstats_finalize(stats, C, e3)
         w, cs, b = f["geglu"]
-        g = ops.gemm_ln(x, w, b, act=2, ln=stats, colsum=cs, ln_eps=e3)
+        g = ops.gemm_ln(x, w, b, act=2, ln=stats, colsum=cs, ln_eps=e3, alt16=f["geglu16"] if ops.USE_GEMM16 else None)
         l2 = self.ff.net[2]
         return ops.gemm_ln(g, l2.w(), l2.b32(), residual=x, out=x, emit_stats=True)
 

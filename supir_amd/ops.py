@@ -62,7 +62,8 @@ def finish_timing(trace):
 
 def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
     if tile is not None and tile >= 32:
-        return f"gemm16_kernel<128,{80 if tile == 32 else 160},2k{',T' if trans else ''}>"
+        nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3"}[tile]
+        return f"gemm16_kernel<{nm}{',T' if trans else ''}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
             "128,128,2x2x2k"][t]
@@ -237,8 +238,9 @@ def _pf(w):
 
 # --------------------------------------------------------------------------------------------- GEMM family
 def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=0, alpha=1.0, out=None,
-         out_dtype=BF16, tile=-1):
-    """out[M,N] = alpha*act(a[M,K] @ w[N,K]^T + bias + rowbias[batch]) + residual.  act=2 (GEGLU) -> N/2 columns."""
+         out_dtype=BF16, tile=-1, alt16=None):
+    """out[M,N] = alpha*act(a[M,K] @ w[N,K]^T + bias + rowbias[batch]) + residual.  act=2 (GEGLU) -> N/2 columns.
+    alt16 = (w, bias) in the 16-row GEGLU interleave: lets the autotuner also try tile 34 (csrc/gemm16.hip)."""
     lib = _lib.load()
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
@@ -259,20 +261,26 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         ld_rb = rowbias.stride(0)
     om = 0 if out.dtype == BF16 else 1
 
-    def launch(t):
-        return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, ldc, _p(bias), _p(rowbias), ld_rb,
-                                   rows_per_batch, _p(residual), ldr, act, om, alpha, t, _stream())
+    def launch(t, outp=None):
+        wq, bq = (alt16[0], alt16[1]) if (t == 34 and act == 2) else (w, bias)
+        return lib.supir_gemm_bf16(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
+                                   _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, act, om, alpha, t, _stream())
 
     if tile == -1:
         key = ("gemm", M, N, K, act, om)
         ok = (lda % 8 == 0 and out.data_ptr() % 16 == 0 and (residual is None or ldr % 4 == 0)
               and (rowbias is None or ld_rb % 4 == 0))
-        cands = _gemm_candidates(M, N, K, act, om, ldc, epilogue_ok=ok)
+        cands = _gemm_candidates(M, N, K, act, om, ldc, epilogue_ok=ok, geglu16=alt16 is not None)
         if residual is not None and residual.data_ptr() == out.data_ptr():
-            tile = _TUNE.get(key, -1)   # in-place accumulate: re-launching would change the data, only reuse a known winner
+            # in-place accumulate (x += f(x)): re-launching would change the data, so the candidates are timed into a scratch
+            # output of the same strides (reads `residual`, never writes it)
+            tile = _TUNE.get(key)
+            if tile is None:
+                scratch = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device)
+                tile = _autotune(key, cands, lambda t: launch(t, scratch))
         else:
             tile = _autotune(key, cands, launch)
-        if tile >= 32 and tile not in cands:   # a winner cached for this shape under friendlier strides
+        if tile >= 32 and tile not in cands:   # a winner cached for this shape under friendlier strides / layouts
             tile = -1
     _pf(w)
     ev = _ev()
@@ -283,23 +291,31 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
 
 _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
-               32: (80, 1), 33: (160, 2)}
+               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1)}
+G16_TILES = {32, 33, 34, 35}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
+_G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3)}   # tile: (BM, BN, K groups, ring)
 USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc/gemm16.hip) in the autotune lists
 
 
-def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True):
-    """Tile candidates for the autotuner.  Tiles 32 / 33 (128 x 80 / 128 x 160, 16x16x32 MFMA, two K groups: exactly 256
-    workgroups on the M = 2048, N = 1280 k shapes) take exact shapes only -- the same predicate as supir_gemm16_supported."""
+def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu16=False):
+    """Tile candidates for the autotuner.  Tiles 32-35 (csrc/gemm16.hip: 16x16x32 MFMA, tile grids that are exact multiples of
+    the 256 CUs) take exact shapes only -- the same predicate as supir_gemm16_supported.  act = 2 (GEGLU) can use tile 34 when the
+    caller also supplied the 16-row-interleaved weight layout (`geglu16`)."""
     base = (0, 2, 4, 5, 6) if act == 2 else (0, 1, 2, 3, 4, 5, 6)
-    if not USE_GEMM16 or act == 2 or om == 1 or M % 128 or K % 128 or ln_slots > 32 or not epilogue_ok:
+    if not USE_GEMM16 or om == 1 or ln_slots > 32 or not epilogue_ok:
         return base
-    if om == 2 and ldc % 4:
+    if (om == 2 and ldc % 4) or (om == 0 and ldc % 8):
         return base
-    if om == 0 and ldc % 8:
-        return base
-    extra = tuple(t for t, bn in ((32, 80), (33, 160)) if N % bn == 0)
-    return base + extra
-MAX_SLOTS_PER = 32   # rowstats slot granularity: one slot per 32 output columns at the finest (64-wide tile, 2 wave columns)
+    extra = []
+    for t, (bm, bn, ks, s) in _G16.items():
+        if t not in G16_TILES:
+            continue
+        if M % bm or N % bn or K % (64 * ks) or (K // 64) // ks < s - 1:
+            continue
+        if act == 2 and not (t == 34 and geglu16):
+            continue
+        extra.append(t)
+    return base + tuple(extra)
 
 
 class RowStats:
@@ -326,9 +342,10 @@ def rowstats_finalize(st, dim, eps):
 
 
 def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=-1, emit_stats=False, ln=None, colsum=None,
-            ln_eps=1e-5, trans=None):
+            ln_eps=1e-5, trans=None, alt16=None):
     """GEMM with LayerNorm folding (see supir_gemm_bf16_ln).  ln = RowStats of `a` (consumer side), emit_stats=True makes
-    this call a producer and returns (out, RowStats).  trans=(B, T, Tpad) selects the transposed (V^T) output."""
+    this call a producer and returns (out, RowStats).  trans=(B, T, Tpad) selects the transposed (V^T) output.
+    alt16 = (w, colsum, bias) in the 16-row GEGLU interleave (act = 2): lets the autotuner also try tile 34."""
     lib = _lib.load()
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
@@ -361,18 +378,22 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
         ln_p, ln_ld, ln_slots = ln.buf.data_ptr(), ln.ld, ln.slots
         assert colsum is not None and colsum.numel() == N
 
-    def launch(t):
-        return lib.supir_gemm_bf16_ln(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, ldc, _p(bias), _p(residual),
-                                      ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots, _p(colsum), ln_eps,
-                                      _stream())
+    def launch(t, outp=None):
+        wq, cq, bq = alt16 if (t == 34 and act == 2) else (w, colsum, bias)
+        return lib.supir_gemm_bf16_ln(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
+                                      _p(bq), _p(residual), ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots,
+                                      _p(cq), ln_eps, _stream())
 
     if tile == -1:
         key = ("gemm", M, N, K, act, om)
         ok = (lda % 8 == 0 and out.data_ptr() % 16 == 0 and (residual is None or ldr % 4 == 0)
               and (trans is None or rpb % 4 == 0))
-        cands = _gemm_candidates(M, N, K, act, om, ldc, ln_slots=ln_slots, epilogue_ok=ok)
+        cands = _gemm_candidates(M, N, K, act, om, ldc, ln_slots=ln_slots, epilogue_ok=ok, geglu16=alt16 is not None)
         if residual is not None and residual.data_ptr() == out.data_ptr():
-            tile = _TUNE.get(key, -1)
+            tile = _TUNE.get(key)
+            if tile is None:   # in-place accumulate: time the candidates into a scratch output (see gemm())
+                scratch = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device)
+                tile = _autotune(key, cands, lambda t: launch(t, scratch))
         else:
             tile = _autotune(key, cands, launch)
         if tile >= 32 and tile not in cands:

@@ -29,17 +29,18 @@ def f32(t):
     return None if t is None else t.detach().float().contiguous()
 
 
-def interleave_geglu(w, b):
+def interleave_geglu(w, b, block=32):
     """GEGLU.proj weight [2N, K] (first half value, second half gate; sgm/modules/attention.py:89-91) ->
-    rows interleaved in blocks of 32 value rows + 32 gate rows so that one wave's fragment pair holds value and gate
-    of the same 32 output columns (supir_gemm_bf16 act=GEGLU)."""
+    rows interleaved in blocks of `block` value rows + `block` gate rows so that one wave's fragment pair holds value and
+    gate of the same `block` output columns (supir_gemm_bf16 act=GEGLU): 32 for the 32x32x16-MFMA tiles of gemm.hip, 16 for
+    the 16x16x32-MFMA tile 34 of gemm16.hip."""
     n2, k = w.shape
     n = n2 // 2
-    assert n % 32 == 0 and n2 % 128 == 0
-    wi = torch.stack([w[:n].reshape(n // 32, 32, k), w[n:].reshape(n // 32, 32, k)], dim=1).reshape(n2, k).contiguous()
+    assert n % block == 0 and n2 % 128 == 0
+    wi = torch.stack([w[:n].reshape(n // block, block, k), w[n:].reshape(n // block, block, k)], dim=1).reshape(n2, k).contiguous()
     bi = None
     if b is not None:
-        bi = torch.stack([b[:n].reshape(n // 32, 32), b[n:].reshape(n // 32, 32)], dim=1).reshape(n2).contiguous()
+        bi = torch.stack([b[:n].reshape(n // block, block), b[n:].reshape(n // block, block)], dim=1).reshape(n2).contiguous()
     return wi, bi
 
 

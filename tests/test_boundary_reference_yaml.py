@@ -1,0 +1,120 @@
+"""Boundary proof: the REFERENCE's own construction path -- `SUPIR.util.create_SUPIR_model`
+(/root/reference/SUPIR/util.py:34-51: OmegaConf.load -> instantiate_from_config(config.model) -> load_state_dict(strict=False))
+-- run on the reference's real `options/SUPIR_v0.yaml` and `options/SUPIR_v0_tiled.yaml` after `supir_amd.plugin.install()`
+must build THIS package's classes, accept reference-keyed state dicts, and expose the attribute protocol test.py uses
+(test.py:62-68).  Only the text conditioner is stubbed (CLIP weights are not available).
+
+CPU tier; needs the reference checkout (present in the build container, absent on the GPU box -> skipped there).  The pip
+packages the reference imports but this image lacks (omegaconf, cv2, ...) come from the oracle's inert import stubs: test
+infrastructure, never touched by the product path.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import ref_import
+
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason="reference checkout not mounted")
+
+
+class StubConditioner(torch.nn.Module):
+    """Stands in for sgm.modules.GeneralConditionerWithControl (sgm/modules/encoders/modules.py:193-243): same call surface."""
+
+    def __init__(self, emb_models=None):
+        super().__init__()
+        self.n_embedders = len(emb_models or [])
+
+    def get_unconditional_conditioning(self, batch_c, batch_uc=None, force_uc_zero_embeddings=None):
+        n = len(batch_c["txt"])
+        mk = lambda: {"crossattn": torch.zeros(n, 77, 2048), "vector": torch.zeros(n, 2816), "control": batch_c["control"]}
+        return mk(), (mk() if batch_uc is not None else None)
+
+
+@pytest.fixture(scope="module")
+def ref_util():
+    """The reference's SUPIR.util module, imported for real (with stubs for missing pip packages), AFTER plugin.install()."""
+    ref_import._install_stubs()
+    if ref_import.REF_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REF_ROOT)
+    from supir_amd import plugin
+    aliased = plugin.install()
+    assert "SUPIR.models.SUPIR_model.SUPIRModel" in aliased
+    with ref_import.quiet():
+        import SUPIR.util as ref_util_mod
+    return ref_util_mod
+
+
+def _yaml_without_checkpoints(tmp_path, name):
+    """The reference YAML, byte for byte, except: checkpoint paths -> null (no weights here) and the conditioner target -> stub."""
+    import yaml
+    src = os.path.join(ref_import.REF_ROOT, "options", name)
+    cfg = yaml.safe_load(open(src))
+    for k in ("SDXL_CKPT", "SUPIR_CKPT", "SUPIR_CKPT_F", "SUPIR_CKPT_Q"):
+        assert k in cfg
+        cfg[k] = None
+    cond = cfg["model"]["params"]["conditioner_config"]
+    assert cond["target"] == "sgm.modules.GeneralConditionerWithControl"
+    cond["target"] = "tests.test_boundary_reference_yaml.StubConditioner"
+    out = tmp_path / name
+    yaml.safe_dump(cfg, open(out, "w"))
+    return str(out), cfg
+
+
+@pytest.mark.parametrize("name,sampler", [("SUPIR_v0.yaml", "RestoreEDMSampler"), ("SUPIR_v0_tiled.yaml", "TiledRestoreEDMSampler")])
+def test_create_supir_model_from_reference_yaml_builds_this_package(ref_util, tmp_path, name, sampler):
+    import supir_amd.models.supir_model as M
+    import supir_amd.modules.sampling as S
+    import supir_amd.modules.supir_v0 as V
+    import supir_amd.modules.vae as VA
+    import supir_amd.modules.wrappers as W
+    path, cfg = _yaml_without_checkpoints(tmp_path, name)
+    with ref_import.quiet():
+        model = ref_util.create_SUPIR_model(path, SUPIR_sign=None)       # the reference's function, unmodified
+    assert type(model) is M.SUPIRModel
+    assert type(model.model) is W.ControlWrapper
+    assert type(model.model.diffusion_model) is V.LightGLVUNet and type(model.model.control_model) is V.GLVControl
+    assert type(model.first_stage_model) is VA.AutoencoderKLInferenceWrapper
+    assert type(model.denoiser) is S.DiscreteDenoiserWithControl
+    assert type(model.sampler).__name__ == sampler and type(model.sampler).__module__ == S.__name__
+    if sampler.startswith("Tiled"):
+        assert model.sampler.tile_size == 128 and model.sampler.tile_stride == 64
+    assert isinstance(model.conditioner, StubConditioner) and model.conditioner.n_embedders == 5
+    # YAML params arrived: dtypes, scale factor (options/SUPIR_v0.yaml:4-6)
+    assert model.ae_dtype == torch.bfloat16 and model.model.dtype == torch.float16 and model.scale_factor == 0.13025
+    for p in model.parameters():
+        assert p.device.type == "cpu"
+
+    # state-dict round trip with the reference's keys, strict=False exactly like SUPIR/util.py:38-47
+    keys = ["model.diffusion_model.input_blocks.4.1.transformer_blocks.0.attn1.to_q.weight",
+            "model.diffusion_model.project_modules.0.zero_conv.weight", "model.diffusion_model.out.2.bias",
+            "model.control_model.input_hint_block.0.weight", "model.control_model.middle_block.1.proj_in.weight",
+            "first_stage_model.decoder.conv_out.weight", "first_stage_model.denoise_encoder.down.0.block.0.conv1.weight",
+            "first_stage_model.quant_conv.bias"]
+    own = model.state_dict()
+    sd = {}
+    g = torch.Generator().manual_seed(0)
+    for k in keys:
+        assert k in own, k
+        sd[k] = torch.randn(own[k].shape, generator=g)
+    sd["conditioner.embedders.0.transformer.text_model.final_layer_norm.weight"] = torch.zeros(768)   # not on our path
+    res = model.load_state_dict(sd, strict=False)
+    assert res.unexpected_keys == ["conditioner.embedders.0.transformer.text_model.final_layer_norm.weight"]
+    after = model.state_dict()
+    for k in keys:
+        assert torch.equal(after[k], sd[k]), k
+
+    # the attribute protocol of test.py:62-68
+    model.init_tile_vae(encoder_tile_size=512, decoder_tile_size=64)
+    model.ae_dtype = torch.bfloat16
+    model.model.dtype = torch.bfloat16
+    assert callable(model.batchify_sample) and callable(model.model.load_control_model)
+
+
+def test_reference_default_setting_block_is_served(ref_util, tmp_path):
+    """create_SUPIR_model(..., load_default_setting=True) (SUPIR/util.py:48-50) returns the YAML's default_setting untouched."""
+    path, cfg = _yaml_without_checkpoints(tmp_path, "SUPIR_v0.yaml")
+    with ref_import.quiet():
+        model, default = ref_util.create_SUPIR_model(path, load_default_setting=True)
+    assert default["edm_steps"] == 50 and default["s_cfg_Quality"] == 7.5

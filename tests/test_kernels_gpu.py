@@ -473,13 +473,17 @@ G16_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (8192,
               (384, 320, 256)]
 
 
+_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80)}
+
+
 @pytest.mark.parametrize("M,N,K", G16_SHAPES)
-@pytest.mark.parametrize("tile", [32, 33])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35])
 def test_gemm16_plain_and_epilogues(M, N, K, tile):
-    """128 x 80 / 128 x 160 tiles (v_mfma_f32_16x16x32_bf16, two K groups per workgroup): plain, residual + alpha, row bias +
-    SiLU, strided operands, run-to-run bitwise equality."""
-    if N % (80 if tile == 32 else 160):
-        pytest.skip("tile needs N % BN == 0")
+    """128 x 80 / 128 x 160 / 256 x 160 tiles (v_mfma_f32_16x16x32_bf16; two K groups per workgroup or eight waves on a 3-deep
+    ring): plain, residual + alpha, row bias + SiLU, strided operands, run-to-run bitwise equality."""
+    bm, bn = _G16_TILE[tile]
+    if N % bn or M % bm:
+        pytest.skip("tile needs M % BM == 0 and N % BN == 0")
     a = rnd(M, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
     bias = rnd(N, seed=2)
@@ -506,8 +510,8 @@ def test_gemm16_plain_and_epilogues(M, N, K, tile):
         check(acc, base + res.float(), name="in-place residual")
 
 
-@pytest.mark.parametrize("B,T,N,K", [(2, 1024, 1280, 1280), (2, 4096, 640, 640), (1, 128, 160, 128)])
-@pytest.mark.parametrize("tile", [32, 33])
+@pytest.mark.parametrize("B,T,N,K", [(2, 1024, 1280, 1280), (2, 4096, 640, 640), (1, 256, 160, 128)])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35])
 def test_gemm16_transposed(B, T, N, K, tile):
     a = rnd(B * T, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
@@ -517,8 +521,8 @@ def test_gemm16_transposed(B, T, N, K, tile):
     check(out, ref, name="gemm16_t")
 
 
-@pytest.mark.parametrize("M,C,N", [(2048, 1280, 2560), (8192, 640, 640), (256, 320, 640)])
-@pytest.mark.parametrize("ptile,ctile", [(32, 32), (33, 33), (32, 0), (3, 32), (0, 33)])
+@pytest.mark.parametrize("M,C,N", [(2048, 1280, 2560), (8192, 640, 640), (256, 640, 1280)])
+@pytest.mark.parametrize("ptile,ctile", [(32, 32), (33, 33), (32, 0), (3, 32), (0, 33), (34, 35), (35, 34)])
 def test_gemm16_layernorm_folding(M, C, N, ptile, ctile):
     """Row statistics emitted by / consumed from the 16x16x32 tiles, mixed with the 32x32x16 tiles on the other side."""
     from supir_amd.weights import fold_layernorm
@@ -556,3 +560,34 @@ def test_gemm16_rejects_inexact_shapes():
     w = rnd(96, 128, seed=1).to(BF)
     with pytest.raises(_lib.SupirHipError):
         ops.gemm(a, w, None, tile=32)          # N % 80 != 0
+
+
+@pytest.mark.parametrize("M,K,N2", [(2048, 1280, 10240), (8192, 640, 5120), (256, 128, 320)])
+def test_gemm16_geglu(M, K, N2):
+    """GEGLU epilogue of tile 34 (value / gate interleaved per 16 rows of W), plain and with the LayerNorm fold, against the
+    reference formula (sgm/modules/attention.py:89-91) and against the 32-row-interleaved tiles of gemm.hip."""
+    from supir_amd.weights import fold_layernorm, interleave_geglu
+    a = rnd(M, K).to(BF)
+    w = rnd(N2, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N2, seed=2)
+    w16, b16 = interleave_geglu(w, bias, 16)
+    out = ops.gemm(a, w16, b16, act=2, tile=34)
+    y = a.float() @ w.float().T + bias
+    v, g = y.chunk(2, dim=-1)
+    check(out, v * F.gelu(g), name="geglu16")
+    assert torch.equal(out, ops.gemm(a, w16, b16, act=2, tile=34))
+    w32, b32 = interleave_geglu(w, bias, 32)
+    check(out, ops.gemm(a, w32, b32, act=2, tile=0).float(), rel=3e-3, name="geglu16 vs geglu32")
+    # autotuned call with both layouts available picks whichever is faster and stays correct
+    check(ops.gemm(a, w32, b32, act=2, alt16=(w16, b16)), v * F.gelu(g), name="geglu auto")
+    # with the LayerNorm fold (the transformer's ff.net.0 as the product path calls it)
+    C = K
+    wp = rnd(C, C, scale=C ** -0.5, seed=5).to(BF)
+    x, st = ops.gemm_ln(a, wp, None, emit_stats=True)
+    gamma, beta = rnd(C, seed=6) * 0.2 + 1.0, rnd(C, seed=7) * 0.2
+    wf, cs, bf_ = fold_layernorm(w.float(), bias, gamma, beta)
+    wf16, bf16_ = interleave_geglu(wf, bf_, 16)
+    _, cs16 = interleave_geglu(wf, cs, 16)
+    yr = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T + bias
+    vr, gr = yr.chunk(2, dim=-1)
+    check(ops.gemm_ln(x, wf16, bf16_, act=2, ln=st, colsum=cs16, tile=34), vr * F.gelu(gr), rel=8e-3, name="geglu16 ln-fold")

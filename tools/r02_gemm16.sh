@@ -20,12 +20,20 @@ def timeit(fn, iters=30):
 for (M, N, K) in [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (2048, 1280, 640), (8192, 640, 640), (8192, 640, 2560), (2048, 10240, 1280)]:
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF); b = torch.randn(N, device="cuda")
     res = torch.randn(M, N, device="cuda").to(BF)
-    for tile in (0, 1, 3, 7, 32, 33):
-        if tile >= 32 and N % (80 if tile == 32 else 160): continue
+    for tile in (0, 1, 3, 32, 33, 34, 35):
+        if tile >= 32 and (N % {32: 80, 33: 160, 34: 160, 35: 80}[tile] or M % (256 if tile == 34 else 128)): continue
         us = timeit(lambda: ops.gemm(a, w, b, residual=res, tile=tile))
         print(dict(M=M, N=N, K=K, tile=tile, us=round(us, 1), tflops=round(2.0 * M * N * K / us / 1e6, 1)), flush=True)
+from supir_amd.weights import interleave_geglu
+for (M, N2, K) in [(2048, 10240, 1280), (8192, 5120, 640)]:
+    a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N2, K, device="cuda") * K ** -0.5).to(BF); b = torch.randn(N2, device="cuda")
+    w32, b32 = interleave_geglu(w, b, 32); w16, b16 = interleave_geglu(w, b, 16)
+    for tile in (0, 2, 4, 34):
+        ww, bb = (w16, b16) if tile == 34 else (w32, b32)
+        us = timeit(lambda: ops.gemm(a, ww, bb, act=2, tile=tile))
+        print(dict(geglu=True, M=M, N2=N2, K=K, tile=tile, us=round(us, 1), tflops=round(2.0 * M * N2 * K / us / 1e6, 1)), flush=True)
 PY
 echo "timing rc=$?" | tee -a $O/summary.log
 cat $O/timing.log
-timeout 400 python tools/step_ab.py base gemm16 > $O/step_ab.log 2>&1; echo "step_ab rc=$?" | tee -a $O/summary.log
+timeout 600 python tools/step_ab.py base g32_33 g32_33_34 gemm16 > $O/step_ab.log 2>&1; echo "step_ab rc=$?" | tee -a $O/summary.log
 grep -E "ms/step|rel-L2|^\{" $O/step_ab.log | cut -c1-400

@@ -1,7 +1,7 @@
 """In-process A/B of one CFG-doubled UNet+control step at 1024^2 (latent 128^2, B = 2) under hipGraph replay.
 Variants are ops-level switches (autotune candidate lists); each variant re-tunes from scratch, re-captures the graph and is
 timed twice, interleaved (box-to-box spread is ~5 %, so never compare numbers from two calls).
-Usage: python tools/step_ab.py [variant ...]   variants: base | gemm16"""
+Usage: python tools/step_ab.py [variant ...]   variants: base | g32_33 | g32_33_34 | g32_33_35 | gemm16"""
 import json
 import os
 import sys
@@ -23,8 +23,12 @@ cond = {"crossattn": synth_tensor("ctx", (B, 77, 2048)).to(dev), "vector": synth
 t = torch.full((B,), 500, dtype=torch.int64, device=dev)
 
 
+VARIANTS = {"base": set(), "g32_33": {32, 33}, "g32_33_34": {32, 33, 34}, "g32_33_35": {32, 33, 35}, "gemm16": {32, 33, 34, 35}}
+
+
 def configure(v):
-    ops.USE_GEMM16 = v in ("gemm16",)
+    ops.G16_TILES = VARIANTS[v]
+    ops.USE_GEMM16 = bool(VARIANTS[v])
     ops._TUNE.clear()
 
 
