@@ -804,9 +804,8 @@ int supir_gemm_launch(const GemmArgs& a_in, bool conv, hipStream_t st, int force
         a.order = cost_n_fast < cost_m_fast ? 1 : 0;
     }
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return SUPIR_ERR_ARG;
-    if (force_tile >= 32) {   // the 16x16x32-MFMA, 256-workgroup tiles (gemm16.hip): exact shapes only, plain GEMM only
-        if (conv) return SUPIR_ERR_SHAPE;
-        return supir_gemm16_launch(a, st, force_tile);
+    if (force_tile >= 32) {   // the 16x16x32-MFMA, 256-workgroup tiles (gemm16.hip): exact shapes only
+        return supir_gemm16_launch(a, st, force_tile, conv);
     }
     if (a.K % 64 != 0 || a.N % 4 != 0 || a.lda % 8 != 0) return SUPIR_ERR_SHAPE;
     if (conv && (a.Cin % 64 != 0 || a.K != 9 * a.Cin)) return SUPIR_ERR_SHAPE;

@@ -41,7 +41,10 @@ __device__ __forceinline__ void g16_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS>
+// zero page for the halo / padding rows of the implicit-GEMM (3x3 convolution) loader
+__device__ __attribute__((aligned(256))) uint32_t g16_zero_page[64];
+
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;                          // waves per K group
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, MIH = MI / KS;
     static_assert(NW * KS == 8 && (BM / 8) % NW == 0 && (NW & 1) == 0, "512 threads; A chunks divide over the waves");
     static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3), "tile / wave grid");
+    static_assert(!(CONV && TRANS), "the implicit-GEMM loader has no transposed epilogue");
     // epilogue LDS map (the rings are idle by then): [0, XCH) K-group exchange, then per-wave C staging, bias / column sums,
     // row-statistics scratch
     constexpr int XCH_HALF = KS == 2 ? NW * MIH * NI * 4 * 64 * 4 : 0;   // bytes one group sends
@@ -97,13 +101,49 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     const bf16_t* a_src = p.A + (size_t)(m0 + wave * 8 + lrow) * p.lda + lchunk * 8 + kg * 64;
     const bf16_t* b_src = p.Wt + (size_t)(n0 + wave * 8 + lrow) * p.K + lchunk * 8 + kg * 64;
     const size_t a_qstride = (size_t)(8 * NW) * p.lda, b_qstride = (size_t)(8 * NW) * p.K;
+    // 3x3 convolution as implicit GEMM (same scheme as gemm.hip): K runs (ky, kx, cin) and a 64-wide K step never straddles a tap
+    // (Cin % 64 == 0; Cin % 128 == 0 with two K groups); the gather address of each of this lane's A rows is computed once per
+    // tap; halo / padding rows read the zero page; stride 2, asymmetric padding and nearest-2x upsampling fold into the gather
+    int c_iy0[CONV ? A_Q : 1], c_ix0[CONV ? A_Q : 1];
+    const bf16_t* c_base[CONV ? A_Q : 1];
+    const bf16_t* c_tap[CONV ? A_Q : 1];
+    int c_cin0 = kg * 64, c_ky = 0, c_kx = 0;
+    const int VH = p.up ? 2 * p.H : p.H, VW = p.up ? 2 * p.W : p.W;
+    auto conv_set_tap = [&]() {
+        if constexpr (CONV) {
+#pragma unroll
+            for (int q = 0; q < A_Q; ++q) {
+                int iy = c_iy0[q] + c_ky, ix = c_ix0[q] + c_kx;
+                const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW;
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                c_tap[q] = ok ? c_base[q] + ((size_t)iy * p.W + ix) * p.lda : nullptr;
+            }
+        }
+    };
+    if constexpr (CONV) {
+#pragma unroll
+        for (int q = 0; q < A_Q; ++q) {
+            const int m = m0 + (wave + NW * q) * 8 + lrow;
+            const int b = m / p.rows_per_batch, r = m - b * p.rows_per_batch;
+            const int oy = r / p.OW, ox = r - oy * p.OW;
+            c_iy0[q] = oy * p.stride - p.pad_t;
+            c_ix0[q] = ox * p.stride - p.pad_l;
+            c_base[q] = p.A + (size_t)b * p.H * p.W * p.lda + lchunk * 8;
+        }
+        conv_set_tap();
+    }
     // one global->LDS instruction: q < A_Q -> A chunk wave + NW q, else W chunk wave + NW (q - A_Q).  A wave whose last W chunk
     // would fall beyond the tile skips it when the ring is drained with vmcnt(0) (S == 2); with counted waits (S == 3) it re-loads
     // its first W chunk instead (same bytes to the same place), so that every wave has the same number of loads in flight
     auto stage_one = [&](int buf, int q) {
         char* sA = ring + buf * STAGE_BYTES;
         if (q < A_Q) {
-            glds16(a_src + q * a_qstride, sA + (wave + NW * q) * 1024);
+            if constexpr (CONV) {
+                const bf16_t* src = c_tap[q] ? c_tap[q] + c_cin0 : (const bf16_t*)g16_zero_page;
+                glds16(src, sA + (wave + NW * q) * 1024);
+            } else {
+                glds16(a_src + q * a_qstride, sA + (wave + NW * q) * 1024);
+            }
         } else {
             const int qb = q - A_Q;
             if ((B_CH % NW == 0) || qb < B_Q - 1 || wave < (B_CH % NW))
@@ -115,6 +155,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     auto stage_advance = [&]() {
         a_src += 64 * KS;
         b_src += 64 * KS;
+        if constexpr (CONV) {
+            c_cin0 += 64 * KS;
+            if (c_cin0 >= p.Cin) {   // next tap (Cin % (64 KS) == 0: the K groups stay tap-aligned)
+                c_cin0 -= p.Cin;
+                if (++c_kx == 3) { c_kx = 0; ++c_ky; }
+                conv_set_tap();
+            }
+        }
     };
 
     // epilogue vectors of this tile's BN columns, fetched now (one element per thread of group 0), parked in LDS after the loop
@@ -480,13 +528,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS>
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false>
 static int launch_gemm16(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
-    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, 2.0 * (double)a.M * a.K, 2.0 * (double)a.N * a.K);
+    const double a_bytes = CONV ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin : 2.0 * (double)a.M * a.K;
+    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, a_bytes, 2.0 * (double)a.N * a.K);
     constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // the ring(s) + the prefetch scratch row
     static_assert(smem <= 163840, "LDS");
-    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS>;
+    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
@@ -497,12 +546,15 @@ static int launch_gemm16(const GemmArgs& a_in, hipStream_t st) {
 }
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
-bool supir_gemm16_supported(const GemmArgs& a, int tile) {
+bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
     if (tile < 32 || tile > 35) return false;
     const int bm = tile == 34 ? 256 : 128, bn = (tile == 32 || tile == 35) ? 80 : 160;
     const int ks = tile == 34 ? 1 : 2, s = (tile == 34 || tile == 35) ? 3 : 2;
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
+    if (conv) {
+        if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
+    }
     if (a.act == 2)
         return tile == 34 && a.out_mode == 0 && !a.res && !a.rowbias && !a.rowstats_out && a.ldc % 8 == 0 && (((size_t)a.C) & 15) == 0;
     if (a.out_mode == 2) return a.rows_per_batch % 4 == 0 && a.ldc % 4 == 0 && !a.res && !a.rowbias && a.act == 0;
@@ -511,8 +563,16 @@ bool supir_gemm16_supported(const GemmArgs& a, int tile) {
     return true;
 }
 
-int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile) {
-    if (!supir_gemm16_supported(a, tile)) return SUPIR_ERR_SHAPE;
+int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) {
+    if (!supir_gemm16_supported(a, tile, conv)) return SUPIR_ERR_SHAPE;
+    if (conv) {
+        switch (tile) {
+            case 32: return launch_gemm16<128, 80, 4, 1, 2, 2, false, true>(a, st);
+            case 33: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true>(a, st);
+            case 34: return launch_gemm16<256, 160, 8, 1, 1, 3, false, true>(a, st);
+            default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(a, st);
+        }
+    }
     const bool t = a.out_mode == 2;
     switch (tile) {
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(a, st);

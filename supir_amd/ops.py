@@ -475,7 +475,20 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
                                       act, om, alpha, t, _stream())
 
     if tile == -1:
-        tile = _autotune(("conv", B, H, W, Cin, Cout, stride, bool(upsample)), (0, 1, 2, 3, 4, 5, 6), launch)
+        M_ = B * OH * OW
+        cands = [0, 1, 2, 3, 4, 5, 6]
+        if USE_GEMM16 and om == 0 and act != 2 and ldx % 8 == 0 and ldy % 8 == 0 and out.data_ptr() % 16 == 0 \
+                and (residual is None or ldr % 4 == 0) and (rowbias is None or ld_rb % 4 == 0):
+            for t, (bm, bn, ks, s_) in _G16.items():   # same predicate as supir_gemm16_supported(conv)
+                if t in G16_TILES and M_ % bm == 0 and Cout % bn == 0 and Cin % (64 * ks) == 0 and (9 * Cin // 64) // ks >= s_ - 1:
+                    cands.append(t)
+        key = ("conv", B, H, W, Cin, Cout, stride, bool(upsample))
+        if residual is not None and residual.data_ptr() == out.data_ptr():
+            tile = _TUNE.get(key, -1)
+        else:
+            tile = _autotune(key, tuple(cands), launch)
+        if tile >= 32 and tile not in cands:
+            tile = -1
     _pf(w)
     ev = _ev()
     rc = launch(tile)

@@ -593,3 +593,50 @@ def test_gemm16_geglu(M, K, N2):
     yr = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T + bias
     vr, gr = yr.chunk(2, dim=-1)
     check(ops.gemm_ln(x, wf16, bf16_, act=2, ln=st, colsum=cs16, tile=34), vr * F.gelu(gr), rel=8e-3, name="geglu16 ln-fold")
+
+
+G16_CONV_CASES = [
+    # B, H, W, Cin, Cout, stride, pad(top,left), upsample, out_hw   (UNet / VAE shapes whose output grid is an exact tile multiple)
+    (2, 32, 32, 1280, 1280, 1, (1, 1), False, None),
+    (2, 32, 32, 2560, 1280, 1, (1, 1), False, None),
+    (2, 64, 64, 640, 640, 1, (1, 1), False, None),
+    (2, 128, 128, 320, 320, 1, (1, 1), False, None),        # Cin % 128 != 0: only the one-K-group tile 34
+    (2, 128, 128, 320, 320, 2, (1, 1), False, None),        # UNet Downsample (openaimodel.py:196)
+    (1, 64, 64, 128, 160, 2, (0, 0), False, (32, 32)),      # VAE-style asymmetric padding (model.py:81-86)
+    (2, 16, 16, 640, 640, 1, (1, 1), True, None),           # Upsample nearest 2x folded (openaimodel.py:145)
+    (2, 32, 32, 128, 2560, 1, (1, 1), False, None),         # ZeroSFT gamma|beta conv (SUPIR_v0.py:79-87), K = 1152
+    (1, 16, 24, 256, 160, 1, (1, 1), False, None),          # non-square
+]
+
+
+@pytest.mark.parametrize("case", G16_CONV_CASES)
+@pytest.mark.parametrize("tile", [32, 33, 34, 35])
+def test_gemm16_conv3x3(case, tile):
+    """Implicit-GEMM 3x3 convolution on the 16x16x32 tiles: plain, and with bias + time-embedding row bias + SiLU + residual."""
+    B, H, W, Cin, Cout, stride, pad, up, out_hw = case
+    bm, bn = _G16_TILE[tile]
+    ks = 1 if tile == 34 else 2
+    x = rnd(B, H, W, Cin).to(BF)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
+    bias = rnd(Cout, seed=2)
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    xr = x.float().permute(0, 3, 1, 2)
+    if up:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    if out_hw is not None:
+        xr = F.pad(xr, (0, 1, 0, 1))
+        ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=0)
+    else:
+        ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=1)
+    OH, OW = ref.shape[2:]
+    if (B * OH * OW) % bm or Cout % bn or Cin % (64 * ks):
+        pytest.skip("not an exact fit for this tile")
+    ref = ref.permute(0, 2, 3, 1)
+    out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile)
+    check(out, ref, name=f"conv16 {case} tile{tile}")
+    assert torch.equal(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile))
+    rb = rnd(B, Cout, seed=4).to(BF)
+    res = rnd(B, OH, OW, Cout, seed=5).to(BF)
+    out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, rowbias=rb, residual=res, act=1, alpha=0.5,
+                      tile=tile)
+    check(out, 0.5 * F.silu(ref + rb.float()[:, None, None, :]) + res.float(), name="conv16 epilogue")
