@@ -75,6 +75,17 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
                        float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                        const float* ln_colsum, float ln_eps, void* stream);
 
+/* Fused q | k | v projection of a self-attention layer (sgm/modules/attention.py:213-219, 241-249: to_q, to_k, to_v on the
+ * same LayerNorm'ed tokens) in ONE launch: W = [Wq; Wk; Wv] ([N][K], N = 3 * inner).  Columns [0, n_split) (q | k) are written
+ * like supir_gemm_bf16_ln's bf16 output into Cqk [M][ldc]; columns [n_split, N) (v) are written TRANSPOSED per batch into
+ * Cvt [M / rows_per_batch][N - n_split][ldc_vt] -- the V^T layout supir_flash_attn_d64 reads.  LayerNorm fold as in
+ * supir_gemm_bf16_ln (ln_stats may be NULL).  256 x 160 tile of csrc/gemm16.hip: M % 256 == 0, N % 160 == 0, n_split % 160 == 0,
+ * K % 64 == 0, K >= 128, rows_per_batch % 4 == 0, ldc % 8 == 0, ldc_vt % 4 == 0; anything else -> SUPIR_ERR_SHAPE (the caller
+ * then issues the two separate projections). */
+int supir_gemm_bf16_qkv(const void* A, const void* W, void* Cqk, void* Cvt, int M, int N, int n_split, int K, int lda, int ldc,
+                        int ldc_vt, int rows_per_batch, const float* bias, const float* ln_stats, int ln_ld, int ln_slots,
+                        const float* ln_colsum, float ln_eps, void* stream);
+
 /* Reduce a producer's row-statistic partials [M][ld][2] to (mean, rstd) [M][2] over `dim` elements per row (fixed order).
  * Consumers then pass ln_slots = 0 and ln_stats = that [M][2] array: two floats per row instead of `slots` partials. */
 int supir_rowstats_finalize(const float* partials, float* mean_rstd, int M, int ld, int slots, int dim, float eps,

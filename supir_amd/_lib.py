@@ -36,6 +36,7 @@ SIGNATURES = {
     "supir_prefetch": [P, c_size_t, P, P],
     "supir_set_next_prefetch": [P, c_size_t],
     "supir_rowstats_finalize": [P, P, I, I, I, I, F, P],
+    "supir_gemm_bf16_qkv": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, F, P],
     "supir_gemm_bf16_ln": [P, P, P, I, I, I, I, I, P, P, I, I, I, I, F, I, P, I, P, I, I, P, F, P],
 }
 

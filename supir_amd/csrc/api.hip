@@ -82,6 +82,22 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
     return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
 }
 
+int supir_gemm_bf16_qkv(const void* A, const void* W, void* Cqk, void* Cvt, int M, int N, int n_split, int K, int lda, int ldc,
+                        int ldc_vt, int rows_per_batch, const float* bias, const float* ln_stats, int ln_ld, int ln_slots,
+                        const float* ln_colsum, float ln_eps, void* stream) {
+    if (!A || !W || !Cqk || !Cvt || rows_per_batch <= 0) return SUPIR_ERR_ARG;
+    if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = Cqk; a.C2 = Cvt;
+    a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldc2 = ldc_vt; a.n_split = n_split;
+    a.rows_per_batch = rows_per_batch;
+    a.alpha = 1.0f;
+    a.ln_stats = ln_stats; a.ln_ld = ln_ld; a.ln_slots = ln_slots; a.ln_colsum = ln_colsum; a.ln_eps = ln_eps;
+    take_prefetch(a);
+    return supir_gemm16_qkv_launch(a, (hipStream_t)stream);
+}
+
 int supir_rowstats_finalize(const float* partials, float* mean_rstd, int M, int ld, int slots, int dim, float eps,
                             void* stream) {
     if (!partials || !mean_rstd) return SUPIR_ERR_ARG;

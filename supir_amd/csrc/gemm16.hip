@@ -44,7 +44,10 @@ __device__ __forceinline__ void g16_wait_vmcnt() {
 // zero page for the halo / padding rows of the implicit-GEMM (3x3 convolution) loader
 __device__ __attribute__((aligned(256))) uint32_t g16_zero_page[64];
 
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false>
+// MIXED (fused q|k|v projection, supir_gemm_bf16_qkv): tile columns [0, n_split) take the normal epilogue into C, tile columns
+// [n_split, N) the transposed one into C2 (V^T, channel index n - n_split); decided per workgroup (tile_n), both main loops
+// (they differ in the MFMA operand order) are in the kernel.
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;                          // waves per K group
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, MIH = MI / KS;
     static_assert(NW * KS == 8 && (BM / 8) % NW == 0 && (NW & 1) == 0, "512 threads; A chunks divide over the waves");
     static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3), "tile / wave grid");
-    static_assert(!(CONV && TRANS), "the implicit-GEMM loader has no transposed epilogue");
+    static_assert(!(CONV && TRANS) && !(MIXED && (TRANS || CONV || KS != 1)), "the implicit-GEMM loader has no transposed epilogue");
     // epilogue LDS map (the rings are idle by then): [0, XCH) K-group exchange, then per-wave C staging, bias / column sums,
     // row-statistics scratch
     constexpr int XCH_HALF = KS == 2 ? NW * MIH * NI * 4 * 64 * 4 : 0;   // bytes one group sends
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
         else { tile_m = id / tiles_n; tile_n = id - tile_m * tiles_n; }
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bool tr = MIXED ? (n0 >= p.n_split) : TRANS;   // this workgroup's epilogue (wave-uniform)
 
     // ---- loader: wave w stages the 8-row chunks w, w+NW, w+2NW, ... of A and of W; lane -> row lane>>3, physical 16-B chunk lane&7.
     // NW is even, so the chunk ids of one wave all have the parity of w and the swizzle ((row >> 1) & 7 with row = 8*chunk + lane>>3)
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     // epilogue vectors of this tile's BN columns, fetched now (one element per thread of group 0), parked in LDS after the loop
     float pre_bias = 0.f, pre_cs = 0.f;
     if constexpr (!TRANS) {
-        if (kg == 0 && tid < BN) {
+        if (kg == 0 && tid < BN && !tr) {
             if (p.bias) pre_bias = p.bias[n0 + tid];
             if (p.ln_stats) pre_cs = p.ln_colsum[n0 + tid];
         }
@@ -245,9 +249,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     // one K step.  STAGE: also issue the global->LDS loads of tile kt + S - 1 (into the buffer step kt - 1 just finished reading),
     // spread over the two 32-wide K slices; INFLIGHT: younger stages that may stay outstanding across this step's barrier
     int buf = 0, sbuf = S - 1;   // ring positions of the tile being read / being staged (kept modulo S without a division)
-    auto kstep = [&](auto stage_c, auto inflight_c) {
+    auto kstep = [&](auto stage_c, auto inflight_c, auto trans_c) {
         constexpr bool STAGE = decltype(stage_c)::value;
         constexpr int INFLIGHT = decltype(inflight_c)::value;
+        constexpr bool TR = decltype(trans_c)::value;
         g16_wait_vmcnt<INFLIGHT * LOADS>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    if constexpr (TRANS)
+                    if constexpr (TR)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
                     else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
@@ -286,14 +291,22 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    for (int kt = 0; kt + S - 1 < nk; ++kt) kstep(T_{}, std::integral_constant<int, S - 2>{});
-    if constexpr (S == 3) kstep(F_{}, std::integral_constant<int, 1>{});
-    kstep(F_{}, std::integral_constant<int, 0>{});
+    auto main_loop = [&](auto trans_c) {
+        for (int kt = 0; kt + S - 1 < nk; ++kt) kstep(T_{}, std::integral_constant<int, S - 2>{}, trans_c);
+        if constexpr (S == 3) kstep(F_{}, std::integral_constant<int, 1>{}, trans_c);
+        kstep(F_{}, std::integral_constant<int, 0>{}, trans_c);
+    };
+    if constexpr (MIXED) {
+        if (tr) main_loop(T_{});
+        else main_loop(F_{});
+    } else {
+        main_loop(std::integral_constant<bool, TRANS>{});
+    }
 
     // ------------------------------------------------------------------ epilogue
     __syncthreads();   // every wave is done with its last fragment reads: the rings are scratch from here on
     if constexpr (!TRANS) {
-        if (kg == 0 && tid < BN) {
+        if (kg == 0 && tid < BN && !tr) {
             ((float*)(smem + OFF_BIAS))[tid] = pre_bias;
             ((float*)(smem + OFF_BIAS))[BN + tid] = pre_cs;
         }
@@ -355,9 +368,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     using K0_ = std::integral_constant<int, 0>;
     using K1_ = std::integral_constant<int, 1>;
 
-    if constexpr (TRANS) {
+    if constexpr (TRANS || MIXED) {
+      if (tr) {
         // D[i = token][j = channel]: lane owns channel l15 of fragment j, tokens 4*quad + r of fragment i -> 4 consecutive tokens
-        bf16_t* Cb = (bf16_t*)p.C;
+        bf16_t* Cb = (bf16_t*)(MIXED ? p.C2 : p.C);
+        const int ldc_t = MIXED ? p.ldc2 : p.ldc, n_base = MIXED ? p.n_split : 0, n_out_total = p.N - n_base;
         auto run = [&](auto kg_c) {
             constexpr int KG = decltype(kg_c)::value;
 #pragma unroll
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = p.alpha * (rs[r] * (acc[KG * MIH + h][j][r] - mu[r] * cs) + bz);
                     const u32x2 o = {f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3])};
-                    *(u32x2*)(Cb + ((size_t)b * p.N + n) * p.ldc + t) = o;
+                    *(u32x2*)(Cb + ((size_t)b * n_out_total + (n - n_base)) * ldc_t + t) = o;
                 }
             }
         };
@@ -387,7 +402,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
         else if constexpr (KS == 2) run(K1_{});
         prefetch_next();
         return;
-    } else {
+      }
+    }
+    if constexpr (!TRANS) {
         const float* s_bias = (const float*)(smem + OFF_BIAS);
         const float* s_cs = s_bias + BN;
         char* c_stage = smem + OFF_CST + bwave * C_STAGE;
@@ -528,14 +545,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false>
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false>
 static int launch_gemm16(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     const double a_bytes = CONV ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin : 2.0 * (double)a.M * a.K;
     supir_choose_xcd_grid(a, a.M / BM, a.N / BN, a_bytes, 2.0 * (double)a.N * a.K);
     constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // the ring(s) + the prefetch scratch row
     static_assert(smem <= 163840, "LDS");
-    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV>;
+    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
@@ -580,4 +597,12 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
         case 34: return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true>(a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false>(a, st);
         default: return t ? launch_gemm16<128, 80, 4, 1, 2, 3, true>(a, st) : launch_gemm16<128, 80, 4, 1, 2, 3, false>(a, st);
     }
+}
+
+// fused q|k|v projection on tile 34 (256 x 160): columns [0, n_split) -> C (normal epilogue), [n_split, N) -> C2 transposed
+int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st) {
+    if (a.M % 256 || a.N % 160 || a.n_split % 160 || a.n_split <= 0 || a.n_split >= a.N || a.K % 64 || (a.K >> 6) < 2) return SUPIR_ERR_SHAPE;
+    if (a.lda % 8 || a.ldc % 8 || (((size_t)a.C) & 15) || a.ldc2 % 4 || a.rows_per_batch % 4 || a.ln_slots > 32) return SUPIR_ERR_SHAPE;
+    if (a.act != 0 || a.out_mode != 0 || a.res || a.rowbias || a.rowstats_out || !a.C2) return SUPIR_ERR_ARG;
+    return launch_gemm16<256, 160, 8, 1, 1, 3, false, false, true>(a, st);
 }

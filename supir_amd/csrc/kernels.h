@@ -29,6 +29,9 @@ struct GemmArgs {
     // touches on its way out, so they are in the Infinity Cache / L2 instead of HBM when that launch streams them
     const char* pf_ptr;
     unsigned pf_lines;
+    // ---- fused q|k|v projection (supir_gemm_bf16_qkv): columns >= n_split go, transposed per batch, to C2 [batch][N - n_split][ldc2]
+    void* C2;
+    int ldc2, n_split;
 };
 
 struct AttnArgs {
@@ -68,6 +71,7 @@ void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes
 // gemm16.hip: tiles 32 (128 x 80) / 33 (128 x 160), v_mfma_f32_16x16x32_bf16, two K groups per workgroup
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv);
 int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv);
+int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st);
 int supir_attn_launch(const AttnArgs& a, hipStream_t st);
 int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, int Tpad, long lds_, long ldp, float scale,
                               hipStream_t st);

@@ -155,13 +155,16 @@ class BasicTransformerBlock(nn.Module):
             wqk = torch.cat([a1.to_q.weight.detach().float(), a1.to_k.weight.detach().float()], 0)
             qk = Wt.fold_layernorm(wqk, None, n1.weight, n1.bias)
             v = Wt.fold_layernorm(a1.to_v.weight, None, n1.weight, n1.bias)
+            # fused q|k|v (supir_gemm_bf16_qkv): the same folded matrices stacked [q; k; v]
+            qkv = (torch.cat([qk[0], v[0]], 0).contiguous(), torch.cat([qk[1], v[1]], 0).contiguous(),
+                   torch.cat([qk[2], v[2]], 0).contiguous())
             q2 = Wt.fold_layernorm(a2.to_q.weight, None, n2.weight, n2.bias)
             gw, gc, gb = Wt.fold_layernorm(ff.proj.weight, ff.proj.bias, n3.weight, n3.bias)
             gwi, gbi = Wt.interleave_geglu(gw, gb)
             _, gci = Wt.interleave_geglu(gw, gc)
             gw16, gb16 = Wt.interleave_geglu(gw, gb, 16)      # tile 34 (csrc/gemm16.hip) pairs value / gate per 16 rows
             _, gc16 = Wt.interleave_geglu(gw, gc, 16)
-            return dict(qk=qk, v=v, q2=q2, geglu=(gwi, gci, gbi), geglu16=(gw16, gc16, gb16))
+            return dict(qk=qk, v=v, q2=q2, qkv=qkv, geglu=(gwi, gci, gbi), geglu16=(gw16, gc16, gb16))
 
         return self._fold.get(srcs, build)
 
@@ -176,10 +179,22 @@ class BasicTransformerBlock(nn.Module):
         e1, e2, e3 = self.norm1.eps, self.norm2.eps, self.norm3.eps
         if FINALIZE_STATS:
             stats = ops.rowstats_finalize(stats, C, e1)
-        w, cs, b = f["qk"]
-        qk = ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e1)
-        w, cs, b = f["v"]
-        vt = ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e1, trans=(B, T, _pad64(T)))
+        def qkv_separate():
+            w, cs, b = f["qk"]
+            qk_ = ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e1)
+            w, cs, b = f["v"]
+            return qk_, ops.gemm_ln(x, w, b, ln=stats, colsum=cs, ln_eps=e1, trans=(B, T, _pad64(T)))
+
+        def qkv_fused():
+            w, cs, b = f["qkv"]
+            return ops.gemm_qkv(x, w, b, B, T, 2 * inner, ln=stats, colsum=cs, ln_eps=e1)
+
+        if T % 64 == 0 and ops.gemm_qkv_supported(B * T, 3 * inner, 2 * inner, C, T):
+            # one launch for q | k | v^T instead of two when it is faster for this shape (timed once, outside graph capture)
+            which = ops.choose(("qkv", B * T, 3 * inner, C), (qkv_separate, qkv_fused))
+            qk, vt = qkv_fused() if which == 1 else qkv_separate()
+        else:
+            qk, vt = qkv_separate()
         a = ops.flash_attn(qk[:, :, :inner], qk[:, :, inner:], vt, B, H, T, T)
         o1 = self.attn1.to_out[0]
         x, stats = ops.gemm_ln(a, o1.w(), o1.b32(), residual=x, out=x, emit_stats=True)

@@ -62,7 +62,7 @@ def finish_timing(trace):
 
 def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
     if tile is not None and tile >= 32:
-        nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3"}[tile]
+        nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv"}[tile]
         return f"gemm16_kernel<{nm}{',T' if trans else ''}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
@@ -409,6 +409,67 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
         bn, _ = _TILE_BN_WN[t_used]
         return out, RowStats(stats, (N + bn - 1) // bn, rs_ld)
     return out
+
+
+USE_QKV = _os.environ.get("SUPIR_FUSED_QKV", "1") != "0"
+
+
+def gemm_qkv_supported(M, N, n_split, K, T):
+    """Shape predicate of supir_gemm_bf16_qkv (256 x 160 tile of csrc/gemm16.hip)."""
+    return (USE_QKV and USE_GEMM16 and 34 in G16_TILES and M % 256 == 0 and N % 160 == 0 and n_split % 160 == 0 and 0 < n_split < N
+            and K % 64 == 0 and K >= 128 and T % 4 == 0)
+
+
+def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, out_qk=None, out_vt=None):
+    """Fused q | k | v projection: a [B*T, K] -> (qk [B, T, n_split] bf16, v^T [B, N - n_split, T] bf16) in one launch; optional
+    LayerNorm fold as in gemm_ln.  Callers check gemm_qkv_supported first."""
+    lib = _lib.load()
+    _check_dev(a, w)
+    M, K, lda = _rows_ld(a)
+    N = w.shape[0]
+    assert M == B * T and w.shape[1] == K and w.is_contiguous() and w.dtype == BF16 and a.dtype == BF16
+    if out_qk is None:
+        out_qk = torch.empty(B, T, n_split, dtype=BF16, device=a.device)
+    if out_vt is None:
+        out_vt = torch.empty(B, N - n_split, T, dtype=BF16, device=a.device)
+    ln_p, ln_ld, ln_slots = 0, 0, 0
+    if ln is not None:
+        ln_p, ln_ld, ln_slots = ln.buf.data_ptr(), ln.ld, ln.slots
+        assert colsum is not None and colsum.numel() == N
+    _pf(w)
+    ev = _ev()
+    rc = lib.supir_gemm_bf16_qkv(a.data_ptr(), w.data_ptr(), out_qk.data_ptr(), out_vt.data_ptr(), M, N, n_split, K, lda, n_split, T, T,
+                                 _p(bias), ln_p, ln_ld, ln_slots, _p(colsum), ln_eps, _stream())
+    _lib.check(rc, "supir_gemm_bf16_qkv")
+    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev, M=M, N=N, K=K, act=0, tile=36)
+    return out_qk, out_vt
+
+
+_CHOICE = {}
+
+
+def choose(key, fns):
+    """Time alternative implementations of the same step once (outside graph capture) and remember the faster one:
+    returns the index into `fns`.  Used where two launch sequences compute the same tensors (fused q|k|v vs two projections)."""
+    c = _CHOICE.get(key)
+    if c is not None:
+        return c
+    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return 0
+    times = []
+    for i, fn in enumerate(fns):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            fn()
+        e1.record()
+        e1.synchronize()
+        times.append((e0.elapsed_time(e1), i))
+    c = min(times)[1]
+    _CHOICE[key] = c
+    return c
 
 
 def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):

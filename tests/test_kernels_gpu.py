@@ -640,3 +640,32 @@ def test_gemm16_conv3x3(case, tile):
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, rowbias=rb, residual=res, act=1, alpha=0.5,
                       tile=tile)
     check(out, 0.5 * F.silu(ref + rb.float()[:, None, None, :]) + res.float(), name="conv16 epilogue")
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 1024, 1280), (2, 4096, 640), (1, 256, 320)])
+def test_gemm_qkv_fused(B, T, C):
+    """supir_gemm_bf16_qkv: q | k written normally, v transposed per batch, one launch; with and without the LayerNorm fold,
+    against the two separate projections and against fp32."""
+    from supir_amd.weights import fold_layernorm
+    M, inner = B * T, C
+    if not ops.gemm_qkv_supported(M, 3 * inner, 2 * inner, C, T):
+        pytest.skip("shape not supported by the fused kernel")
+    a = rnd(M, C).to(BF)
+    w = rnd(3 * inner, C, scale=C ** -0.5, seed=1).to(BF)
+    ref = a.float() @ w.float().T
+    qk, vt = ops.gemm_qkv(a, w, None, B, T, 2 * inner)
+    check(qk.view(M, 2 * inner), ref[:, :2 * inner], name="qkv: q|k")
+    check(vt, ref[:, 2 * inner:].view(B, T, inner).permute(0, 2, 1), name="qkv: v^T")
+    qk2, vt2 = ops.gemm_qkv(a, w, None, B, T, 2 * inner)
+    assert torch.equal(qk, qk2) and torch.equal(vt, vt2)
+    # LayerNorm fold
+    wp = rnd(C, C, scale=C ** -0.5, seed=5).to(BF)
+    x, st = ops.gemm_ln(a, wp, None, emit_stats=True)
+    gamma, beta = rnd(C, seed=6) * 0.2 + 1.0, rnd(C, seed=7) * 0.2
+    wf, cs, bf_ = fold_layernorm(w.float(), None, gamma, beta)
+    refn = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T
+    qk, vt = ops.gemm_qkv(x, wf, bf_, B, T, 2 * inner, ln=st, colsum=cs)
+    check(qk.view(M, 2 * inner), refn[:, :2 * inner], rel=6e-3, name="qkv ln: q|k")
+    check(vt, refn[:, 2 * inner:].view(B, T, inner).permute(0, 2, 1), rel=6e-3, name="qkv ln: v^T")
+    sep = ops.gemm_ln(x, wf[:2 * inner].contiguous(), bf_[:2 * inner].contiguous(), ln=st, colsum=cs[:2 * inner].contiguous())
+    check(qk.view(M, 2 * inner), sep.float(), rel=3e-3, name="qkv vs separate")

@@ -23,13 +23,15 @@ cond = {"crossattn": synth_tensor("ctx", (B, 77, 2048)).to(dev), "vector": synth
 t = torch.full((B,), 500, dtype=torch.int64, device=dev)
 
 
-VARIANTS = {"base": set(), "g32_33": {32, 33}, "g32_33_34": {32, 33, 34}, "g32_33_35": {32, 33, 35}, "gemm16": {32, 33, 34, 35}}
+VARIANTS = {"base": set(), "noqkv": {32, 33, 34, 35}, "g32_33": {32, 33}, "g32_33_34": {32, 33, 34}, "g32_33_35": {32, 33, 35}, "gemm16": {32, 33, 34, 35}}
 
 
 def configure(v):
     ops.G16_TILES = VARIANTS[v]
     ops.USE_GEMM16 = bool(VARIANTS[v])
+    ops.USE_QKV = v != "noqkv"
     ops._TUNE.clear()
+    ops._CHOICE.clear()
 
 
 res = {}
@@ -57,7 +59,7 @@ with torch.no_grad():
             for k, tl in ops._TUNE.items():
                 if k[0] == "gemm":
                     picks[str(k[1:])] = tl
-            print(f"rep{rep} {v}: {ms:.2f} ms/step; tiles {json.dumps(picks)}", flush=True)
+            print(f"rep{rep} {v}: {ms:.2f} ms/step; tiles {json.dumps(picks)} choices {ops._CHOICE}", flush=True)
     wrap.enable_graph(False)
 ref = outs[variants[0]]
 for v in variants[1:]:
