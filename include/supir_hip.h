@@ -7,7 +7,9 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
- *   - caller owns every buffer (including workspaces); the library allocates nothing and keeps no mutable state;
+ *   - caller owns every buffer (including workspaces); the library allocates nothing.  Its only mutable state is (a) the
+ *     per-thread one-shot request set by supir_set_next_prefetch and consumed by the next GEMM / conv launch of that thread,
+ *     (b) the per-thread last-HIP-error code read by supir_last_hip_error; results never depend on either;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and stream ordered, never synchronise;
  *   - return 0 on success, <0 on error (SUPIR_ERR_*); never throws;
  *   - "bf16" buffers are raw 16-bit bfloat16; activations are NHWC / token-major: element (b, y, x, c) of a

@@ -7,9 +7,14 @@ import torch
 import torch.distributed as dist
 
 
-def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",)):
+def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), payload_dtype=None):
     """Broadcast every floating parameter/buffer of `module` from rank `src`, coalesced into buckets (few large
-    collectives: xGMI rings are per-link bound, so size matters more than count). Returns the number of buckets sent."""
+    collectives: xGMI rings are per-link bound, so size matters more than count). Returns the number of buckets sent.
+
+    payload_dtype=torch.bfloat16: the fp32 masters travel as bf16 (7.9 GB instead of 15.9 GB for SDXL + control + VAE,
+    SURVEY.md 8(e)).  The kernels only ever read bf16 copies of the weights, so nothing the compute path sees changes; to keep
+    every rank's masters IDENTICAL (derived layouts such as LayerNorm-folded matrices are computed from the masters), rank
+    `src` rounds its own masters to the payload precision as well."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     tensors = [t for k, t in module.state_dict().items() if t.is_floating_point() and not any(k.endswith(s) for s in skip)]
@@ -17,15 +22,16 @@ def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",)):
     for t in tensors:
         groups.setdefault((t.dtype, t.device), []).append(t)
     sent = 0
-    for (_, _), ts in groups.items():
+    for (dt, _), ts in groups.items():
+        wire = payload_dtype if (payload_dtype is not None and dt == torch.float32) else dt
         bucket, size = [], 0
         for t in ts + [None]:
             if t is None or (bucket and size + t.numel() > bucket_elems):
-                flat = torch.cat([b.reshape(-1) for b in bucket])
+                flat = torch.cat([b.reshape(-1).to(wire) for b in bucket])
                 dist.broadcast(flat, src=src)
                 o = 0
                 with torch.no_grad():
-                    for b in bucket:
+                    for b in bucket:     # on rank src too: its masters become the rounded values every other rank receives
                         b.copy_(flat[o:o + b.numel()].view_as(b))
                         o += b.numel()
                 sent += 1

@@ -38,6 +38,11 @@ def ref_util():
     ref_import._install_stubs()
     if ref_import.REF_ROOT not in sys.path:
         sys.path.insert(0, ref_import.REF_ROOT)
+    # an earlier test may have called plugin.install() WITHOUT the reference on sys.path, which registers empty alias packages
+    # named sgm / SUPIR: drop those so that the real packages are imported (and patched in place) this time
+    for name in [n for n in sys.modules if n == "sgm" or n.startswith("sgm.") or n == "SUPIR" or n.startswith("SUPIR.")]:
+        if getattr(sys.modules[name], "__file__", None) is None:
+            del sys.modules[name]
     from supir_amd import plugin
     aliased = plugin.install()
     assert "SUPIR.models.SUPIR_model.SUPIRModel" in aliased

@@ -329,3 +329,40 @@ def test_graph_mode_runs_eagerly_when_control_scale_keeps_changing():
     assert w._resident[(tuple(c["crossattn"].shape), tuple(c["vector"].shape))][0] is c["crossattn"]
     w.enable_graph(False)
     assert w._cs_miss == {}
+
+
+def test_fp16_request_is_not_silently_served_by_bf16(monkeypatch):
+    """diff_dtype=fp16 (the reference's default, test.py:68) must not be silently computed in bf16: the wrapper
+    warns once (RuntimeWarning), raises under SUPIR_STRICT_DTYPE=1, and reports what it computes in."""
+    import warnings
+    from supir_amd.modules.wrappers import ControlWrapper
+
+    class Ctl(torch.nn.Module):
+        def forward(self, x, timesteps, xt, context=None, y=None, **kw):
+            return [xt + x]
+
+    class Net(torch.nn.Module):
+        def forward(self, x, timesteps=None, context=None, y=None, control=None, control_scale=1, **kw):
+            return x + control[0]
+
+    x, t = torch.ones(2, 4, 8, 8), torch.zeros(2, dtype=torch.int64)
+    c = {"crossattn": torch.zeros(2, 77, 8), "vector": torch.zeros(2, 16), "control": torch.ones(2, 4, 8, 8)}
+    w = ControlWrapper(Net(), dtype=torch.float16)
+    w.load_control_model(Ctl())
+    assert w.effective_dtype == torch.bfloat16
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        w(x, t, c)
+        w(x, t, c)
+    assert sum(issubclass(r.category, RuntimeWarning) and "float16" in str(r.message) for r in rec) == 1   # once
+    w2 = ControlWrapper(Net(), dtype=torch.bfloat16)
+    w2.load_control_model(Ctl())
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        w2(x, t, c)
+    assert not rec
+    monkeypatch.setenv("SUPIR_STRICT_DTYPE", "1")
+    w3 = ControlWrapper(Net(), dtype=torch.float16)
+    w3.load_control_model(Ctl())
+    with pytest.raises(RuntimeError, match="float16"):
+        w3(x, t, c)

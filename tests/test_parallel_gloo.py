@@ -34,6 +34,16 @@ def _worker(rank, world, port, q):
     ref = AutoencoderKLInferenceWrapper(embed_dim=4, ddconfig=dd, lossconfig={"target": "torch.nn.Identity"})
     fill_state_dict_(ref)
     same = all(torch.equal(a, b) for a, b in zip(vae.state_dict().values(), ref.state_dict().values()))
+    # bf16 payload (what bench.py uses: half the bytes over xGMI): every rank, rank 0 included, ends with the SAME bf16-rounded masters
+    vae2 = AutoencoderKLInferenceWrapper(embed_dim=4, ddconfig=dd, lossconfig={"target": "torch.nn.Identity"})
+    with torch.no_grad():
+        for p in vae2.parameters():
+            p.fill_(float(rank + 3))
+    if rank == 0:
+        fill_state_dict_(vae2)
+    parallel.broadcast_module_(vae2, src=0, bucket_elems=50_000, payload_dtype=torch.bfloat16)
+    same = same and all(torch.equal(a, b.to(torch.bfloat16).to(b.dtype)) and a.dtype == torch.float32
+                        for (k, a), b in zip(vae2.state_dict().items(), ref.state_dict().values()) if a.is_floating_point())
     mine = parallel.shard_items(5)
     t = parallel.max_over_ranks(1.0 + rank)
     imgs = parallel.gather_images({i: torch.full((3, 2, 2), float(i)) for i in mine}, 5)
