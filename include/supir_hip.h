@@ -35,6 +35,8 @@ extern "C" {
 #define SUPIR_ACT_NONE 0
 #define SUPIR_ACT_SILU 1
 #define SUPIR_ACT_GEGLU 2 /* W rows interleaved [32 value | 32 gate] per 64; output has N/2 columns */
+#define SUPIR_ACT_GELU 3  /* erf GELU (OpenCLIP text tower MLP) */
+#define SUPIR_ACT_QUICKGELU 4 /* x * sigmoid(1.702 x) (OpenAI CLIP text tower MLP) */
 
 /* output modes */
 #define SUPIR_OUT_BF16 0
@@ -116,6 +118,12 @@ int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int 
 int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
                          int ldk, int ldvt, int ldo, float scale, void* stream);
 
+/* supir_flash_attn_d64 with options.  flags bit 0: causal mask (key j visible to query i only for j <= i; Tq == Tk) -- the
+ * text towers of the conditioner (CLIP-L: transformers CLIPTextModel; OpenCLIP bigG: nn.MultiheadAttention with attn_mask;
+ * call sites sgm/modules/encoders/modules.py:487-489, 560-603). */
+int supir_flash_attn_d64_ex(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
+                            int ldk, int ldvt, int ldo, float scale, int flags, void* stream);
+
 /* P[r][:] = softmax(S[r][:] * scale): fp32 scores -> bf16 probabilities (VAE mid-block single-head attention,
  * sgm/modules/diffusionmodules/model.py:177-192, 228-256; the score matrix itself comes from supir_gemm_bf16).
  * Columns [T, Tpad) (K padding of the following P.V GEMM) are written as zeros. */
@@ -164,10 +172,22 @@ int supir_pointwise_nchw(const float* x, const float* w, const float* bias, floa
 /* One level of the colour-fix wavelet decomposition on fp32 planes [planes][H][W] (planes = N*3):
  *   low = depthwise 3x3 blur of img, kernel [[1,2,1],[2,4,2],[1,2,1]]/16, dilation `radius`, replicate padding;
  *   high = (first ? 0 : high) + (img - low).
- * img / low / high must be three distinct buffers.  Replaces the F.conv2d(F.pad(..., 'replicate'), groups=3, dilation=radius)
+ * img / low / high must be three distinct buffers; high may be NULL when only the low band is wanted (the style image).  Replaces the F.conv2d(F.pad(..., 'replicate'), groups=3, dilation=radius)
  * of wavelet_blur / wavelet_decomposition, SUPIR/utils/colorfix.py:73-107 (called from SUPIR_model.py:129-131). */
 int supir_wavelet_level(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
                         void* stream);
+
+/* One pass (vertical != 0: along y, else along x) of Pillow's 8-bit separable resampler -- what PIL.Image.resize(size, BICUBIC)
+ * does inside PIL2Tensor (SUPIR/util.py:60-83; arithmetic: third-party Pillow, src/libImaging/Resample.c).  src / dst_u8 are HWC
+ * uint8 with `channels` interleaved channels.  bounds [out][2] = (first input index, tap count), coeffs [out][ksize] = 22-bit
+ * fixed-point weights (host-built, supir_amd/utils/imageio.py); out = clip8((2^21 + sum pixel * coeff) >> 22): bit-exact.
+ * dst_f32 (optional, with lut[256]) receives lut[out] in CHW order -- the fp32 [-1, 1] tensor PIL2Tensor returns. */
+int supir_resample_u8(const void* src, void* dst_u8, float* dst_f32, const float* lut, const int* bounds, const int* coeffs, int ksize,
+                      int in_h, int in_w, int out_h, int out_w, int channels, int vertical, void* stream);
+
+/* Tensor2PIL (SUPIR/util.py:86-94): F.interpolate(x[C][H][W] fp32, size=(OH, OW), mode='bicubic') (A = -0.75, align_corners
+ * False, replicated border) -> out_f32 [C][OH][OW] and / or out_u8 [OH][OW][C] = uint8(clip(v * 127.5 + 127.5, 0, 255)). */
+int supir_bicubic_f32(const float* src, void* out_u8, float* out_f32, int C, int H, int W, int OH, int OW, void* stream);
 
 /* Touch one dword per 128-byte line of [p, p+bytes) (a weight matrix) so that it is in flight through the memory-side
  * cache before the kernel that consumes it starts; launched a few ops ahead on a separate stream. `sink`: any 4 writable

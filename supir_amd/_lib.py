@@ -24,6 +24,7 @@ SIGNATURES = {
     "supir_gemm_bf16": [P, P, P, I, I, I, I, I, P, P, I, I, P, I, I, I, F, I, P],
     "supir_conv3x3_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, I, I, I, F, I, P],
     "supir_flash_attn_d64": [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
+    "supir_flash_attn_d64_ex": [P, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
     "supir_softmax_rows": [P, P, I, I, I, L, L, F, P],
     "supir_groupnorm_nhwc": [P, P, P, P, I, I, I, I, I, I, P, P, F, I, P, P, I, F, P, I, P, c_size_t, P, P],
     "supir_groupnorm_stats": [P, P, I, I, I, I, I, I, P, P, c_size_t, P],
@@ -32,6 +33,8 @@ SIGNATURES = {
     "supir_conv3x3_smallcout": [P, P, P, P, I, I, I, I, I, I, P],
     "supir_pointwise_nchw": [P, P, P, P, I, I, I, L, F, P],
     "supir_wavelet_level": [P, P, P, I, I, I, I, I, P],
+    "supir_resample_u8": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "supir_bicubic_f32": [P, P, P, I, I, I, I, I, P],
     "supir_gemm_tile_for": [I, I, I],
     "supir_prefetch": [P, c_size_t, P, P],
     "supir_set_next_prefetch": [P, c_size_t],

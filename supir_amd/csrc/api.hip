@@ -41,7 +41,7 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 35) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 35) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
@@ -60,7 +60,7 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
                        float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                        const float* ln_colsum, float ln_eps, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 2 || out_mode < 0 || out_mode > 2 || tile > 35) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 35) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
     if (rowstats_out && (out_mode != 0 || act == 2 || rs_ld <= 0)) return SUPIR_ERR_ARG;
@@ -124,6 +124,18 @@ int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int 
     a.act = act; a.out_mode = out_mode; a.alpha = alpha;
     take_prefetch(a);
     return supir_gemm_launch(a, true, (hipStream_t)stream, tile);
+}
+
+int supir_flash_attn_d64_ex(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
+                            int ldk, int ldvt, int ldo, float scale, int flags, void* stream) {
+    if (!Q || !K || !Vt || !O || (flags & ~1)) return SUPIR_ERR_ARG;
+    if ((flags & 1) && Tq != Tk) return SUPIR_ERR_SHAPE;
+    AttnArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.Vt = (const bf16_t*)Vt; a.O = (bf16_t*)O;
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.causal = flags & 1;
+    return supir_attn_launch(a, (hipStream_t)stream);
 }
 
 int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
@@ -202,8 +214,20 @@ int supir_pointwise_nchw(const float* x, const float* w, const float* bias, floa
 
 int supir_wavelet_level(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
                         void* stream) {
-    if (!img || !low || !high) return SUPIR_ERR_ARG;
+    if (!img || !low) return SUPIR_ERR_ARG;   // high may be NULL: low band only
     return supir_wavelet_level_launch(img, low, high, planes, H, W, radius, first, (hipStream_t)stream);
+}
+
+int supir_resample_u8(const void* src, void* dst_u8, float* dst_f32, const float* lut, const int* bounds, const int* coeffs, int ksize,
+                      int in_h, int in_w, int out_h, int out_w, int channels, int vertical, void* stream) {
+    if (!src || !bounds || !coeffs) return SUPIR_ERR_ARG;
+    return supir_resample_u8_launch((const uint8_t*)src, (uint8_t*)dst_u8, dst_f32, lut, bounds, coeffs, ksize, in_h, in_w, out_h, out_w,
+                                    channels, vertical, (hipStream_t)stream);
+}
+
+int supir_bicubic_f32(const float* src, void* out_u8, float* out_f32, int C, int H, int W, int OH, int OW, void* stream) {
+    if (!src) return SUPIR_ERR_ARG;
+    return supir_bicubic_f32_launch(src, (uint8_t*)out_u8, out_f32, C, H, W, OH, OW, (hipStream_t)stream);
 }
 
 }  // extern "C"

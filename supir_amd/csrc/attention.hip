@@ -165,14 +165,15 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_kernel(const AttnArgs p) {
 #endif
         ATL(tl_d);
         // lane holds query l31, keys t*64 + kf*32 + 16*(r>>3) + 8*half + (r&7)
-        if (t == nt - 1 && (p.Tk & 63)) {
+        if ((t == nt - 1 && (p.Tk & 63)) || p.causal) {
             asm volatile("" ::: "memory");   // keep this a (wave-uniform) branch: if-converted it costs 32 v_cndmask per tile
+            const int klim = p.causal ? (q < p.Tk - 1 ? q : p.Tk - 1) : p.Tk - 1;   // last visible key of this lane's query
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * 64 + kf * 32 + 16 * (r >> 3) + 8 * half + (r & 7);
-                    if (key >= p.Tk) s[kf][r] = -INFINITY;
+                    if (key > klim) s[kf][r] = -INFINITY;
                 }
         }
         float mx = s[0][0];

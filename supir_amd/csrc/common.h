@@ -56,6 +56,8 @@ __device__ __forceinline__ float erf_as(float x) {
     const float y = 1.0f - pl * t * __expf(-ax * ax);
     return copysignf(y, x);
 }
+// QuickGELU x * sigmoid(1.702 x): the activation of OpenAI CLIP text towers (transformers CLIPTextModel "quick_gelu")
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

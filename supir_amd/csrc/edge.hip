@@ -256,14 +256,108 @@ __global__ __launch_bounds__(256) void wavelet_level_kernel(const float* __restr
     const float lo = 0.0625f * corners + 0.125f * edges + 0.25f * c;
     const size_t o = plane + (size_t)y * W + x;
     low[o] = lo;
-    high[o] = (first ? 0.f : high[o]) + (c - lo);
+    if (high) high[o] = (first ? 0.f : high[o]) + (c - lo);   // high == null: the caller only wants the low band (style image)
 }
 
 int supir_wavelet_level_launch(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
                                hipStream_t st) {
     if (planes <= 0 || H <= 0 || W <= 0 || radius <= 0 || planes > 65535 || H > 65535) return SUPIR_ERR_SHAPE;
-    if (img == low || img == high || low == high) return SUPIR_ERR_ARG;
+    if (img == low || (high && (img == high || low == high))) return SUPIR_ERR_ARG;
     SUPIR_LAUNCH(wavelet_level_kernel, dim3((W + 255) / 256, H, planes), dim3(256), 0, st, img, low, high, H, W, radius, first);
     return SUPIR_LAUNCH_STATUS();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Image I/O edges of test.py (SUPIR/util.py:60-94).
+//
+// PIL2Tensor resizes the input with PIL's Image.resize(BICUBIC): Pillow's separable resampler on 8-bit pixels with 22-bit
+// fixed-point coefficients (src/libImaging/Resample.c, third party: Pillow; the coefficient tables are rebuilt on the host in
+// float64 with Pillow's formulas, supir_amd/utils/imageio.py).  One pass (horizontal or vertical) per launch, bit-exact:
+//   acc = 1 << 21;  acc += pixel[xmin + i] * kk[i], i < n;  out = clip8(acc >> 22)
+// src / dst are HWC uint8 with `ch` interleaved channels.  The vertical pass can emit the final fp32 CHW tensor directly through
+// a 256-entry table (x / 255 * 2 - 1 evaluated on the host exactly as numpy does), so the resized uint8 image never exists.
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst_u8,
+                                                           float* __restrict__ dst_f32, const float* __restrict__ lut,
+                                                           const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                           int in_h, int in_w, int out_h, int out_w, int ch, int vertical) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= out_w) return;
+    const int o = vertical ? oy : ox;                       // index into the coefficient tables
+    const int xmin = bounds[2 * o], n = bounds[2 * o + 1];
+    const int* k = kk + (size_t)o * ksize;
+    for (int c = 0; c < ch; ++c) {
+        int acc = 1 << 21;
+        if (vertical) {
+            for (int i = 0; i < n; ++i) acc += (int)src[((size_t)(xmin + i) * in_w + ox) * ch + c] * k[i];
+        } else {
+            for (int i = 0; i < n; ++i) acc += (int)src[((size_t)oy * in_w + xmin + i) * ch + c] * k[i];
+        }
+        int v = acc >> 22;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        if (dst_u8) dst_u8[((size_t)oy * out_w + ox) * ch + c] = (uint8_t)v;
+        if (dst_f32) dst_f32[((size_t)c * out_h + oy) * out_w + ox] = lut[v];
+    }
+}
+
+int supir_resample_u8_launch(const uint8_t* src, uint8_t* dst_u8, float* dst_f32, const float* lut, const int* bounds, const int* kk,
+                             int ksize, int in_h, int in_w, int out_h, int out_w, int ch, int vertical, hipStream_t st) {
+    if (in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || ch <= 0 || ch > 4 || ksize <= 0 || out_h > 65535) return SUPIR_ERR_SHAPE;
+    if (!dst_u8 && !dst_f32) return SUPIR_ERR_ARG;
+    if (dst_f32 && !lut) return SUPIR_ERR_ARG;
+    if (vertical ? in_w != out_w : in_h != out_h) return SUPIR_ERR_SHAPE;
+    SUPIR_LAUNCH(resample_u8_kernel, dim3((out_w + 255) / 256, out_h), dim3(256), 0, st, src, dst_u8, dst_f32, lut, bounds, kk, ksize,
+                 in_h, in_w, out_h, out_w, ch, vertical);
+    return SUPIR_LAUNCH_STATUS();
+}
+
+// Tensor2PIL (SUPIR/util.py:86-94): F.interpolate(x, size, mode='bicubic') -- ATen's cubic convolution with A = -0.75,
+// align_corners = False, border pixels replicated -- then x * 127.5 + 127.5, clip to [0, 255], truncate to uint8, HWC.
+// fp32 planes [C][H][W] in; out_u8 [OH][OW][C] and / or out_f32 [C][OH][OW].
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ __launch_bounds__(256) void bicubic_f32_kernel(const float* __restrict__ src, uint8_t* __restrict__ out_u8,
+                                                           float* __restrict__ out_f32, int C, int H, int W, int OH, int OW,
+                                                           float scale_h, float scale_w) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= OW) return;
+    const float A = -0.75f;
+    const float ry = scale_h * (oy + 0.5f) - 0.5f, rx = scale_w * (ox + 0.5f) - 0.5f;
+    const float fy = floorf(ry), fx = floorf(rx);
+    const int iy = (int)fy, ix = (int)fx;
+    const float ty = ry - fy, tx = rx - fx;
+    const float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+    const float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+    int ys[4], xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int y = iy - 1 + i, x = ix - 1 + i;
+        ys[i] = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+        xs[i] = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+    }
+    for (int c = 0; c < C; ++c) {
+        const float* p = src + (size_t)c * H * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* r = p + (size_t)ys[i] * W;
+            const float row = r[xs[0]] * wx[0] + r[xs[1]] * wx[1] + r[xs[2]] * wx[2] + r[xs[3]] * wx[3];
+            acc += row * wy[i];
+        }
+        if (out_f32) out_f32[((size_t)c * OH + oy) * OW + ox] = acc;
+        if (out_u8) {
+            float v = acc * 127.5f + 127.5f;
+            v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+            out_u8[((size_t)oy * OW + ox) * C + c] = (uint8_t)v;   // truncation, like numpy's astype(uint8)
+        }
+    }
+}
+
+int supir_bicubic_f32_launch(const float* src, uint8_t* out_u8, float* out_f32, int C, int H, int W, int OH, int OW, hipStream_t st) {
+    if (C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || OH > 65535) return SUPIR_ERR_SHAPE;
+    if (!out_u8 && !out_f32) return SUPIR_ERR_ARG;
+    SUPIR_LAUNCH(bicubic_f32_kernel, dim3((OW + 255) / 256, OH), dim3(256), 0, st, src, out_u8, out_f32, C, H, W, OH, OW,
+                 (float)H / (float)OH, (float)W / (float)OW);
+    return SUPIR_LAUNCH_STATUS();
+}

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
                         for (int e = 0; e < 4; ++e) {
                             float t = rs * (acc[i][j][rg * 4 + e] - mu * cs[e]) + bz[e];
                             t += (e & 1) ? bfhi2f(rb[e >> 1]) : bflo2f(rb[e >> 1]);
-                            if constexpr (SILU) t = silu_f(t);
+                            if constexpr (SILU) t = p.act == 1 ? silu_f(t) : (p.act == 3 ? gelu_f(t) : quick_gelu_f(t));
                             t *= p.alpha;
                             t += (e & 1) ? bfhi2f(rr[e >> 1]) : bflo2f(rr[e >> 1]);
                             v[e] = t;
@@ -613,13 +613,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
         using M2_ = std::integral_constant<int, 2>;
         const bool via_lds = (p.ldc & 7) == 0 && (p.N & 7) == 0 && (((size_t)p.C) & 15) == 0;
         if (p.out_mode == 1) {
-            if (p.act == 1) epilogue(T_{}, M1_{});
+            if (p.act != 0) epilogue(T_{}, M1_{});
             else epilogue(F_{}, M1_{});
         } else if (via_lds) {
-            if (p.act == 1) epilogue(T_{}, M2_{});
+            if (p.act != 0) epilogue(T_{}, M2_{});
             else epilogue(F_{}, M2_{});
         } else {
-            if (p.act == 1) epilogue(T_{}, M0_{});
+            if (p.act != 0) epilogue(T_{}, M0_{});
             else epilogue(F_{}, M0_{});
         }
         if (p.rowstats_out) {

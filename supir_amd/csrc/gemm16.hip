@@ -487,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                     for (int e = 0; e < 4; ++e) {
                         float t = rs * (acc[KG * MIH + h][j][e] - mu * cs[e]) + bz[e];
                         t += (e & 1) ? bfhi2f(rb[e >> 1]) : bflo2f(rb[e >> 1]);
-                        if constexpr (SILU) t = silu_f(t);
+                        if constexpr (SILU) t = p.act == 1 ? silu_f(t) : (p.act == 3 ? gelu_f(t) : quick_gelu_f(t));
                         t *= p.alpha;
                         t += (e & 1) ? bfhi2f(rr[e >> 1]) : bflo2f(rr[e >> 1]);
                         v[e] = t;
@@ -519,10 +519,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
             }
         };
         if (kg == 0) {
-            if (p.act == 1) run(K0_{}, T_{});
+            if (p.act != 0) run(K0_{}, T_{});
             else run(K0_{}, F_{});
         } else if constexpr (KS == 2) {
-            if (p.act == 1) run(K1_{}, T_{});
+            if (p.act != 0) run(K1_{}, T_{});
             else run(K1_{}, F_{});
         }
         if constexpr (WN > 1) {

@@ -42,6 +42,7 @@ struct AttnArgs {
     int B, H, Tq, Tk;
     int ldq, ldk, ldvt, ldo;
     float scale_log2e;  // softmax scale * log2(e)
+    int causal;         // 1: key j is visible to query i only for j <= i (text towers of the conditioner); needs Tq == Tk
 };
 
 struct GnArgs {
@@ -88,3 +89,6 @@ int supir_pointwise_nchw_launch(const float* x, const float* w, const float* bia
 int supir_wavelet_level_launch(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
                                hipStream_t st);
 int supir_prefetch_launch(const void* p, size_t bytes, void* sink, hipStream_t st);
+int supir_resample_u8_launch(const uint8_t* src, uint8_t* dst_u8, float* dst_f32, const float* lut, const int* bounds, const int* kk,
+                             int ksize, int in_h, int in_w, int out_h, int out_w, int ch, int vertical, hipStream_t st);
+int supir_bicubic_f32_launch(const float* src, uint8_t* out_u8, float* out_f32, int C, int H, int W, int OH, int OW, hipStream_t st);

@@ -561,8 +561,9 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
 
 
 # --------------------------------------------------------------------------------------------- attention
-def flash_attn(q, k, vt, B, H, Tq, Tk, out=None):
-    """q [B,Tq,>=H*64] k [B,Tk,>=H*64] (views with row stride), vt [B,H*64,Tpad]; returns [B,Tq,H*64]."""
+def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
+    """q [B,Tq,>=H*64] k [B,Tk,>=H*64] (views with row stride), vt [B,H*64,Tpad]; returns [B,Tq,H*64].
+    causal=True (text towers): query i sees keys j <= i."""
     lib = _lib.load()
     _check_dev(q, k, vt)
     assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16
@@ -572,8 +573,12 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None):
     if out is None:
         out = torch.empty(B, Tq, H * 64, dtype=BF16, device=q.device)
     ev = _ev()
-    rc = lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
-                                  out.stride(-2), 0.125, _stream())
+    if causal:
+        rc = lib.supir_flash_attn_d64_ex(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
+                                         out.stride(-2), 0.125, 1, _stream())
+    else:
+        rc = lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
+                                      out.stride(-2), 0.125, _stream())
     _lib.check(rc, "supir_flash_attn_d64")
     _rec("attn", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * H * 64 * (2 * Tq + 2 * Tk), ev, B=B, H=H, Tq=Tq, Tk=Tk)
     return out
@@ -715,20 +720,20 @@ def pointwise_nchw(x, w, bias, in_scale=1.0):
     return out
 
 
-def wavelet_decomposition(img, levels=5):
+def wavelet_decomposition(img, levels=5, want_high=True):
     """(high, low) of SUPIR/utils/colorfix.py:96-107 on fp32 [N,3,H,W]: `levels` launches of supir_wavelet_level (radius 2^i),
-    ping-ponging two low-pass buffers; `high` accumulates img_i - low_i in place."""
+    ping-ponging two low-pass buffers; `high` accumulates img_i - low_i in place.  want_high=False skips the high band (the style
+    image of wavelet_reconstruction only contributes its low band): returns (None, low)."""
     lib = _lib.load()
     _check_dev(img)
     assert img.dtype == torch.float32 and img.dim() == 4
     cur = img.contiguous()
     N, C, H, W = cur.shape
-    high = torch.empty_like(cur)
+    high = torch.empty_like(cur) if want_high else None
     bufs = [torch.empty_like(cur), torch.empty_like(cur)]
     for i in range(levels):
         low = bufs[i & 1]
-        rc = lib.supir_wavelet_level(cur.data_ptr(), low.data_ptr(), high.data_ptr(), N * C, H, W, 2 ** i, int(i == 0),
-                                     _stream())
+        rc = lib.supir_wavelet_level(cur.data_ptr(), low.data_ptr(), _p(high), N * C, H, W, 2 ** i, int(i == 0), _stream())
         _lib.check(rc, "supir_wavelet_level")
         cur = low
     return high, cur

@@ -40,6 +40,14 @@ TARGET_MAP = {
     "sgm.modules.diffusionmodules.model.Decoder": "supir_amd.modules.vae.Decoder",
     "sgm.models.autoencoder.AutoencoderKL": "supir_amd.modules.vae.AutoencoderKL",
     "sgm.models.autoencoder.AutoencoderKLInferenceWrapper": "supir_amd.modules.vae.AutoencoderKLInferenceWrapper",
+    "sgm.modules.GeneralConditionerWithControl": "supir_amd.modules.conditioner.GeneralConditionerWithControl",
+    "sgm.modules.GeneralConditioner": "supir_amd.modules.conditioner.GeneralConditioner",
+    "sgm.modules.encoders.modules.GeneralConditionerWithControl": "supir_amd.modules.conditioner.GeneralConditionerWithControl",
+    "sgm.modules.encoders.modules.FrozenCLIPEmbedder": "supir_amd.modules.conditioner.FrozenCLIPEmbedder",
+    "sgm.modules.encoders.modules.FrozenOpenCLIPEmbedder2": "supir_amd.modules.conditioner.FrozenOpenCLIPEmbedder2",
+    "sgm.modules.encoders.modules.ConcatTimestepEmbedderND": "supir_amd.modules.conditioner.ConcatTimestepEmbedderND",
+    "SUPIR.util.PIL2Tensor": "supir_amd.utils.imageio.PIL2Tensor",
+    "SUPIR.util.Tensor2PIL": "supir_amd.utils.imageio.Tensor2PIL",
     "torch.nn.Identity": "torch.nn.Identity",
 }
 

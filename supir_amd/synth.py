@@ -30,7 +30,9 @@ _ZERO_INIT_MARKERS = (".out_layers.3.", ".proj_out.", ".zero_mul.", ".zero_add."
 # output projections of the other residual branches (attention to_out, feed-forward net.2): not zero-initialised by the
 # reference, but given the same modest gain so that a 70-block-deep random network is not chaotic in bf16 (with O(1)
 # branches the ATen-autocast bf16 path itself lands 23 % away from fp32 at full depth -- useless as a parity bar).
-_BRANCH_OUT_MARKERS = (".to_out.0.", ".ff.net.2.")
+_BRANCH_OUT_MARKERS = (".to_out.0.", ".ff.net.2.",
+                       # residual-branch outputs of the text towers (transformers CLIPTextModel / open_clip key names)
+                       ".self_attn.out_proj.", ".attn.out_proj.", ".mlp.fc2.", ".mlp.c_proj.")
 
 
 def _is_zero_init(key):

@@ -6,12 +6,14 @@ F.conv2d(F.pad(..., 'replicate'), groups=3, dilation=r) went through MIOpen's na
 from .. import ops
 
 
-def wavelet_decomposition(img, levels=5):
-    return ops.wavelet_decomposition(img.float(), levels)
+def wavelet_decomposition(img, levels=5, want_high=True):
+    return ops.wavelet_decomposition(img.float(), levels, want_high=want_high)
 
 
 def wavelet_reconstruction(content, style):
-    return wavelet_decomposition(content)[0] + wavelet_decomposition(style)[1]
+    """high frequencies of `content` + low frequencies of `style` (colorfix.py:109-119); the style image's high band is never
+    formed (the reference computes and discards it)."""
+    return wavelet_decomposition(content)[0] + wavelet_decomposition(style, want_high=False)[1]
 
 
 def adaptive_instance_normalization(content, style, eps=1e-5):

@@ -1,0 +1,183 @@
+"""Text conditioner (sgm/modules/encoders/modules.py:193-243, 445-609, 1027-1043).
+
+CPU tier: the oracle restatement (oracle/cond_oracle.py) is pinned against the real transformers.CLIPTextModel (the class the
+reference instantiates for CLIP-L) and, block-wise, against torch.nn.MultiheadAttention (what open_clip's ResidualAttentionBlock
+wraps; open_clip itself is not installed: parity unpinned for that package); state-dict keys of the product classes against the
+transformers / open_clip naming; the conditioner's key routing / concatenation.
+GPU tier: the HIP towers at full size (CLIP-L 12 x 768, bigG 32 x 1280) against the oracle on synthetic weights.
+"""
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import cond_oracle as CO
+from supir_amd.synth import synth_param
+
+
+def _tokens(n, seed=0, eot_pos=(20, 76)):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(1000, 40000, (n, 77), generator=g)
+    t[:, 0] = 49406
+    for i in range(n):
+        e = eot_pos[i % len(eot_pos)]
+        t[i, e] = 49407
+        t[i, e + 1:] = 0
+    return t
+
+
+def test_clip_l_restatement_vs_transformers_cliptextmodel():
+    from transformers import CLIPTextConfig, CLIPTextModel
+    cfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                         max_position_embeddings=77, hidden_act="quick_gelu")
+    torch.manual_seed(0)
+    hf = CLIPTextModel(cfg).eval()
+    sd = {}
+    for k, v in hf.state_dict().items():
+        k = k if k.startswith("text_model.") else "text_model." + k     # transformers >= 5 dropped the wrapper level
+        sd["transformer." + k] = v.float()
+    tok = _tokens(2)
+    tok_hf = tok.clone()
+    tok_hf[tok_hf == 0] = 49407      # HF pads with eot; hidden_states before the eot position do not depend on the padding (causal)
+    with torch.no_grad():
+        ref = hf(input_ids=tok_hf, output_hidden_states=True).hidden_states[11]
+        got = CO.clip_l_hidden(sd, tok_hf)
+    assert ((got - ref).norm() / ref.norm()).item() <= 2e-5
+    with torch.no_grad():
+        got0 = CO.clip_l_hidden(sd, tok)
+    assert torch.allclose(got0[0, :21], got[0, :21], atol=1e-5)       # causal: rows up to the eot are padding independent
+
+
+def test_openclip_block_restatement_vs_torch_multihead_attention():
+    d, heads, n = 128, 2, 77
+    torch.manual_seed(1)
+    mha = nn.MultiheadAttention(d, heads, batch_first=True)
+    ln1, ln2 = nn.LayerNorm(d), nn.LayerNorm(d)
+    fc, proj = nn.Linear(d, 4 * d), nn.Linear(4 * d, d)
+    sd = {"b.ln_1.weight": ln1.weight, "b.ln_1.bias": ln1.bias, "b.ln_2.weight": ln2.weight, "b.ln_2.bias": ln2.bias,
+          "b.attn.in_proj_weight": mha.in_proj_weight, "b.attn.in_proj_bias": mha.in_proj_bias,
+          "b.attn.out_proj.weight": mha.out_proj.weight, "b.attn.out_proj.bias": mha.out_proj.bias,
+          "b.mlp.c_fc.weight": fc.weight, "b.mlp.c_fc.bias": fc.bias, "b.mlp.c_proj.weight": proj.weight, "b.mlp.c_proj.bias": proj.bias}
+    x = torch.randn(2, n, d)
+    mask = CO.causal_mask(n, "cpu")
+    with torch.no_grad():
+        h = ln1(x)
+        y = x + mha(h, h, h, need_weights=False, attn_mask=mask)[0]
+        ref = y + proj(torch.nn.functional.gelu(fc(ln2(y))))
+        got = CO.openclip_block({k: v.detach() for k, v in sd.items()}, "b.", x, heads)
+    assert ((got - ref).norm() / ref.norm()).item() <= 2e-5
+
+
+def test_product_state_dict_keys_follow_transformers_and_open_clip():
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from supir_amd.modules import conditioner as C
+    with torch.device("meta"):
+        ours = C.FrozenCLIPEmbedder(layer="hidden", layer_idx=11)
+        hf = CLIPTextModel(CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                          num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu"))
+        g = C.FrozenOpenCLIPEmbedder2(arch="ViT-bigG-14", layer="penultimate", always_return_pooled=True, legacy=False)
+    want = {("transformer." + (k if k.startswith("text_model.") else "text_model." + k)): tuple(v.shape) for k, v in hf.state_dict().items()}
+    assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == want
+    gk = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+    assert gk["model.positional_embedding"] == (77, 1280) and gk["model.text_projection"] == (1280, 1280)
+    assert gk["model.token_embedding.weight"] == (49408, 1280) and gk["model.ln_final.weight"] == (1280,)
+    for i in (0, 31):
+        p = f"model.transformer.resblocks.{i}."
+        assert gk[p + "attn.in_proj_weight"] == (3840, 1280) and gk[p + "attn.out_proj.weight"] == (1280, 1280)
+        assert gk[p + "mlp.c_fc.weight"] == (5120, 1280) and gk[p + "mlp.c_proj.weight"] == (1280, 5120)
+        assert gk[p + "ln_1.weight"] == gk[p + "ln_2.bias"] == (1280,)
+    assert len(gk) == 4 + 2 + 32 * 12          # open_clip's text-side key count for ViT-bigG-14 (visual tower deleted, modules.py:538)
+
+
+def test_conditioner_routing_concat_and_control_passthrough():
+    """GeneralConditionerWithControl: 3-D outputs concatenate on dim 2 into crossattn, 2-D on dim 1 into vector, tuple outputs are
+    routed element-wise, force_zero_embeddings zeroes by input key, `control` is passed through (modules.py:193-243)."""
+    from supir_amd.modules import conditioner as C
+
+    class A(C.AbstractEmbModel):
+        def forward(self, txt):
+            return torch.ones(len(txt), 77, 3)
+
+    class B(C.AbstractEmbModel):
+        def forward(self, txt):
+            return torch.full((len(txt), 77, 5), 2.0), torch.full((len(txt), 7), 3.0)
+
+    C._test_A, C._test_B = A, B
+    cfgs = [{"target": "supir_amd.modules.conditioner._test_A", "input_key": "txt"},
+            {"target": "supir_amd.modules.conditioner._test_B", "input_key": "txt"},
+            {"target": "supir_amd.modules.conditioner.ConcatTimestepEmbedderND", "params": {"outdim": 256},
+             "input_key": "original_size_as_tuple"}]
+    cond = C.GeneralConditionerWithControl(cfgs)
+    batch = {"txt": ["a", "b"], "original_size_as_tuple": torch.tensor([[1024, 1024], [512, 768]]), "control": torch.zeros(2, 4, 8, 8)}
+    out = cond(batch)
+    assert out["crossattn"].shape == (2, 77, 8) and out["vector"].shape == (2, 7 + 512) and out["control"] is batch["control"]
+    assert torch.equal(out["vector"][:, 7:], CO.concat_timestep_embedder_nd(batch["original_size_as_tuple"]))
+    c, uc = cond.get_unconditional_conditioning(batch, dict(batch, txt=["", ""]), force_uc_zero_embeddings=["txt"])
+    assert c["crossattn"].abs().sum() > 0 and uc["crossattn"].abs().sum() == 0 and uc["vector"][:, :7].abs().sum() == 0
+    assert uc["vector"][:, 7:].abs().sum() > 0
+
+
+def _fill(module, prefix, dev):
+    with torch.no_grad():
+        for k, t in module.state_dict().items():
+            if t.is_floating_point():
+                t.copy_(synth_param(prefix + k, t.shape, device=dev))
+    return module
+
+
+@pytest.mark.gpu
+def test_text_towers_on_gpu_vs_oracle():
+    from supir_amd.modules import conditioner as C
+    dev = "cuda"
+    tok = _tokens(2, seed=3)
+    with torch.device(dev):
+        cl = C.FrozenCLIPEmbedder(layer="hidden", layer_idx=11)
+        g = C.FrozenOpenCLIPEmbedder2(arch="ViT-bigG-14", layer="penultimate", always_return_pooled=True, legacy=False)
+    _fill(cl, "conditioner.embedders.0.", dev)
+    _fill(g, "conditioner.embedders.1.", dev)
+    with torch.no_grad():
+        z = cl(tok)
+        pen, pooled = g(tok)
+        ref_z = CO.clip_l_hidden(cl.state_dict(), tok.to(dev), p="transformer.text_model.")
+        ref_pen, ref_pool = CO.openclip_g_penultimate_pooled(g.state_dict(), tok.to(dev), p="model.")
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    e = dict(clip_l_hidden11=rel(z, ref_z), bigg_penultimate=rel(pen, ref_pen), bigg_pooled=rel(pooled, ref_pool))
+    print("[parity] text towers:", {k: f"{v:.3e}" for k, v in e.items()})
+    assert z.shape == (2, 77, 768) and pen.shape == (2, 77, 1280) and pooled.shape == (2, 1280)
+    assert e["clip_l_hidden11"] <= 1.5e-2 and e["bigg_penultimate"] <= 2e-2 and e["bigg_pooled"] <= 2.5e-2
+    # causal mask: changing tokens AFTER position p leaves rows <= p unchanged bit for bit
+    tok2 = tok.clone()
+    tok2[:, 40:] = torch.randint(1000, 40000, (2, 37))
+    with torch.no_grad():
+        z2 = cl(tok2)
+    assert torch.equal(z[:, :40], z2[:, :40]) and not torch.equal(z[:, 40:], z2[:, 40:])
+
+
+@pytest.mark.gpu
+def test_general_conditioner_with_control_on_gpu_vs_oracle():
+    """The embedder list of options/SUPIR_v0.yaml:66-106 through the plugin: crossattn [N,77,2048], vector [N,2816], control."""
+    from supir_amd.plugin import instantiate_from_config
+    dev = "cuda"
+    P = "sgm.modules.encoders.modules."
+    cfg = {"target": "sgm.modules.GeneralConditionerWithControl", "params": {"emb_models": [
+        {"is_trainable": False, "input_key": "txt", "target": P + "FrozenCLIPEmbedder", "params": {"layer": "hidden", "layer_idx": 11}},
+        {"is_trainable": False, "input_key": "txt", "target": P + "FrozenOpenCLIPEmbedder2",
+         "params": {"arch": "ViT-bigG-14", "version": "laion2b_s39b_b160k", "freeze": True, "layer": "penultimate",
+                    "always_return_pooled": True, "legacy": False}},
+        {"is_trainable": False, "input_key": "original_size_as_tuple", "target": P + "ConcatTimestepEmbedderND", "params": {"outdim": 256}},
+        {"is_trainable": False, "input_key": "crop_coords_top_left", "target": P + "ConcatTimestepEmbedderND", "params": {"outdim": 256}},
+        {"is_trainable": False, "input_key": "target_size_as_tuple", "target": P + "ConcatTimestepEmbedderND", "params": {"outdim": 256}}]}}
+    with torch.device(dev):
+        cond = instantiate_from_config(cfg)
+    _fill(cond, "conditioner.", dev)
+    tok = _tokens(2, seed=5)
+    z4 = torch.zeros(2, 4, 16, 16, device=dev)
+    batch = {"txt": tok, "original_size_as_tuple": torch.tensor([1024, 1024]).repeat(2, 1).to(dev),
+             "crop_coords_top_left": torch.tensor([0, 0]).repeat(2, 1).to(dev),
+             "target_size_as_tuple": torch.tensor([1024, 1024]).repeat(2, 1).to(dev), "control": z4}
+    with torch.no_grad():
+        c, uc = cond.get_unconditional_conditioning(batch, dict(batch, txt=_tokens(2, seed=6)))
+        ref = CO.general_conditioner_with_control(cond.state_dict(), batch, tok.to(dev), tok.to(dev))
+    assert c["crossattn"].shape == (2, 77, 2048) and c["vector"].shape == (2, 2816) and c["control"] is z4
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    assert rel(c["crossattn"], ref["crossattn"]) <= 2e-2 and rel(c["vector"], ref["vector"]) <= 2e-2
+    assert not torch.equal(c["crossattn"], uc["crossattn"])

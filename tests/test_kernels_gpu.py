@@ -423,6 +423,9 @@ def test_wavelet_decomposition(shape):
         assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
     # reconstruction identity of the decomposition itself: high + low == img
     assert (high + low - x).abs().max().item() <= 1e-5
+    # low band only (the style image of wavelet_reconstruction): same low, no high buffer
+    h2, l2 = ops.wavelet_decomposition(x, want_high=False)
+    assert h2 is None and torch.equal(l2, low)
 
 
 def test_wavelet_reconstruction_vs_reference_golden():
@@ -441,7 +444,8 @@ def test_wavelet_level_rejects_aliased_buffers():
     b = torch.empty_like(a)
     assert lib.supir_wavelet_level(a.data_ptr(), a.data_ptr(), b.data_ptr(), 3, 8, 8, 1, 1, None) != 0
     assert lib.supir_wavelet_level(a.data_ptr(), b.data_ptr(), b.data_ptr(), 3, 8, 8, 1, 1, None) != 0
-    assert lib.supir_wavelet_level(a.data_ptr(), b.data_ptr(), None, 3, 8, 8, 1, 1, None) != 0
+    assert lib.supir_wavelet_level(a.data_ptr(), b.data_ptr(), None, 3, 8, 8, 1, 1, None) == 0   # high = NULL: low band only
+    assert lib.supir_wavelet_level(a.data_ptr(), None, None, 3, 8, 8, 1, 1, None) != 0
 
 
 @pytest.mark.skipif(__import__("os").environ.get("SUPIR_TEST_EXPERIMENTAL") != "1",
@@ -669,3 +673,31 @@ def test_gemm_qkv_fused(B, T, C):
     check(vt, refn[:, 2 * inner:].view(B, T, inner).permute(0, 2, 1), rel=6e-3, name="qkv ln: v^T")
     sep = ops.gemm_ln(x, wf[:2 * inner].contiguous(), bf_[:2 * inner].contiguous(), ln=st, colsum=cs[:2 * inner].contiguous())
     check(qk.view(M, 2 * inner), sep.float(), rel=3e-3, name="qkv vs separate")
+
+
+@pytest.mark.parametrize("tile", [-1, 3, 32])
+def test_gemm_gelu_and_quick_gelu_epilogues(tile):
+    """act 3 (erf GELU: OpenCLIP text tower MLP) and act 4 (QuickGELU x * sigmoid(1.702 x): OpenAI CLIP text tower MLP)."""
+    M, N, K = (256, 320, 256) if tile == 32 else (154, 3072, 768)
+    a = rnd(M, K).to(BF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N, seed=2)
+    y = a.float() @ w.float().T + bias
+    check(ops.gemm(a, w, bias, act=3, tile=tile), F.gelu(y), name="gelu")
+    check(ops.gemm(a, w, bias, act=4, tile=tile), y * torch.sigmoid(1.702 * y), name="quick_gelu")
+
+
+@pytest.mark.parametrize("B,H,T", [(2, 12, 77), (1, 20, 77), (2, 4, 200), (1, 2, 1024)])
+def test_flash_attn_causal(B, H, T):
+    """supir_flash_attn_d64_ex flags bit 0: causal mask (text towers), against SDPA(is_causal=True)."""
+    C = H * 64
+    q, k, v = rnd(B, T, C).to(BF), rnd(B, T, C, seed=1).to(BF), rnd(B, T, C, seed=2).to(BF)
+    Tp = (T + 63) // 64 * 64
+    vt = torch.zeros(B, C, Tp, dtype=BF, device=DEV)
+    vt[:, :, :T] = v.permute(0, 2, 1)
+    out = ops.flash_attn(q, k, vt, B, H, T, T, causal=True)
+    sp = lambda t: t.float().view(B, T, H, 64).permute(0, 2, 1, 3)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v), is_causal=True).permute(0, 2, 1, 3).reshape(B, T, C)
+    check(out, ref, rel=6e-3, name="causal attention")
+    # the first query only sees the first key: its output row is exactly v[0]
+    assert torch.equal(out[:, 0], v[:, 0])
