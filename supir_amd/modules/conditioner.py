@@ -61,6 +61,14 @@ def _run_block(x, ln1, w_qk, b_qk, w_v, b_v, out, ln2, fc1, fc2, heads, act):
     return ops.gemm(h, fc2.w(), fc2.b32(), residual=x)
 
 
+class _Table(nn.Module):
+    """nn.Embedding's parameter (`weight` [rows, dim]) without its random initialisation: real use loads a checkpoint."""
+
+    def __init__(self, rows, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(rows, dim), requires_grad=False)
+
+
 class AbstractEmbModel(nn.Module):
     def __init__(self):
         super().__init__()
@@ -100,8 +108,8 @@ class _HFLayer(nn.Module):
 class _HFEmbeddings(nn.Module):
     def __init__(self, vocab, d, n_pos):
         super().__init__()
-        self.token_embedding = nn.Embedding(vocab, d)
-        self.position_embedding = nn.Embedding(n_pos, d)
+        self.token_embedding = _Table(vocab, d)
+        self.position_embedding = _Table(n_pos, d)
         self.register_buffer("position_ids", torch.arange(n_pos).unsqueeze(0), persistent=False)
 
 
@@ -204,7 +212,7 @@ class _OCTransformer(nn.Module):
 class _OCModel(nn.Module):
     def __init__(self, vocab, d, inner, layers, out_dim, n_pos=77):
         super().__init__()
-        self.token_embedding = nn.Embedding(vocab, d)
+        self.token_embedding = _Table(vocab, d)
         self.positional_embedding = nn.Parameter(torch.empty(n_pos, d), requires_grad=False)
         self.transformer = _OCTransformer(d, inner, layers)
         self.ln_final = Norm(d, 1e-5)

@@ -733,7 +733,9 @@ def wavelet_decomposition(img, levels=5, want_high=True):
     bufs = [torch.empty_like(cur), torch.empty_like(cur)]
     for i in range(levels):
         low = bufs[i & 1]
+        ev = _ev()
         rc = lib.supir_wavelet_level(cur.data_ptr(), low.data_ptr(), _p(high), N * C, H, W, 2 ** i, int(i == 0), _stream())
         _lib.check(rc, "supir_wavelet_level")
+        _rec("wavelet_level", 0, 4.0 * N * C * H * W * (2 + (2 if (want_high and i) else 1 if want_high else 0)), ev)
         cur = low
     return high, cur

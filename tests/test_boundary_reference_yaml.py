@@ -2,7 +2,9 @@
 (/root/reference/SUPIR/util.py:34-51: OmegaConf.load -> instantiate_from_config(config.model) -> load_state_dict(strict=False))
 -- run on the reference's real `options/SUPIR_v0.yaml` and `options/SUPIR_v0_tiled.yaml` after `supir_amd.plugin.install()`
 must build THIS package's classes, accept reference-keyed state dicts, and expose the attribute protocol test.py uses
-(test.py:62-68).  Only the text conditioner is stubbed (CLIP weights are not available).
+(test.py:62-68).  The YAML is used as is, text conditioner included (sgm.modules.GeneralConditionerWithControl with the CLIP-L /
+OpenCLIP-bigG embedders resolves to supir_amd.modules.conditioner); one parametrisation swaps in a stub conditioner to show
+that a user-supplied conditioner object still plugs in.
 
 CPU tier; needs the reference checkout (present in the build container, absent on the GPU box -> skipped there).  The pip
 packages the reference imports but this image lacks (omegaconf, cv2, ...) come from the oracle's inert import stubs: test
@@ -51,8 +53,8 @@ def ref_util():
     return ref_util_mod
 
 
-def _yaml_without_checkpoints(tmp_path, name):
-    """The reference YAML, byte for byte, except: checkpoint paths -> null (no weights here) and the conditioner target -> stub."""
+def _yaml_without_checkpoints(tmp_path, name, stub_conditioner=False):
+    """The reference YAML, byte for byte, except: checkpoint paths -> null (no weights here) [and the conditioner target -> stub]."""
     import yaml
     src = os.path.join(ref_import.REF_ROOT, "options", name)
     cfg = yaml.safe_load(open(src))
@@ -61,7 +63,8 @@ def _yaml_without_checkpoints(tmp_path, name):
         cfg[k] = None
     cond = cfg["model"]["params"]["conditioner_config"]
     assert cond["target"] == "sgm.modules.GeneralConditionerWithControl"
-    cond["target"] = "tests.test_boundary_reference_yaml.StubConditioner"
+    if stub_conditioner:
+        cond["target"] = "tests.test_boundary_reference_yaml.StubConditioner"
     out = tmp_path / name
     yaml.safe_dump(cfg, open(out, "w"))
     return str(out), cfg
@@ -85,7 +88,12 @@ def test_create_supir_model_from_reference_yaml_builds_this_package(ref_util, tm
     assert type(model.sampler).__name__ == sampler and type(model.sampler).__module__ == S.__name__
     if sampler.startswith("Tiled"):
         assert model.sampler.tile_size == 128 and model.sampler.tile_stride == 64
-    assert isinstance(model.conditioner, StubConditioner) and model.conditioner.n_embedders == 5
+    import supir_amd.modules.conditioner as CD
+    assert type(model.conditioner) is CD.GeneralConditionerWithControl and len(model.conditioner.embedders) == 5
+    assert type(model.conditioner.embedders[0]) is CD.FrozenCLIPEmbedder and model.conditioner.embedders[0].layer_idx == 11
+    assert type(model.conditioner.embedders[1]) is CD.FrozenOpenCLIPEmbedder2 and model.conditioner.embedders[1].heads == 20
+    assert [e.input_key for e in model.conditioner.embedders] == ["txt", "txt", "original_size_as_tuple", "crop_coords_top_left",
+                                                                  "target_size_as_tuple"]
     # YAML params arrived: dtypes, scale factor (options/SUPIR_v0.yaml:4-6)
     assert model.ae_dtype == torch.bfloat16 and model.model.dtype == torch.float16 and model.scale_factor == 0.13025
     for p in model.parameters():
@@ -103,9 +111,14 @@ def test_create_supir_model_from_reference_yaml_builds_this_package(ref_util, tm
     for k in keys:
         assert k in own, k
         sd[k] = torch.randn(own[k].shape, generator=g)
-    sd["conditioner.embedders.0.transformer.text_model.final_layer_norm.weight"] = torch.zeros(768)   # not on our path
+    keys += ["conditioner.embedders.0.transformer.text_model.final_layer_norm.weight",
+             "conditioner.embedders.1.model.transformer.resblocks.31.attn.in_proj_weight", "conditioner.embedders.1.model.text_projection"]
+    for k in keys[-3:]:
+        assert k in own, k
+        sd[k] = torch.randn(own[k].shape, generator=g)
+    sd["conditioner.embedders.0.transformer.text_model.embeddings.position_ids"] = torch.arange(77)[None]   # older transformers saved it
     res = model.load_state_dict(sd, strict=False)
-    assert res.unexpected_keys == ["conditioner.embedders.0.transformer.text_model.final_layer_norm.weight"]
+    assert res.unexpected_keys == ["conditioner.embedders.0.transformer.text_model.embeddings.position_ids"]
     after = model.state_dict()
     for k in keys:
         assert torch.equal(after[k], sd[k]), k
@@ -118,8 +131,10 @@ def test_create_supir_model_from_reference_yaml_builds_this_package(ref_util, tm
 
 
 def test_reference_default_setting_block_is_served(ref_util, tmp_path):
-    """create_SUPIR_model(..., load_default_setting=True) (SUPIR/util.py:48-50) returns the YAML's default_setting untouched."""
-    path, cfg = _yaml_without_checkpoints(tmp_path, "SUPIR_v0.yaml")
+    """create_SUPIR_model(..., load_default_setting=True) (SUPIR/util.py:48-50) returns the YAML's default_setting untouched; a
+    user-supplied conditioner target (here a stub) still plugs in through the same `target:` mechanism."""
+    path, cfg = _yaml_without_checkpoints(tmp_path, "SUPIR_v0.yaml", stub_conditioner=True)
     with ref_import.quiet():
         model, default = ref_util.create_SUPIR_model(path, load_default_setting=True)
     assert default["edm_steps"] == 50 and default["s_cfg_Quality"] == 7.5
+    assert isinstance(model.conditioner, StubConditioner) and model.conditioner.n_embedders == 5

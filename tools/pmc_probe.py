@@ -1,28 +1,57 @@
-"""Tiny driver for rocprofv3 --pmc passes: a handful of launches of the hot kernels at production shapes."""
-import os, sys
+"""Tiny driver for rocprofv3 --pmc passes: a handful of launches of the hot kernels at production shapes (round 2: the
+16x16x32-MFMA tile family of csrc/gemm16.hip, the implicit-GEMM convs on it, attention, GroupNorm).  Each case is tagged by its
+grid size in the counter CSV; tools/pmc_summarize.py maps (kernel name, grid) back to the case."""
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
 from supir_amd import ops
+from supir_amd.weights import interleave_geglu
+
 BF = torch.bfloat16
 dev = "cuda"
-which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
 torch.manual_seed(0)
-if which == "gemm":
-    for (M, N, K, tile) in [(2048, 1280, 1280, 3), (2048, 1280, 1280, 1), (2048, 10240, 1280, 0), (2048, 1280, 5120, 3),
-                            (8192, 640, 2560, 0)]:
-        a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
-        for _ in range(3):
-            ops.gemm(a, w, None, tile=tile)
-elif which == "conv":
-    for (B, H, W, Cin, Cout, tile) in [(2, 32, 32, 1280, 1280, 1), (2, 64, 64, 640, 640, 0), (2, 128, 128, 320, 320, 0)]:
-        x = torch.randn(B, H, W, Cin, device=dev).to(BF); w = (torch.randn(Cout, 3, 3, Cin, device=dev) * (9 * Cin) ** -0.5).to(BF)
-        for _ in range(3):
-            ops.conv3x3(x, w, None, tile=tile)
-elif which == "attn":
-    for (B, H, Tq, Tk) in [(2, 20, 1024, 1024), (2, 10, 4096, 4096)]:
-        C = H * 64
-        q = torch.randn(B, Tq, C, device=dev).to(BF); k = torch.randn(B, Tk, C, device=dev).to(BF)
-        vt = torch.randn(B, C, Tk, device=dev).to(BF)
-        for _ in range(3):
-            ops.flash_attn(q, k, vt, B, H, Tq, Tk)
+cases = []
+
+
+def note(kind, shape, flops, bytes_, tile):
+    cases.append(dict(kind=kind, shape=shape, flops=flops, algorithmic_bytes=bytes_, tile=tile))
+
+
+# GEGLU projection on tile 34 (the dominant kernel of the step), N = 1280 GEMMs on tile 35, q|k on tile 33
+M, K, N2 = 2048, 1280, 10240
+a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N2, K, device=dev) * K ** -0.5).to(BF); b = torch.randn(N2, device=dev)
+w16, b16 = interleave_geglu(w, b, 16)
+for _ in range(3):
+    ops.gemm(a, w16, b16, act=2, tile=34)
+note("gemm_geglu", f"M{M} N{N2} K{K}", 2.0 * M * N2 * K, 2.0 * (M * K + N2 * K + M * N2 // 2), 34)
+for (M, N, K, tile) in [(2048, 1280, 1280, 35), (2048, 1280, 5120, 35), (2048, 2560, 1280, 33), (8192, 640, 2560, 33)]:
+    a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
+    res = torch.randn(M, N, device=dev).to(BF)
+    for _ in range(3):
+        ops.gemm(a, w, None, residual=res, tile=tile)
+    note("gemm", f"M{M} N{N} K{K}", 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N), tile)
+for (B, H, W, Cin, Cout, tile) in [(2, 32, 32, 1280, 1280, 35), (2, 64, 64, 640, 640, 33), (2, 128, 128, 320, 320, 34)]:
+    x = torch.randn(B, H, W, Cin, device=dev).to(BF); w = (torch.randn(Cout, 3, 3, Cin, device=dev) * (9 * Cin) ** -0.5).to(BF)
+    for _ in range(3):
+        ops.conv3x3(x, w, None, tile=tile)
+    note("conv3x3", f"B{B} {H}x{W} {Cin}->{Cout}", 2.0 * B * H * W * Cout * 9 * Cin, 2.0 * (B * H * W * (Cin + Cout) + Cout * 9 * Cin), tile)
+for (B, H, Tq, Tk) in [(2, 20, 1024, 1024), (2, 10, 4096, 4096)]:
+    C = H * 64
+    q = torch.randn(B, Tq, C, device=dev).to(BF); k = torch.randn(B, Tk, C, device=dev).to(BF)
+    vt = torch.randn(B, C, Tk, device=dev).to(BF)
+    for _ in range(3):
+        ops.flash_attn(q, k, vt, B, H, Tq, Tk)
+    note("attn", f"B{B} H{H} Tq{Tq} Tk{Tk}", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * C * (2 * Tq + 2 * Tk), -1)
+for (B, HW, C) in [(2, 1024, 1280), (2, 4096, 640), (2, 16384, 320)]:
+    x = torch.randn(B, HW, C, device=dev).to(BF)
+    g, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    for _ in range(3):
+        ops.groupnorm(x.view(B, HW, 1, C), g, bt, 1e-5, silu=True)
+    note("groupnorm", f"B{B} HW{HW} C{C}", 0.0, 4.0 * B * HW * C, -1)
 torch.cuda.synchronize()
+if len(sys.argv) > 1:
+    json.dump(cases, open(sys.argv[1], "w"), indent=1)
