@@ -667,22 +667,66 @@ static bool xcd_grid_enabled() {
     return v == 1;
 }
 
-// choose the XCD partition for a tiles_m x tiles_n grid (see the kernel comment); a_bytes / w_bytes = operand footprints
-void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes) {
+// Choose the XCD partition for a tiles_m x tiles_n grid (see the kernel comment): a gm x gn grid of XCD regions and the tile
+// order inside a region, minimising the bytes the eight private L2s have to pull in over the fabric.  Model (checked against
+// rocprofv3 FETCH_SIZE, profiles/r02/pmc_summary.json): an XCD runs `slots` = 32 CUs x wgs_per_cu workgroups at a time; within one
+// round the co-resident workgroups stream their operand panels through the L2 together, so each panel is fetched once.  What is
+// re-fetched: (a) an operand that is swept more than once -- the implicit-GEMM input is read once per tap (resweep = 9) -- unless
+// the XCD's share of it stays resident (<= ~3 MB of the 4 MB L2); (b) with several rounds per XCD, the operand that every round
+// needs again, unless it fits beside the other round's band.  The first version of this model charged gn*A + gm*W only: it put the
+// 1280-channel 32x32 convolutions on a (1, 8) grid whose 5.2 MB activation map does not stay resident -- 389 MB fetched for 35 MB
+// of operands (11x), 4.5 TB/s of fabric traffic in an "MFMA-bound" kernel.
+void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes, int resweep, int wgs_per_cu) {
     a.gm = a.gn = 0;
     if (!xcd_grid_enabled() || ((tiles_m * tiles_n) & 7)) return;
+    static int model = -1;
+    if (model < 0) {
+        const char* e = getenv("SUPIR_XCD_MODEL");   // 0: the round-1 cost model (kept for A/B runs)
+        model = (e && e[0] == '0') ? 0 : 1;
+    }
     const double c_bytes = 2.0 * (double)a.M * a.N / 8.0;   // each XCD also write-allocates its share of the output
+    const double RES = 3.0e6, BOTH = 3.5e6;
+    const int slots = 32 * (wgs_per_cu < 1 ? 1 : wgs_per_cu);
     double best = 0.0;
     for (int gm = 8; gm >= 1; gm >>= 1) {
         const int gn = 8 / gm;
         if (tiles_m % gm || tiles_n % gn) continue;
-        double cost = gn * a_bytes + gm * w_bytes;                            // L2 fills summed over the 8 XCDs
-        if (a_bytes / gm + w_bytes / gn + c_bytes > 3.3e6) cost *= 1.5;       // region does not fit a 4 MB L2: re-fetches
-        if (a.gm == 0 || cost < best) {
-            best = cost;
-            a.gm = gm;
-            a.gn = gn;
-            a.order = (a_bytes / gm > w_bytes / gn) ? 1 : 0;   // keep the region's bigger operand panel resident longer
+        if (model == 0) {
+            double cost = gn * a_bytes + gm * w_bytes;
+            if (a_bytes / gm + w_bytes / gn + c_bytes > 3.3e6) cost *= 1.5;
+            if (a.gm == 0 || cost < best) {
+                best = cost;
+                a.gm = gm;
+                a.gn = gn;
+                a.order = (a_bytes / gm > w_bytes / gn) ? 1 : 0;
+            }
+            continue;
+        }
+        const double ax = a_bytes / gm, wx = w_bytes / gn;
+        const int n_wg = (tiles_m / gm) * (tiles_n / gn);
+        const int rounds = (n_wg + slots - 1) / slots;
+        for (int order = 0; order < 2; ++order) {
+            double at, wt;
+            if (rounds == 1) {
+                at = ax <= RES ? ax : resweep * ax;
+                wt = wx;
+            } else if (order == 1) {   // tile_n fastest: a round = a band of tile rows x all tile columns of the region
+                const double band_a = ax / rounds;
+                at = band_a <= RES ? ax : resweep * ax;
+                wt = (wx + band_a <= BOTH) ? wx : rounds * wx;
+            } else {                   // tile_m fastest: a round = all tile rows x a band of tile columns
+                const double band_w = wx / rounds;
+                wt = wx;
+                at = (ax + band_w <= BOTH) ? ax : rounds * (ax <= RES ? ax : resweep * ax);
+            }
+            const double cost = at + wt;
+            if (a.gm == 0 || cost < best) {
+                best = cost;
+                a.gm = gm;
+                a.gn = gn;
+                a.order = order;
+            }
+            if (rounds == 1) break;   // order is irrelevant inside a single round: keep 0
         }
     }
 }
@@ -693,7 +737,8 @@ static int launch_gemm(const GemmArgs& a_in, hipStream_t st) {
     {
         const double a_bytes = CONV ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin
                                     : 2.0 * (double)a.M * a.K;
-        supir_choose_xcd_grid(a, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a_bytes, 2.0 * (double)a.N * a.K);
+        constexpr int lds = KS * S * (BM + BN) * 128 + 256;
+        supir_choose_xcd_grid(a, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a_bytes, 2.0 * (double)a.N * a.K, CONV ? 9 : 1, 163840 / lds);
     }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // ring(s) + the prefetch scratch row

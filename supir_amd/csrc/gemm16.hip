@@ -549,7 +549,7 @@ template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV =
 static int launch_gemm16(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     const double a_bytes = CONV ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin : 2.0 * (double)a.M * a.K;
-    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, a_bytes, 2.0 * (double)a.N * a.K);
+    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, a_bytes, 2.0 * (double)a.N * a.K, CONV ? 9 : 1, 1);
     constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // the ring(s) + the prefetch scratch row
     static_assert(smem <= 163840, "LDS");
     auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED>;

@@ -68,7 +68,7 @@ struct GnArgs {
 int supir_gemm_select_tile(int M, int N, int act, int force_tile);
 int supir_rowstats_finalize_launch(const float* part, float* out, int M, int ld, int slots, int dim, float eps, hipStream_t st);
 int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile);
-void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes);
+void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes, int resweep, int wgs_per_cu);
 // gemm16.hip: tiles 32 (128 x 80) / 33 (128 x 160), v_mfma_f32_16x16x32_bf16, two K groups per workgroup
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv);
 int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv);
