@@ -333,11 +333,30 @@ def main():
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):   # HBM / fabric-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes
+        traffic = {}
+        if os.path.exists(pmc):   # HBM / fabric-side bytes per launch from the committed rocprofv3 --pmc passes (per shape)
             try:
-                roofline["traffic"] = json.load(open(pmc)).get(name)
+                traffic = json.load(open(pmc))
+                roofline["traffic"] = traffic.get(name)
             except Exception:
                 pass
+        # the same figures for every kernel class that takes >= 3 % of the step (the dominant one is `roofline`)
+        by_kernel = []
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):
+            if v["us"] < 0.03 * total_us:
+                continue
+            if v["flops"] > 0:
+                ach = v["flops"] / v["us"] / 1e6
+                e = {"kernel": k, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4)}
+            else:
+                ach = v["bytes"] / v["us"] / 1e3
+                e = {"kernel": k, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(ach / HBM_PEAK_GBPS, 4)}
+            e.update(launches_per_unet_step=v["launches"], avg_launch_us=round(v["us"] / v["launches"], 2),
+                     share_of_step_time=round(v["us"] / total_us, 3), traffic=traffic.get(k))
+            by_kernel.append(e)
+        extra["roofline_by_kernel"] = by_kernel
         try:
             extra["kernel_breakdown_vae_colorfix"] = vae_colorfix_profile(model, P, device)
         except Exception as e:   # a profiling extra must never take the bench line down

@@ -21,7 +21,8 @@ def supir_v0_config(transformer_depth=None, sampler="RestoreEDMSampler", sampler
     cfg = {
         "target": "SUPIR.models.SUPIR_model.SUPIRModel",
         "params": {
-            "ae_dtype": "bf16", "diffusion_dtype": "bf16",   # the YAML says fp16; the HIP path computes bf16 (wrappers.py) "scale_factor": 0.13025, "disable_first_stage_autocast": True,
+            # the YAML says diffusion_dtype fp16; the HIP path computes bf16 (modules/wrappers.py): asked for explicitly here
+            "ae_dtype": "bf16", "diffusion_dtype": "bf16", "scale_factor": 0.13025, "disable_first_stage_autocast": True,
             "network_wrapper": "sgm.modules.diffusionmodules.wrappers.ControlWrapper",
             "denoiser_config": {"target": "sgm.modules.diffusionmodules.denoiser.DiscreteDenoiserWithControl",
                                 "params": {"num_idx": 1000, "discretization_config": _DDPM,

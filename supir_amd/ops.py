@@ -63,7 +63,7 @@ def finish_timing(trace):
 def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv"}[tile]
-        return f"gemm16_kernel<{nm}{',T' if trans else ''}>"
+        return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
             "128,128,2x2x2k"][t]

@@ -366,3 +366,13 @@ def test_fp16_request_is_not_silently_served_by_bf16(monkeypatch):
     w3.load_control_model(Ctl())
     with pytest.raises(RuntimeError, match="float16"):
         w3(x, t, c)
+
+
+def test_builtin_config_mirrors_the_reference_yaml_scalars():
+    """supir_amd.configs.supir_v0_config (what bench.py / the GPU parity tests build from) keeps the scalar parameters of
+    options/SUPIR_v0.yaml:4-8 -- a dropped `scale_factor` once made every latent 7.7x too large."""
+    from supir_amd.configs import supir_v0_config
+    p = supir_v0_config()["params"]
+    assert p["scale_factor"] == 0.13025 and p["ae_dtype"] == "bf16" and p["disable_first_stage_autocast"] is True
+    assert p["network_wrapper"] == "sgm.modules.diffusionmodules.wrappers.ControlWrapper"
+    assert p["sampler_config"]["params"]["guider_config"]["params"] == {"scale": 7.5, "scale_min": 4.0}
