@@ -34,20 +34,14 @@ __device__ __forceinline__ void attn_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int S, int NW, int KVS = 1, int OCC = 1>
-__global__ __launch_bounds__(64 * NW * KVS, OCC) void attn_d64_kernel(const AttnArgs p) {
+template <int S, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_d64_kernel(const AttnArgs p) {
     // S-deep ring of (K tile, V^T tile) pairs, 16 KB each (2 measured best: deeper rings bought nothing, the kernel is not
     // load-latency bound).  NW waves = 32*NW query rows per workgroup: 4 normally, 2 when the launch would otherwise put
     // fewer than two 4-wave workgroups on a CU (320 workgroups on 256 CUs run as two rounds at 62 % occupancy).
-    // KVS = 2 (the small-grid shapes: 1024-token self attention = 320 workgroups, text cross attention): two groups of NW waves
-    // share the SAME query rows and take alternate K / V tiles (step s: group g works on tile 2s + g, both tiles are staged
-    // together), so every SIMD holds two waves of the workgroup -- the VALU-heavy softmax of one overlaps the MFMAs of the other --
-    // and each wave's serial tile chain is half as long; the two partial (O, m, l) are merged through LDS at the end.
-    __shared__ __attribute__((aligned(16))) char smem[S * KVS * 16384];
-    constexpr int NT = 64 * NW * KVS, QB = 32 * NW, LPT = 512 / NT;   // threads, queries per workgroup, loads per thread per 8 KB tile
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int bw = tid >> 6;                              // wave inside the workgroup
-    const int wave = bw % NW, kh = bw / NW;               // query group / K-V group of this wave
+    __shared__ __attribute__((aligned(16))) char smem[S * 16384];
+    constexpr int NT = 64 * NW, QB = 32 * NW, LPT = 512 / NT;   // threads, queries per workgroup, loads per thread per 8 KB tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nqb = (p.Tq + QB - 1) / QB;
@@ -71,28 +65,24 @@ __global__ __launch_bounds__(64 * NW * KVS, OCC) void attn_d64_kernel(const Attn
     const int lrow = tid >> 3;
     const int lchunk = (tid & 7) ^ ((tid >> 4) & 7);
     const int nt = (p.Tk + 63) >> 6;
-    const int nsteps = (nt + KVS - 1) / KVS;              // loop steps: KVS tiles are staged and consumed per step
-    constexpr int NL = 2 * LPT * KVS;   // global->LDS instructions per thread per step: per tile K rows first, then V^T rows
-    auto stage_one = [&](int st, int buf, int q) {
-        const int ti = q / (2 * LPT), r = q - ti * (2 * LPT);     // tile inside the step, load inside the tile
-        int t = st * KVS + ti;
-        t = t < nt ? t : nt - 1;                                  // odd tile count: the last slot re-loads the last tile (never used)
-        char* sK = smem + (buf * KVS + ti) * 16384;
+    constexpr int NL = 2 * LPT;   // global->LDS instructions per thread per (K, V^T) tile pair: K rows first, then V^T rows
+    auto stage_one = [&](int t, int buf, int q) {
+        char* sK = smem + buf * 16384;
         char* sV = sK + 8192;
-        if (r < LPT) {
-            const int j = r;
+        if (q < LPT) {
+            const int j = q;
             int key = t * 64 + j * (NT / 8) + lrow;
             key = key < p.Tk ? key : p.Tk - 1;
-            glds16(Kb + (size_t)key * p.ldk + lchunk * 8, sK + (j * NT + bw * 64) * 16);
+            glds16(Kb + (size_t)key * p.ldk + lchunk * 8, sK + (j * NT + wave * 64) * 16);
         } else {
-            const int j = r - LPT;
+            const int j = q - LPT;
             const int d = j * (NT / 8) + lrow;
-            glds16(Vb + (size_t)d * p.ldvt + t * 64 + lchunk * 8, sV + (j * NT + bw * 64) * 16);
+            glds16(Vb + (size_t)d * p.ldvt + t * 64 + lchunk * 8, sV + (j * NT + wave * 64) * 16);
         }
     };
-    auto stage = [&](int st, int buf) {
+    auto stage = [&](int t, int buf) {
 #pragma unroll
-        for (int q = 0; q < NL; ++q) stage_one(st, buf, q);
+        for (int q = 0; q < NL; ++q) stage_one(t, buf, q);
     };
 
     f32x16 o[2];
@@ -115,37 +105,35 @@ __global__ __launch_bounds__(64 * NW * KVS, OCC) void attn_d64_kernel(const Attn
 #endif
     ATL(tl_t0);
     {
-        const int pre = nsteps < S - 1 ? nsteps : S - 1;
+        const int pre = nt < S - 1 ? nt : S - 1;
         for (int t = 0; t < pre; ++t) stage(t, t);
     }
-    for (int st = 0; st < nsteps; ++st) {
+    for (int t = 0; t < nt; ++t) {
         ATL(tl_a);
-        const int buf = st % S;
-        const int rem = nsteps - 1 - st;
-        const int inflight = rem < S - 2 ? rem : S - 2;   // younger steps allowed to stay outstanding (NL loads each)
+        const int buf = t % S;
+        const int rem = nt - 1 - t;
+        const int inflight = rem < S - 2 ? rem : S - 2;   // younger tiles allowed to stay outstanding (4 loads each)
         if constexpr (S >= 4) {
-            if (inflight >= 2) attn_wait_vmcnt<2 * NL>();
-            else if (inflight == 1) attn_wait_vmcnt<NL>();
+            if (inflight >= 2) attn_wait_vmcnt<4 * LPT>();
+            else if (inflight == 1) attn_wait_vmcnt<2 * LPT>();
             else attn_wait_vmcnt<0>();
         } else if constexpr (S == 3) {
-            if (inflight >= 1) attn_wait_vmcnt<NL>();
+            if (inflight >= 1) attn_wait_vmcnt<2 * LPT>();
             else attn_wait_vmcnt<0>();
         } else {
             attn_wait_vmcnt<0>();
         }
-        __builtin_amdgcn_s_barrier();   // step st visible to all waves; all waves are done with step st-1's buffer
+        __builtin_amdgcn_s_barrier();   // tile t visible to all waves; all waves are done with tile t-1's buffer
         asm volatile("" ::: "memory");
         ATL(tl_b);
-        // The next step's global->LDS instructions are spread over the 8 MFMA groups of this iteration (4 in Q.K^T,
+        // The next tile pair's global->LDS instructions are spread over the 8 MFMA groups of this iteration (4 in Q.K^T,
         // 4 in P.V): issued back to back they stall ~550 cycles on the CU's vector-memory path with the matrix pipe idle
         // (s_memtime, tools/probes/attn_timeline.hip).  The two independent accumulators of each product alternate, so
         // consecutive MFMAs never wait on each other's result.
-        const bool do_stage = st + S - 1 < nsteps;
-        const int st_t = st + S - 1, st_buf = (st + S - 1) % S;
+        const bool do_stage = t + S - 1 < nt;
+        const int st_t = t + S - 1, st_buf = (t + S - 1) % S;
         ATL(tl_c);
-        const int t = st * KVS + kh;                       // this wave's tile of the step
-        if (KVS > 1 && t >= nt) continue;                  // odd tile count: the second group idles in the last step (nothing to stage)
-        const char* sK = smem + (buf * KVS + kh) * 16384;
+        const char* sK = smem + buf * 16384;
         const char* sV = sK + 8192;
 
         // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
@@ -258,31 +246,6 @@ __global__ __launch_bounds__(64 * NW * KVS, OCC) void attn_d64_kernel(const Attn
     }
     ATL(tl_loop1);
 
-    if constexpr (KVS == 2) {
-        // merge the two K / V groups' partial results of the same query rows: group 1 parks (O, m, l) in LDS ([wave][34][lane] fp32,
-        // lane-contiguous), group 0 rescales both to the common maximum and finishes.  A group that saw no tile has m = -inf, l = 0,
-        // O = 0 and drops out with weight exp2(-inf) = 0.
-        __syncthreads();                                   // every wave is done with the K / V ring
-        float* xb = (float*)smem + (size_t)wave * (34 * 64) + lane;
-        if (kh == 1) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xb[(i * 16 + r) * 64] = o[i][r];
-            xb[32 * 64] = m_run;
-            xb[33 * 64] = l_run;
-        }
-        __syncthreads();
-        if (kh == 1) return;
-        const float m1 = xb[32 * 64], l1 = xb[33 * 64];
-        const float m = fmaxf(m_run, m1);
-        const float a0 = __builtin_amdgcn_exp2f((m_run - m) * p.scale_log2e), a1 = __builtin_amdgcn_exp2f((m1 - m) * p.scale_log2e);
-        l_run = l_run * a0 + l1 * a1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + xb[(i * 16 + r) * 64] * a1;
-    }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_ok) {
@@ -324,20 +287,8 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
         force_nw = e ? atoi(e) : 0;
     }
     const int blocks4 = ((a.Tq + 127) / 128) * a.H * a.B;
-    const int nt = (a.Tk + 63) / 64;
-    static int force_kvs = -1;  // SUPIR_ATTN_KVS=1|2 pins the K / V split (A/B runs)
-    if (force_kvs < 0) {
-        const char* e = getenv("SUPIR_ATTN_KVS");
-        force_kvs = e ? atoi(e) : 0;
-    }
     const bool small = force_nw == 2;   // measured: the 2-wave form is never faster (the kernel is VALU-bound, not occupancy-bound)
-    // two K / V groups per workgroup when the grid leaves most SIMDs with a single wave (<= 2 workgroups per CU) and there are at
-    // least two tiles to split: the 1024-token self attention (320 workgroups) and the text cross attention (Tk = 77: one tile each)
-    const bool kvs2 = force_kvs >= 2 || (force_kvs == 0 && blocks4 <= 512 && nt >= 2);   // 3: never the <= 128-VGPR build
     if (small) SUPIR_LAUNCH((attn_d64_kernel<2, 2>), dim3(((a.Tq + 63) / 64) * a.H * a.B), dim3(128), 0, st, a);
-    else if (kvs2 && blocks4 > 256 && force_kvs != 3)   // more workgroups than CUs: two must fit a CU (<= 128 VGPRs, a few spills)
-        SUPIR_LAUNCH((attn_d64_kernel<2, 4, 2, 4>), dim3(blocks4), dim3(512), 0, st, a);
-    else if (kvs2) SUPIR_LAUNCH((attn_d64_kernel<2, 4, 2, 2>), dim3(blocks4), dim3(512), 0, st, a);
     else SUPIR_LAUNCH((attn_d64_kernel<2, 4>), dim3(blocks4), dim3(256), 0, st, a);
     return SUPIR_LAUNCH_STATUS();
 }
