@@ -246,6 +246,35 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
         }
     }
 
+    // Residual / row-bias operands of the epilogue (this lane's 4 channels of its token per fragment), fetched NOW: issued in the
+    // epilogue they were a dependent L2 / fabric round trip (~0.5-1 us) at the very end of a 13 us launch.  In-place residuals
+    // (x += f(x)) are safe: a workgroup reads its whole tile here, long before any of its stores, and tiles are disjoint.
+    // (only where it is cheap in registers: 2 x MIH x NI x 2 VGPRs held across the main loop; the 256 x 160 tile would spill)
+    constexpr bool PRE = !TRANS && MIH * NI <= 10;
+    u32x2 pre_res[PRE ? MIH : 1][PRE ? NI : 1], pre_rb[PRE ? MIH : 1][PRE ? NI : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int h = 0; h < MIH; ++h)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) pre_res[h][j] = pre_rb[h][j] = u32x2{0u, 0u};
+        if (!tr && p.act != 2) {
+#pragma unroll
+            for (int h = 0; h < MIH; ++h) {
+                const int m = m0 + wm * WTM + (kg * MIH + h) * 16 + l15;
+                if (p.res) {
+                    const bf16_t* rp = p.res + (size_t)m * p.ldr + n0 + wn * WTN + 4 * quad;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) pre_res[h][j] = *(const u32x2*)(rp + j * 16);
+                }
+                if (p.rowbias) {
+                    const bf16_t* rbp = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rb + n0 + wn * WTN + 4 * quad;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) pre_rb[h][j] = *(const u32x2*)(rbp + j * 16);
+                }
+            }
+        }
+    }
+
     // one K step.  STAGE: also issue the global->LDS loads of tile kt + S - 1 (into the buffer step kt - 1 just finished reading),
     // spread over the two 32-wide K slices; INFLIGHT: younger stages that may stay outstanding across this step's barrier
     int buf = 0, sbuf = S - 1;   // ring positions of the tile being read / being staged (kept modulo S without a division)
@@ -464,17 +493,25 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                 const int m = m0 + mrow + l15;
                 const float mu = ln_mean[h], rs = ln_rstd[h];
                 u32x2 e_rb[NI], e_res[NI];
+                if constexpr (PRE) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) e_rb[j] = e_res[j] = u32x2{0u, 0u};
-                if (p.rowbias) {
-                    const bf16_t* rbp = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rb + n0 + wn * WTN + 4 * quad;
+                    for (int j = 0; j < NI; ++j) {
+                        e_rb[j] = pre_rb[h][j];
+                        e_res[j] = pre_res[h][j];
+                    }
+                } else {
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) e_rb[j] = *(const u32x2*)(rbp + j * 16);
-                }
-                if (p.res) {
-                    const bf16_t* rp = p.res + (size_t)m * p.ldr + n0 + wn * WTN + 4 * quad;
+                    for (int j = 0; j < NI; ++j) e_rb[j] = e_res[j] = u32x2{0u, 0u};
+                    if (p.rowbias) {
+                        const bf16_t* rbp = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rb + n0 + wn * WTN + 4 * quad;
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) e_res[j] = *(const u32x2*)(rp + j * 16);
+                        for (int j = 0; j < NI; ++j) e_rb[j] = *(const u32x2*)(rbp + j * 16);
+                    }
+                    if (p.res) {
+                        const bf16_t* rp = p.res + (size_t)m * p.ldr + n0 + wn * WTN + 4 * quad;
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) e_res[j] = *(const u32x2*)(rp + j * 16);
+                    }
                 }
                 float rsum = 0.f, rsq = 0.f;
 #pragma unroll

@@ -21,6 +21,7 @@ ap.add_argument("--tile-batch", type=int, default=4)
 ap.add_argument("--skip-tiled", action="store_true")
 ap.add_argument("--only-tiled", action="store_true")
 ap.add_argument("--tiled-res", type=int, default=4096)
+ap.add_argument("--tiled-single", action="store_true", help="time ONE tiled call (a warm-up at 2 steps first): for 50-step runs")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 
@@ -75,17 +76,16 @@ if not args.skip_tiled:
     m.sampler_config["params"].update(tile_size=128, tile_stride=64, tile_batch=args.tile_batch)
     m.init_tile_vae(encoder_tile_size=512, decoder_tile_size=64)
     torch.cuda.reset_peak_memory_stats()
-    t0 = time.time()
     R = args.tiled_res
     x = synth_tensor(f"img{R}", (1, 3, R, R), scale=0.5).clamp(-1, 1).to(dev)
-    out = m.batchify_sample(x, cond=cond(), num_steps=args.tiled_steps, restoration_scale=-1, s_churn=5, s_noise=1.01, cfg_scale=4.0,
-                            seed=1234, color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=1.0)
+    kw = dict(cond=cond(), restoration_scale=-1, s_churn=5, s_noise=1.01, cfg_scale=4.0, seed=1234, color_fix_type="Wavelet",
+              use_linear_CFG=True, cfg_scale_start=1.0)
+    t0 = time.time()
+    out = m.batchify_sample(x, num_steps=2 if args.tiled_single else args.tiled_steps, **kw)   # warm-up: autotune, graph capture
     torch.cuda.synchronize()
     t_all = time.time() - t0
-    # sampler alone, steady state
     t0 = time.time()
-    out = m.batchify_sample(x, cond=cond(), num_steps=args.tiled_steps, restoration_scale=-1, s_churn=5, s_noise=1.01, cfg_scale=4.0,
-                            seed=1234, color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=1.0)
+    out = m.batchify_sample(x, num_steps=args.tiled_steps, **kw)
     torch.cuda.synchronize()
     t2 = time.time() - t0
     res[f"config3_{R}px_tiled"] = {"edm_steps": args.tiled_steps, "tile_batch": args.tile_batch, "s_first_call": t_all, "s_per_image": t2,
