@@ -41,6 +41,15 @@ __device__ __forceinline__ void g16_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef SUPIR_G16_TIMELINE
+// tools/probes/g16_timeline.py only (never defined in the product build): per-wave s_memtime stamps of the kernel's phases
+__device__ unsigned long long* g16_tl_buf;
+extern "C" void supir_g16_tl_set(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g16_tl_buf), &p, sizeof(p)); }
+#define G16_TL(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define G16_TL(var)
+#endif
+
 // zero page for the halo / padding rows of the implicit-GEMM (3x3 convolution) loader
 __device__ __attribute__((aligned(256))) uint32_t g16_zero_page[64];
 
@@ -50,6 +59,7 @@ __device__ __attribute__((aligned(256))) uint32_t g16_zero_page[64];
 template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    G16_TL(tl_start);
     constexpr int NW = WM * WN;                          // waves per K group
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, RING = S * STAGE_BYTES;
     constexpr int A_Q = BM / 8 / NW;                     // 8-row chunks of A per wave and K step (chunk id = wave + NW q)
@@ -320,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
+    G16_TL(tl_loop0);
     auto main_loop = [&](auto trans_c) {
         for (int kt = 0; kt + S - 1 < nk; ++kt) kstep(T_{}, std::integral_constant<int, S - 2>{}, trans_c);
         if constexpr (S == 3) kstep(F_{}, std::integral_constant<int, 1>{}, trans_c);
@@ -333,6 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     }
 
     // ------------------------------------------------------------------ epilogue
+    G16_TL(tl_loop1);
     __syncthreads();   // every wave is done with its last fragment reads: the rings are scratch from here on
     if constexpr (!TRANS) {
         if (kg == 0 && tid < BN && !tr) {
@@ -381,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     } else {
         __syncthreads();   // bias / column sums are in LDS
     }
+    G16_TL(tl_xch);
     // from here on the wave's data is acc[kg*MIH + h][j], h < MIH (compile-time indices in both wave-uniform branches)
     auto prefetch_next = [&]() {
         const unsigned pf_lines = p.pf_lines;
@@ -578,6 +591,20 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                 }
             }
         }
+#ifdef SUPIR_G16_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g16_tl_buf && lane == 0) {
+            const unsigned long long tl_end = __builtin_amdgcn_s_memtime();
+            unsigned long long* o = g16_tl_buf + ((size_t)blockIdx.x * 8 + bwave) * 8;
+            o[0] = tl_start;
+            o[1] = tl_loop0 - tl_start;
+            o[2] = tl_loop1 - tl_loop0;
+            o[3] = tl_xch - tl_loop1;
+            o[4] = tl_end - tl_xch;
+            o[5] = tl_end - tl_start;
+            o[6] = tl_end;
+        }
+#endif
         prefetch_next();
     }
 }

@@ -1,0 +1,54 @@
+"""Per-phase s_memtime breakdown of the gemm16 kernels (prologue incl. row-statistics fetch / main loop / K-group exchange /
+epilogue), per wave, averaged.  Builds a second copy of the library with -DSUPIR_G16_TIMELINE (the product build never defines
+it) and calls it directly through ctypes.   python tools/probes/g16_timeline.py"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+CSRC = os.path.join(ROOT, "supir_amd", "csrc")
+OUT = "/tmp/libsupir_hip_tl.so"
+srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "gemm16.hip", "attention.hip", "norm.hip", "edge.hip", "api.hip")]
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+       "-DSUPIR_G16_TIMELINE"] + srcs + ["-o", OUT]
+subprocess.check_call(cmd)
+lib = ctypes.CDLL(OUT)
+P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+lib.supir_gemm_bf16.argtypes = [P, P, P, I, I, I, I, I, P, P, I, I, P, I, I, I, F, I, P]
+lib.supir_g16_tl_set.argtypes = [P]
+BF = torch.bfloat16
+for (M, N, K, tile) in [(2048, 1280, 1280, 35), (2048, 1280, 1280, 32), (2048, 1280, 5120, 35), (2048, 2560, 1280, 33), (2048, 10240, 1280, 34)]:
+    a = torch.randn(M, K, device="cuda").to(BF)
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
+    res = torch.randn(M, N, device="cuda").to(BF)
+    bias = torch.randn(N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=BF)
+    bm, bn = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80)}[tile]
+    nwg = (M // bm) * (N // bn)
+    buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device="cuda")
+    lib.supir_g16_tl_set(buf.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, K, N, bias.data_ptr(), None, 0, 0,
+                                   res.data_ptr(), N, 0, 0, 1.0, tile, st)
+    for _ in range(5):
+        assert run() == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    t = buf.view(nwg * 8, 8).cpu().double()
+    nk = (K // 64) // (1 if tile == 34 else 2)
+    print(f"M={M} N={N} K={K} tile={tile} wgs={nwg} | event {us:.1f} us | per wave (cycles): prologue "
+          f"{t[:, 1].mean():.0f}  loop {t[:, 2].mean():.0f} ({t[:, 2].mean() / nk:.0f} per K step x {nk})  exchange {t[:, 3].mean():.0f}  "
+          f"epilogue {t[:, 4].mean():.0f}  total {t[:, 5].mean():.0f} (max {t[:, 5].max():.0f})", flush=True)
+    lib.supir_g16_tl_set(None)
