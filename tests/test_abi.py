@@ -56,3 +56,23 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     assert lib.supir_wavelet_level(fake, fake, fake + 4096, 3, 8, 8, 1, 1, None) == -1      # img aliases low
     assert lib.supir_wavelet_level(fake, fake + 4096, fake + 8192, 3, 8, 8, 0, 1, None) == -2   # radius 0: shape error
     assert lib.supir_wavelet_level(fake, fake + 4096, fake + 8192, 70000, 8, 8, 1, 1, None) == -2   # planes > grid limit
+
+
+def test_round2_entry_points_validate_arguments_without_a_gpu():
+    """supir_gemm_bf16_qkv / supir_flash_attn_d64_ex / supir_resample_u8 / supir_bicubic_f32 and the gemm16 tile indices: argument
+    and shape errors are reported before any HIP call (null pointers, inexact shapes, bad flags)."""
+    lib = _lib.load()
+    fake = 0x10000
+    assert lib.supir_gemm_bf16_qkv(None, None, None, None, 2048, 3840, 2560, 1280, 1280, 2560, 1024, 1024, None, None, 0, 0, None, 1e-5, None) == -1
+    # M not a multiple of 256 -> SUPIR_ERR_SHAPE (the caller then issues the two separate projections)
+    assert lib.supir_gemm_bf16_qkv(fake, fake, fake, fake, 2000, 3840, 2560, 1280, 1280, 2560, 1000, 1000, None, None, 0, 0, None, 1e-5, None) == -2
+    assert lib.supir_flash_attn_d64_ex(None, None, None, None, 1, 1, 64, 64, 64, 64, 64, 64, 0.125, 1, None) == -1
+    assert lib.supir_flash_attn_d64_ex(fake, fake, fake, fake, 1, 1, 64, 128, 64, 64, 128, 64, 0.125, 1, None) == -2   # causal needs Tq == Tk
+    assert lib.supir_flash_attn_d64_ex(fake, fake, fake, fake, 1, 1, 64, 64, 64, 64, 64, 64, 0.125, 6, None) == -1    # unknown flag bits
+    assert lib.supir_resample_u8(None, None, None, None, None, None, 5, 8, 8, 8, 16, 3, 0, None) == -1
+    assert lib.supir_resample_u8(fake, None, None, None, fake, fake, 5, 8, 8, 8, 16, 3, 0, None) == -1                  # no output at all
+    assert lib.supir_resample_u8(fake, fake, None, None, fake, fake, 5, 8, 8, 9, 16, 3, 0, None) == -2                  # horizontal pass keeps H
+    assert lib.supir_bicubic_f32(None, None, None, 3, 8, 8, 4, 4, None) == -1
+    # tile 32 (128 x 80) on an inexact shape is refused, not silently run on another tile
+    assert lib.supir_gemm_bf16(fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 32, None) == -2
+    assert lib.supir_gemm_bf16(fake, fake, fake, 128, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 36, None) == -1   # no such tile
