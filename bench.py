@@ -86,38 +86,42 @@ def kernel_profile(model, latent, device):
         model.model(x, t, cond, 1.0)
         torch.cuda.synchronize()
         tr = ops.finish_timing(ops.stop_trace())
-    agg = collections.OrderedDict()
+    agg, by_shape = collections.OrderedDict(), collections.OrderedDict()
     for r in tr:
         k = r["kernel"]
+        shape = None
         if k in ("gemm", "gemm_t", "conv3x3"):
+            shape = f"M{r['M']} N{r['N']} K{r['K']}" + (" geglu" if r.get("act", 0) == 2 else "")
             k = ops.gemm_tile_name(r["M"], r["N"], r.get("act", 0), conv=(k == "conv3x3"), trans=(k == "gemm_t"),
                                    tile=r.get("tile", -1))
-        a = agg.setdefault(k, dict(launches=0, us=0.0, flops=0.0, bytes=0.0))
-        a["launches"] += 1
-        a["us"] += r["us"]
-        a["flops"] += r["flops"]
-        a["bytes"] += r["bytes"]
-    return agg, sum(r["us"] for r in tr)
+        elif k == "attn":
+            shape = f"B{r['B']} H{r['H']} Tq{r['Tq']} Tk{r['Tk']}"
+        elif k == "groupnorm":
+            shape = f"B{r['B']} HW{r['HW']} C{r['C']}"
+        for d, key in ((agg, k), (by_shape, (k, shape))):
+            a = d.setdefault(key, dict(launches=0, us=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["us"] += r["us"]
+            a["flops"] += r["flops"]
+            a["bytes"] += r["bytes"]
+    return agg, sum(r["us"] for r in tr), by_shape
 
 
-def _pick_threads():
-    """Thread count for the CPU baseline: a 2048^3 fp32 matmul timed at a few counts (all hardware threads is NOT best on a
-    2-socket SMT box: the first attempt of round 1 with 256 threads was 10x slower than 32)."""
+def _pick_threads(sample, cands=(32, 64)):
+    """Thread count for the CPU baseline, chosen on the workload itself: `sample()` (one small oracle network call) is timed at a
+    few counts.  A matmul probe is misleading here -- it prefers 128-256 threads on the 2-socket host, where the oracle's mix of
+    small convolutions / attention / norms runs 4-10x slower than at 32 (oversubscribed OpenMP barriers)."""
     n = os.cpu_count() or 1
-    cands = sorted({c for c in (n, n // 2, n // 4, n // 8, 32) if 1 <= c <= n}, reverse=True)
-    a, b = torch.randn(2048, 2048), torch.randn(2048, 2048)
     best = None
-    for c in cands:
+    for c in [c for c in cands if c <= n] or [n]:
         torch.set_num_threads(c)
-        torch.mm(a, b)
         t0 = time.time()
-        for _ in range(3):
-            torch.mm(a, b)
-        dt = (time.time() - t0) / 3
+        sample()
+        dt = time.time() - t0
         if best is None or dt < best[0]:
             best = (dt, c)
     torch.set_num_threads(best[1])
-    return best[1], {c: None for c in cands}
+    return best[1], best[0]
 
 
 def cpu_baseline(model, device, budget_s=60.0):
@@ -129,7 +133,6 @@ def cpu_baseline(model, device, budget_s=60.0):
     from oracle import supir_oracle as O
     from supir_amd import ops
     from supir_amd.synth import synth_tensor
-    threads, _ = _pick_threads()
     B, latent = 2, 32
     x = synth_tensor("bench.x", (B, 4, latent, latent))
     cond = {"crossattn": synth_tensor("bench.ctx", (B, 77, 2048)), "vector": synth_tensor("bench.y", (B, 2816)),
@@ -141,10 +144,12 @@ def cpu_baseline(model, device, budget_s=60.0):
         model.model(x.to(device), t.to(device), {k: v.to(device) for k, v in cond.items()}, 1.0)
         tflop_a = sum(r["flops"] for r in ops.stop_trace()) / 1e12
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if v.is_floating_point()}
-    with torch.no_grad():
-        t0 = time.time()
-        O.control_wrapper(sd, x, t, cond, 1.0)
-        dt_a = time.time() - t0
+
+    def sample():
+        with torch.no_grad():
+            O.control_wrapper(sd, x, t, cond, 1.0)
+
+    threads, dt_a = _pick_threads(sample)
     rate = tflop_a / dt_a
     cfg1_tflop = 2 * UNET_STEP_TFLOP[64] + 2 * 1.117 + 2 * 2.515     # 512^2 step, VAE enc / dec at 512^2
     res = {"unit": "images/s", "cores": threads, "kind": "port", "host_threads_available": os.cpu_count(),
@@ -313,20 +318,22 @@ def main():
 
     roofline, breakdown = None, None
     if rank == 0 and not args.no_kernel_profile:
-        agg, total_us = kernel_profile(model, P // 8, device)
+        agg, total_us, by_shape = kernel_profile(model, P // 8, device)
         breakdown = {k: {"launches": v["launches"], "ms": round(v["us"] / 1e3, 3),
                          "tflops": round(v["flops"] / v["us"] / 1e6, 1) if v["flops"] else None,
                          "gbps": round(v["bytes"] / v["us"] / 1e3, 1),
                          "frac_of_peak": round(v["flops"] / v["us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 3) if v["flops"]
                          else round(v["bytes"] / v["us"] / 1e3 / HBM_PEAK_GBPS, 3)} for k, v in agg.items()}
-        dom = max(agg.items(), key=lambda kv: kv[1]["us"])
-        name, v = dom
+        # the dominant kernel = the (instantiation, problem shape) with the largest share of the step: one instantiation serves
+        # shapes of very different work per launch (128x80 tile: K = 1280 and K = 5120), and the roofline figure is per launch
+        (name, dom_shape), v = max(by_shape.items(), key=lambda kv: kv[1]["us"])
         if v["flops"] > 0:
             ach = v["flops"] / v["launches"] / (v["us"] / v["launches"] * 1e-6) / 1e12
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                         "launches_per_unet_step": v["launches"], "avg_launch_us": round(v["us"] / v["launches"], 2),
                         "algorithmic_gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3),
+                        "algorithmic_mb_per_launch": round(v["bytes"] / v["launches"] / 1e6, 3), "shape": dom_shape,
                         "share_of_step_time": round(v["us"] / total_us, 3)}
         else:
             ach = v["bytes"] / (v["us"] * 1e-6) / 1e9
@@ -337,7 +344,10 @@ def main():
         if os.path.exists(pmc):   # HBM / fabric-side bytes per launch from the committed rocprofv3 --pmc passes (per shape)
             try:
                 traffic = json.load(open(pmc))
-                roofline["traffic"] = traffic.get(name)
+                tr_e = traffic.get(name)
+                if isinstance(tr_e, list):   # per-shape entries: pick this shape's
+                    tr_e = next((e for e in tr_e if dom_shape and e.get("shape", "").replace(" geglu", "") in dom_shape), tr_e)
+                roofline["traffic"] = tr_e
             except Exception:
                 pass
         # the same figures for every kernel class that takes >= 3 % of the step (the dominant one is `roofline`)
