@@ -10,10 +10,10 @@
 //   Vt [B][H*64][ldvt]  V TRANSPOSED per batch (row = h*64+d, column = key), written by the to_v GEMM's
 //                       transposed epilogue; ldvt >= round_up(Tk,64) and the padding is finite (zero)
 //   O  [B][Tq][ldo]
-// One workgroup = 4 (or 2) waves = 128 (64) query rows of one (batch, head); K / Vt tiles of 64 keys are staged through LDS
-// by global_load_lds (double buffered, counted vmcnt) and shared by the 4 waves.
-// MFMA 32x32x16 with swapped operands: S^T = K.Q^T puts one query row per lane (softmax needs one shfl_xor 32),
-// and P feeds the PV MFMA straight from those registers: the key order inside each 16-wide k block is
+// One workgroup = 4 waves = 128 query rows of one (batch, head); K / Vt tiles of 64 keys are staged through LDS by
+// global_load_lds (3-deep ring, counted vmcnt) and shared by the 4 waves.
+// MFMA 32x32x16 with swapped operands: S^T = K.Q^T puts one query row per lane (the row maximum needs one
+// v_permlane32_swap), and P feeds the PV MFMA straight from those registers: the key order inside each 16-wide k block is
 // arranged (K rows read with bits 2/3 of the row index swapped) so that it is one 16-byte chunk of a Vt row: no
 // cross-lane exchange, conflict-free ds_read_b128 on both operands.
 #include "kernels.h"
@@ -34,217 +34,285 @@ __device__ __forceinline__ void attn_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int S, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_d64_kernel(const AttnArgs p) {
-    // S-deep ring of (K tile, V^T tile) pairs, 16 KB each (2 measured best: deeper rings bought nothing, the kernel is not
-    // load-latency bound).  NW waves = 32*NW query rows per workgroup: 4 normally, 2 when the launch would otherwise put
-    // fewer than two 4-wave workgroups on a CU (320 workgroups on 256 CUs run as two rounds at 62 % occupancy).
+// ---------------------------------------------------------------------------------------------------------
+// Software pipeline.  Run strictly one after the other, Q.K^T, softmax and P.V of a 64-key tile cost 2470 cycles per wave
+// for 512 cycles of MFMA (profiles/r01/attn_timeline_after.log, profiles/r02/attn_timeline_unpipelined.log): a wave issues
+// in order, one VALU instruction per >= 4 cycles (8 for v_exp_f32) and 12.5 per MFMA, and up to five plain VALU
+// instructions are free beside each 32-cycle MFMA (tools/probes/issue_probe.hip, profiles/r02/issue_probe.log).  So the
+// unit here is a HALF tile g (32 keys) and every MFMA is issued with independent VALU work of the neighbouring half tile:
+//     slots 1-4:  S(g+1) = K(g+1).Q^T - m   (4 chained MFMAs, C operand = -m)  |  P(g) = exp2(S(g)), row sums, bf16 pack
+//     slots 5-8:  O += V^T(g).P(g)          (4 MFMAs)                          |  row maximum of S(g+1)
+// K / V^T fragments are ds_read one stage ahead of their MFMAs.  Because S(t+1, half 0) is produced during tile t, tile t+1
+// must already be in LDS while tile t is being consumed: an S-deep ring (S >= 3), one barrier per tile at which tile t+1
+// is awaited and the loads of tile t+S-1 are issued.  Measured (profiles/r02/attn_pipelined_vs_unpipelined_timing.log):
+// 28.9 -> 24.3 us at (B2, H20, 1024^2), 138 -> 114 us at (B2, H10, 4096^2) = 755 TFLOP/s.
+template <bool V>
+struct attn_flag {
+    static constexpr bool value = V;
+};
+
+__device__ __forceinline__ float xhalf_max(float x) {
+    // max over lanes l and l^32: one v_permlane32_swap, no LDS round trip in the dependent chain
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int S, int NW, bool PRE>
+__global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgs p) {
+    static_assert(S >= 3, "tile t+1 is read while tile t is live and tile t+2 is in flight");
     __shared__ __attribute__((aligned(16))) char smem[S * 16384];
-    constexpr int NT = 64 * NW, QB = 32 * NW, LPT = 512 / NT;   // threads, queries per workgroup, loads per thread per 8 KB tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = 64 * NW, QB = 32 * NW, LPT = 512 / NT, NL = 2 * LPT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nqb = (p.Tq + QB - 1) / QB;
     const int id = xcd_remap(blockIdx.x, nqb * p.H * p.B);
-    const int bh = id / nqb, qb = id - bh * nqb;  // consecutive ids (same XCD) share K/V of one (b,h)
+    const int bh = id / nqb, qb = id - bh * nqb;
     const int b = bh / p.H, h = bh - b * p.H;
+    const char* Kb = (const char*)(p.K + (size_t)b * p.Tk * p.ldk + h * 64);
+    const char* Vb = (const char*)(p.Vt + ((size_t)b * p.H + h) * 64 * p.ldvt);
 
-    const bf16_t* Kb = p.K + (size_t)b * p.Tk * p.ldk + h * 64;
-    const bf16_t* Vb = p.Vt + ((size_t)b * p.H + h) * 64 * p.ldvt;
-
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane -> query l31, d = 16*ks + 8*half .. +7
-    int q = qb * QB + wave * 32 + l31;
+    const int q = qb * QB + wave * 32 + l31;
     const bool q_ok = q < p.Tq;
     const int qc = q_ok ? q : p.Tq - 1;
     const bf16_t* Qp = p.Q + ((size_t)b * p.Tq + qc) * p.ldq + h * 64 + 8 * half;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qp + 16 * ks);
+    const float c = p.scale_log2e;
+    const float pmul = PRE ? 1.0f : c;   // PRE = false: S stays in raw q.k units and the exponent pays one multiply per element
+    bf16x8 qf[4];   // loaded after the first K / V^T tiles have been requested (their latencies then overlap)
 
-    // ---- loader: slot s = j*NT+tid -> row j*(NT/8) + (tid>>3), physical chunk tid&7, logical chunk swizzled
+    // ---- loader.  Source address = wave-uniform tile base (SGPR pair) + a per-lane 32-bit byte offset that does not
+    // change from tile to tile, so a tile costs no address VALU; only the last (ragged) tile of K needs its rows clamped,
+    // and that is a second, precomputed set of offsets chosen by a wave-uniform select.
+    const int nt = (p.Tk + 63) >> 6;
     const int lrow = tid >> 3;
     const int lchunk = (tid & 7) ^ ((tid >> 4) & 7);
-    const int nt = (p.Tk + 63) >> 6;
-    constexpr int NL = 2 * LPT;   // global->LDS instructions per thread per (K, V^T) tile pair: K rows first, then V^T rows
-    auto stage_one = [&](int t, int buf, int q) {
-        char* sK = smem + buf * 16384;
+    unsigned kofs[LPT], kofs_last[LPT], vofs[LPT];
+    const int last_rows = p.Tk - 1 - (nt - 1) * 64;   // highest valid row of the last tile
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int r = i * (NT / 8) + lrow;
+        kofs[i] = (unsigned)(r * p.ldk * 2 + lchunk * 16);
+        kofs_last[i] = (unsigned)((r < last_rows ? r : last_rows) * p.ldk * 2 + lchunk * 16);
+        vofs[i] = (unsigned)(r * p.ldvt * 2 + lchunk * 16);
+    }
+    const size_t k_tile_bytes = (size_t)64 * p.ldk * 2;
+    auto stage_one = [&](int t, int soff, int i) {   // soff = ring slot of tile t, in bytes
+        const int tc = t < nt - 1 ? t : nt - 1;   // past the end: reload the last tile into a ring slot nobody reads any more
+        char* sK = smem + soff;
         char* sV = sK + 8192;
-        if (q < LPT) {
-            const int j = q;
-            int key = t * 64 + j * (NT / 8) + lrow;
-            key = key < p.Tk ? key : p.Tk - 1;
-            glds16(Kb + (size_t)key * p.ldk + lchunk * 8, sK + (j * NT + wave * 64) * 16);
+        if (i < LPT) {
+            const unsigned off = t < nt - 1 ? kofs[i] : kofs_last[i];
+            glds16(Kb + tc * k_tile_bytes + off, sK + (i * NT + wave * 64) * 16);
         } else {
-            const int j = q - LPT;
-            const int d = j * (NT / 8) + lrow;
-            glds16(Vb + (size_t)d * p.ldvt + t * 64 + lchunk * 8, sV + (j * NT + wave * 64) * 16);
+            glds16(Vb + (size_t)tc * 128 + vofs[i - LPT], sV + ((i - LPT) * NT + wave * 64) * 16);
         }
     };
-    auto stage = [&](int t, int buf) {
-#pragma unroll
-        for (int q = 0; q < NL; ++q) stage_one(t, buf, q);
-    };
 
-    f32x16 o[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const int sw = (l31 >> 1) & 7;
-    const int row_off = l31 * 128;
+    // ---- LDS fragment addresses (per lane, tile independent); the ring slot is a scalar added per tile.
     // K fragment rows are read PERMUTED: MFMA row i of S^T holds key swap_bits(2,3)(i).  With that, the 8 P values a lane
     // owns per 16-key block (rows 4*half + (r&3) + 8*(r>>2)) are the 8 CONSECUTIVE keys 16*kb + 8*half + 0..7, i.e. exactly
     // one 16-byte chunk of a V^T row: the PV operand is a conflict-free ds_read_b128 and no lane exchange is needed.
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    const int krow_off = krow * 128;
-    const int ksw = (krow >> 1) & 7;
-
-#ifdef SUPIR_ATTN_TIMELINE
-    unsigned long long tl_sync = 0, tl_issue = 0, tl_qk = 0, tl_sm = 0, tl_pv = 0;
-#endif
-    ATL(tl_t0);
-    {
-        const int pre = nt < S - 1 ? nt : S - 1;
-        for (int t = 0; t < pre; ++t) stage(t, t);
+    const int ksw = (krow >> 1) & 7, vsw = (l31 >> 1) & 7;
+    int kaddr[4], vaddr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        kaddr[i] = krow * 128 + (((2 * i + half) ^ ksw) * 16);          // + hf*4096: K half tile hf, k step i
+        vaddr[i] = 8192 + l31 * 128 + (((2 * i + half) ^ vsw) * 16);    // + df*4096: keys 16*i + 8*half .. +7 of V^T rows df*32 + l31
     }
-    for (int t = 0; t < nt; ++t) {
-        ATL(tl_a);
-        const int buf = t % S;
-        const int rem = nt - 1 - t;
-        const int inflight = rem < S - 2 ? rem : S - 2;   // younger tiles allowed to stay outstanding (4 loads each)
-        if constexpr (S >= 4) {
-            if (inflight >= 2) attn_wait_vmcnt<4 * LPT>();
-            else if (inflight == 1) attn_wait_vmcnt<2 * LPT>();
-            else attn_wait_vmcnt<0>();
-        } else if constexpr (S == 3) {
-            if (inflight >= 1) attn_wait_vmcnt<2 * LPT>();
-            else attn_wait_vmcnt<0>();
-        } else {
-            attn_wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();   // tile t visible to all waves; all waves are done with tile t-1's buffer
-        asm volatile("" ::: "memory");
-        ATL(tl_b);
-        // The next tile pair's global->LDS instructions are spread over the 8 MFMA groups of this iteration (4 in Q.K^T,
-        // 4 in P.V): issued back to back they stall ~550 cycles on the CU's vector-memory path with the matrix pipe idle
-        // (s_memtime, tools/probes/attn_timeline.hip).  The two independent accumulators of each product alternate, so
-        // consecutive MFMAs never wait on each other's result.
-        const bool do_stage = t + S - 1 < nt;
-        const int st_t = t + S - 1, st_buf = (t + S - 1) % S;
-        ATL(tl_c);
-        const char* sK = smem + buf * 16384;
-        const char* sV = sK + 8192;
+    auto load_k = [&](bf16x8 (&kf)[4], int boff, int hf) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)(smem + boff + hf * 4096 + kaddr[ks]);
+    };
+    auto load_v = [&](bf16x8 (&vf)[4], int boff, int hf) {   // vf[kb*2+df]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int df = 0; df < 2; ++df) vf[kb * 2 + df] = *(const bf16x8*)(smem + boff + df * 4096 + vaddr[2 * hf + kb]);
+    };
 
-        // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
-        f32x16 s[2];
+    f32x16 o[2], nm;   // nm = -m_run in every element: the C operand of the first Q.K^T MFMA of each half tile
 #pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
+    for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = nm[r] = 0.f;
+    float l_run = 0.f;
+    const bool tail_mask = (p.Tk & 63) != 0;
+    const bool last_half_empty = tail_mask && (p.Tk & 63) <= 32 && !p.causal;
+    const int klim = p.causal ? (q < p.Tk - 1 ? q : p.Tk - 1) : p.Tk - 1;   // last visible key of this lane's query
+    // four S values (already relative to the running maximum) of a half tile that starts at key k0: mask, fold into mx
+    auto max4 = [&](f32x16& s, float mx, int k0, int j, bool masked) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kf][r] = 0.f;
-        bf16x8 kfr[2][2];
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf) kfr[0][kf] = *(const bf16x8*)(sK + kf * 4096 + krow_off + (((0 + half) ^ ksw) * 16));
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) {
-#pragma unroll
-                for (int kf = 0; kf < 2; ++kf)
-                    kfr[(ks + 1) & 1][kf] = *(const bf16x8*)(sK + kf * 4096 + krow_off + (((2 * (ks + 1) + half) ^ ksw) * 16));
-            }
-            if (do_stage) {
-#pragma unroll
-                for (int q = (ks * NL) / 8; q < ((ks + 1) * NL) / 8; ++q) stage_one(st_t, st_buf, q);
-            }
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf) s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks & 1][kf], qf[ks], s[kf], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            if (masked && k0 + 16 * (r >> 3) + 8 * half + (r & 7) > klim) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
         }
-#ifdef SUPIR_ATTN_TIMELINE
-        asm volatile("s_nop 0" ::"v"(s[0][0]), "v"(s[1][0]));   // force the QK results before the timestamp
-#endif
-        ATL(tl_d);
-        // lane holds query l31, keys t*64 + kf*32 + 16*(r>>3) + 8*half + (r&7)
-        if ((t == nt - 1 && (p.Tk & 63)) || p.causal) {
-            asm volatile("" ::: "memory");   // keep this a (wave-uniform) branch: if-converted it costs 32 v_cndmask per tile
-            const int klim = p.causal ? (q < p.Tk - 1 ? q : p.Tk - 1) : p.Tk - 1;   // last visible key of this lane's query
-#pragma unroll
-            for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + kf * 32 + 16 * (r >> 3) + 8 * half + (r & 7);
-                    if (key > klim) s[kf][r] = -INFINITY;
-                }
-        }
-        float mx = s[0][0];
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kf][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        // the running maximum settles after the first tiles: rescale O and l only when some row's maximum moved
-        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+        return mx;
+    };
+    // s holds S' - m_ref and d = its row maximum (over both lane halves).  m_ref is a REFERENCE, not the exact running maximum:
+    // it is moved (s, nm, O and l rebased) only when some row exceeds it by more than 2^8, so P stays <= 256 -- exact in
+    // fp32, and bf16 keeps its relative precision at any magnitude.  An exact running maximum would take this branch whenever
+    // any of the wave's 32 rows sees a new maximum: most half tiles of the first few hundred keys (86 % at key 512 for i.i.d.
+    // logits), ~70 VALU instructions each time (measured: 29.4 -> 22.9 us at 1024^2, tools/probes/attn_timeline.hip).
+    constexpr float REBASE_AT = 8.0f;
+    auto rebase = [&](f32x16& s, float d) {
+        if (__builtin_amdgcn_ballot_w64(d * pmul > REBASE_AT) != 0) {
             asm volatile("" ::: "memory");
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);
+            d = fmaxf(d, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-d * pmul);
             l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-        m_run = m_new;
-        const float mb = m_new * p.scale_log2e;
-        float psum = 0.f;
-        bf16x8 pf[4];  // pf[kf*2+kb]: keys kf*32 + 16*kb + 8*half + 0..7
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[kf][r] * p.scale_log2e - mb);
-                psum += pv;
-                pf[kf * 2 + (r >> 3)][r & 7] = (bf16_t)pv;
+                s[r] -= d;
+                nm[r] -= d;
+                o[0][r] *= alpha;
+                o[1][r] *= alpha;
             }
-        l_run += psum;
+        }
+    };
+    // P values 4*j .. 4*j+3 of a half tile: exp2, row sum, bf16 pack into the P.V operand.  The empty asm pins the
+    // exponentials to the slot they are written in (otherwise they are sunk to their first use, behind the MFMAs they are
+    // meant to run under).  Plain (unpacked) fp32 VALU on purpose: v_pk_* beside MFMAs issues slower than two scalar ops
+    // (tools/probes/issue_probe.hip).
+    auto exp4 = [&](const f32x16& s, bf16x8 (&pf)[2], int j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            float pv = PRE ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * c);
+            asm volatile("" : "+v"(pv));
+            l_run += pv;
+            pf[r >> 3][r & 7] = (bf16_t)pv;
+        }
+    };
 
 #ifdef SUPIR_ATTN_TIMELINE
-        asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][15]), "v"(pf[3]));
+    unsigned long long tl_sync = 0, tl_a0 = 0, tl_b0 = 0, tl_a1 = 0, tl_b1 = 0;
 #endif
-        ATL(tl_e);
-        // ---- O^T[d][q] += sum_key Vt[d][key] P[q][key]
-        // 16 keys 16*kb4 .. +15 = logical chunks 2*kb4, 2*kb4+1 of the V^T row; lane half h takes chunk 2*kb4+h
-        bf16x8 vfr[2][2];
+    ATL(tl_t0);
+    // ---- prologue: tiles 0 .. S-2 in flight, tiles 0 and 1 awaited, S(0, half 0) and its maximum computed un-overlapped
 #pragma unroll
-        for (int df = 0; df < 2; ++df) vfr[0][df] = *(const bf16x8*)(sV + df * 4096 + row_off + (((0 + half) ^ sw) * 16));
+    for (int t = 0; t < S - 1; ++t)
 #pragma unroll
-        for (int kb4 = 0; kb4 < 4; ++kb4) {
-            if (kb4 < 3) {
+        for (int i = 0; i < NL; ++i) stage_one(t, t * 16384, i);
+    // Q carries the softmax scale (log2 units) from here on: S' = (c Q).K^T, so that P = exp2(S' - m) needs no multiply per
+    // element; the MFMA's C operand supplies the "- m" (nm).  One extra bf16 rounding of Q (2^-9 relative, averaged over the
+    // 64-term dot product) against 32 VALU instructions per lane per tile.
 #pragma unroll
-                for (int df = 0; df < 2; ++df)
-                    vfr[(kb4 + 1) & 1][df] = *(const bf16x8*)(sV + df * 4096 + row_off + (((2 * (kb4 + 1) + half) ^ sw) * 16));
-            }
-            if (do_stage) {
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 raw = *(const bf16x8*)(Qp + 16 * ks);
 #pragma unroll
-                for (int q = ((kb4 + 4) * NL) / 8; q < ((kb4 + 5) * NL) / 8; ++q) stage_one(st_t, st_buf, q);
-            }
+        for (int e = 0; e < 8; ++e) qf[ks][e] = PRE ? (bf16_t)((float)raw[e] * c) : raw[e];
+    }
+    bf16x8 kA[4], vA[4], pf[2];
+    f32x16 sa, sb;
+    attn_wait_vmcnt<(S - 3) * NL>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_k(kA, 0, 0);
+    sa = nm;
 #pragma unroll
-            for (int df = 0; df < 2; ++df) o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb4 & 1][df], pf[kb4], o[df], 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[ks], qf[ks], sa, 0, 0, 0);
+    load_k(kA, 0, 1);
+    {
+        const bool mk = (nt == 1 && tail_mask) || p.causal;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = max4(sa, mx, 0, j, mk);
+        mx = xhalf_max(mx);   // finite: key 0 is visible to every query
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sa[r] -= mx;
+            nm[r] = -mx;
+        }
+    }
+
+    // One tile.  MASKED (compile time) = this iteration produces half tiles that may hold keys past the end / past the
+    // diagonal: only the last two iterations of a ragged launch, or every iteration of a causal one, so that the common
+    // loop body is straight-line code between the two (rare) rebase branches.
+    int boff = 0;   // ring slot of the current tile (bytes), carried as a scalar
+    auto tile = [&](const int t, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
+        const int nboff = __builtin_amdgcn_readfirstlane(boff + 16384 == S * 16384 ? 0 : boff + 16384);
+        const int soff = __builtin_amdgcn_readfirstlane(boff == 0 ? (S - 1) * 16384 : boff - 16384);   // slot of tile t-1 = of tile t+S-1
+        ATL(tl_0);
+        if (t > 0) {
+            // tile t+1 landed (issued one tile ago); every wave is done with tile t-1, whose ring slot takes tile t+S-1
+            attn_wait_vmcnt<(S - 3) * NL>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        ATL(tl_1);
+        // ================= half 0: P(t,0) from sa, S(t,1) into sb =================
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[j], qf[j], j == 0 ? nm : sb, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 0) load_v(vA, boff, 0);   // after the MFMA: it must not wait for these reads, only for kA's
+            exp4(sa, pf, j);
+#pragma unroll
+            for (int i = j * NL / 4; i < (j + 1) * NL / 4; ++i) stage_one(t + S - 1, soff, i);
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef SUPIR_ATTN_TIMELINE
-        asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][15]));
+        asm volatile("s_nop 0" ::"v"(sb[0]), "v"(pf[1]));
+#endif
+        ATL(tl_2);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[j], pf[j >> 1], o[j & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 0) load_k(kA, nboff, 0);   // past the last tile: a ring slot nobody waits for; its products are never used
+            mx = max4(sb, mx, t * 64 + 32, j, MASKED);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rebase(sb, xhalf_max(mx));
+#ifdef SUPIR_ATTN_TIMELINE
+        asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][15]), "v"(sb[0]));
+#endif
+        ATL(tl_3);
+        // ================= half 1: P(t,1) from sb, S(t+1,0) into sa =================
+        if (MASKED && t == nt - 1 && last_half_empty) return;   // nothing but masked keys left (Tk % 64 in 1..32): P = 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[j], qf[j], j == 0 ? nm : sa, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 0) load_v(vA, boff, 1);
+            exp4(sb, pf, j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef SUPIR_ATTN_TIMELINE
+        asm volatile("s_nop 0" ::"v"(sa[0]), "v"(pf[1]));
+#endif
+        ATL(tl_4);
+        mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[j], pf[j >> 1], o[j & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 0) load_k(kA, nboff, 1);
+            mx = max4(sa, mx, (t + 1) * 64, j, MASKED);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 1 < nt) rebase(sa, xhalf_max(mx));
+        boff = nboff;
+#ifdef SUPIR_ATTN_TIMELINE
+        asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][15]), "v"(sa[0]));
         {
-            ATL(tl_f);
-            tl_sync += tl_b - tl_a;
-            tl_issue += tl_c - tl_b;
-            tl_qk += tl_d - tl_c;
-            tl_sm += tl_e - tl_d;
-            tl_pv += tl_f - tl_e;
+            ATL(tl_5);
+            tl_sync += tl_1 - tl_0;
+            tl_a0 += tl_2 - tl_1;
+            tl_b0 += tl_3 - tl_2;
+            tl_a1 += tl_4 - tl_3;
+            tl_b1 += tl_5 - tl_4;
         }
 #endif
-    }
+    };
+    const int n_plain = p.causal ? 0 : (tail_mask ? (nt - 2 > 0 ? nt - 2 : 0) : nt);
+    int t = 0;
+    for (; t < n_plain; ++t) tile(t, attn_flag<false>{});
+    for (; t < nt; ++t) tile(t, attn_flag<true>{});
     ATL(tl_loop1);
+    attn_wait_vmcnt<0>();   // the reloads issued by the last S-1 iterations still target this workgroup's LDS
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -265,12 +333,12 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_kernel(const AttnArgs p) {
     if (g_atl_buf && lane == 0) {
         ATL(tl_end);
         unsigned long long* ob = g_atl_buf + ((size_t)blockIdx.x * NW + wave) * 8;
-        ob[0] = tl_t0;
+        ob[0] = tl_loop1 - tl_t0;   // prologue + loop
         ob[1] = tl_sync;
-        ob[2] = tl_issue;
-        ob[3] = tl_qk;
-        ob[4] = tl_sm;
-        ob[5] = tl_pv;
+        ob[2] = tl_a0;
+        ob[3] = tl_b0;
+        ob[4] = tl_a1;
+        ob[5] = tl_b1;
         ob[6] = tl_end - tl_loop1;
         ob[7] = tl_end - tl_t0;
     }
@@ -281,15 +349,10 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0) return SUPIR_ERR_ARG;
     if ((a.ldq | a.ldk | a.ldvt) % 8 != 0 || a.ldo % 4 != 0) return SUPIR_ERR_SHAPE;
     if (a.ldvt < ((a.Tk + 63) / 64) * 64) return SUPIR_ERR_SHAPE;
-    static int force_nw = -1;   // SUPIR_ATTN_NW=2|4 pins the workgroup size (tools/attn_probe.py)
-    if (force_nw < 0) {
-        const char* e = getenv("SUPIR_ATTN_NW");
-        force_nw = e ? atoi(e) : 0;
-    }
-    const int blocks4 = ((a.Tq + 127) / 128) * a.H * a.B;
-    const bool small = force_nw == 2;   // measured: the 2-wave form is never faster (the kernel is VALU-bound, not occupancy-bound)
-    if (small) SUPIR_LAUNCH((attn_d64_kernel<2, 2>), dim3(((a.Tq + 63) / 64) * a.H * a.B), dim3(128), 0, st, a);
-    else SUPIR_LAUNCH((attn_d64_kernel<2, 4>), dim3(blocks4), dim3(256), 0, st, a);
+    // ring depth 3 (4 measured equal or slower), 4 waves = 128 queries per workgroup (2 waves measured slower on every shape),
+    // softmax scale folded into Q (6-10 % faster than a multiply per element; network-level parity unchanged:
+    // profiles/r02/attn_pipelined_network_parity_and_step.log)
+    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true>), dim3(((a.Tq + 127) / 128) * a.H * a.B), dim3(256), 0, st, a);
     return SUPIR_LAUNCH_STATUS();
 }
 

@@ -47,18 +47,22 @@ int main() {
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const int blocks4 = ((s.Tq + 127) / 128) * s.H * s.B;
-        const bool small = blocks4 < 512;
-        const int nblk = small ? ((s.Tq + 63) / 64) * s.H * s.B : blocks4, nwv = small ? 2 : 4;
+        const int nblk = blocks4, nwv = 4;
         const int nw = nblk * nwv, nt = (s.Tk + 63) / 64;
         std::vector<unsigned long long> h((size_t)nw * 8);
         CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
-        double sum[8] = {0};
-        for (int w = 0; w < nw; ++w)
-            for (int c = 1; c < 8; ++c) sum[c] += (double)h[(size_t)w * 8 + c];
-        printf("B=%d H=%d Tq=%d Tk=%d blocks=%d x %d waves | event %.1f us, TF %.0f | per KV tile (%d): sync %.0f  issue %.0f  QK %.0f  softmax %.0f  PV %.0f | "
-               "epilogue %.0f | total %.0f\n",
+        double sum[8] = {0}, mx_total = 0, mx_loop = 0;
+        for (int w = 0; w < nw; ++w) {
+            for (int c = 0; c < 8; ++c) sum[c] += (double)h[(size_t)w * 8 + c];
+            if ((double)h[(size_t)w * 8 + 7] > mx_total) mx_total = (double)h[(size_t)w * 8 + 7];
+            if ((double)h[(size_t)w * 8 + 0] > mx_loop) mx_loop = (double)h[(size_t)w * 8 + 0];
+        }
+        // sync = vmcnt wait + barrier, A0/A1 = Q.K^T(next half) beside exp(this half), B0/B1 = P.V beside the row maximum + rebase
+        printf("B=%d H=%d Tq=%d Tk=%d blocks=%d x %d waves | event %.1f us, TF %.0f | per KV tile (%d): sync %.0f  A0 %.0f  B0 %.0f  A1 %.0f  B1 %.0f "
+               "(sum %.0f) | prologue+loop %.0f (max %.0f) epilogue %.0f | total avg %.0f max %.0f ticks\n",
                s.B, s.H, s.Tq, s.Tk, nblk, nwv, ms * 1000 / 20, 4.0 * s.B * s.H * s.Tq * s.Tk * 64 / (ms * 1e-3 / 20) / 1e12, nt,
-               sum[1] / nw / nt, sum[2] / nw / nt, sum[3] / nw / nt, sum[4] / nw / nt, sum[5] / nw / nt, sum[6] / nw, sum[7] / nw);
+               sum[1] / nw / nt, sum[2] / nw / nt, sum[3] / nw / nt, sum[4] / nw / nt, sum[5] / nw / nt,
+               (sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / nw / nt, sum[0] / nw, mx_loop, sum[6] / nw, sum[7] / nw, mx_total);
         fflush(stdout);
         CK(hipFree(Q)); CK(hipFree(K)); CK(hipFree(Vt)); CK(hipFree(O));
     }
