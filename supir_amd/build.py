@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm16.hip", "attention.hip", "norm.hip", "edge.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm16.hip", "gemm_big.hip", "attention.hip", "norm.hip", "edge.hip", "api.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "supir_hip.h")]
 LIB = os.path.join(HERE, "libsupir_hip.so")
 

@@ -73,6 +73,9 @@ void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv);
 int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv);
 int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st);
+// gemm_big.hip: tile 37 = 256 x 320, activation operand global -> VGPR, GEGLU epilogue (16-row value / gate interleave)
+bool supir_gemm_big_supported(const GemmArgs& a);
+int supir_gemm_big_launch(const GemmArgs& a, hipStream_t st);
 int supir_attn_launch(const AttnArgs& a, hipStream_t st);
 int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, int Tpad, long lds_, long ldp, float scale,
                               hipStream_t st);

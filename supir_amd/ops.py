@@ -61,6 +61,8 @@ def finish_timing(trace):
 
 
 def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
+    if tile == 37:
+        return "geglu_big_kernel<256,320,4x2,a-direct>"
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}>"
@@ -266,7 +268,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
     om = 0 if out.dtype == BF16 else 1
 
     def launch(t, outp=None):
-        wq, bq = (alt16[0], alt16[1]) if (t == 34 and act == 2 and alt16 is not None) else (w, bias)
+        wq, bq = (alt16[0], alt16[1]) if (t in (34, 37) and act == 2 and alt16 is not None) else (w, bias)
         return lib.supir_gemm_bf16(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
                                    _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, act, om, alpha, t, _stream())
 
@@ -295,10 +297,11 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
 
 _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
-               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1)}
+               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2)}
 G16_TILES = {32, 33, 34, 35}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
 _G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3)}   # tile: (BM, BN, K groups, ring)
 USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc/gemm16.hip) in the autotune lists
+USE_GEMM_BIG = _os.environ.get("SUPIR_GEMM_BIG", "1") != "0"   # tile 37 (csrc/gemm_big.hip) in the GEGLU autotune lists
 
 
 def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu16=False):
@@ -319,6 +322,9 @@ def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu1
         if act == 2 and not (t == 34 and geglu16):
             continue
         extra.append(t)
+    # tile 37 (csrc/gemm_big.hip): 256 x 320, activation operand global -> VGPR, GEGLU only; same predicate as supir_gemm_big_supported
+    if act == 2 and geglu16 and USE_GEMM_BIG and om == 0 and M % 256 == 0 and N % 320 == 0 and K % 64 == 0 and K >= 128 and ln_slots <= 64:
+        extra.append(37)
     return base + tuple(extra)
 
 
@@ -383,7 +389,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
         assert colsum is not None and colsum.numel() == N
 
     def launch(t, outp=None):
-        wq, cq, bq = alt16 if (t == 34 and act == 2 and alt16 is not None) else (w, colsum, bias)
+        wq, cq, bq = alt16 if (t in (34, 37) and act == 2 and alt16 is not None) else (w, colsum, bias)
         return lib.supir_gemm_bf16_ln(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
                                       _p(bq), _p(residual), ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots,
                                       _p(cq), ln_eps, _stream())

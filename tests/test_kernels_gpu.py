@@ -599,6 +599,52 @@ def test_gemm16_geglu(M, K, N2):
     check(ops.gemm_ln(x, wf16, bf16_, act=2, ln=st, colsum=cs16, tile=34), vr * F.gelu(gr), rel=8e-3, name="geglu16 ln-fold")
 
 
+@pytest.mark.parametrize("M,K,N2", [(2048, 1280, 10240), (8192, 640, 5120), (256, 128, 640), (512, 320, 1280)])
+def test_gemm_big_geglu(M, K, N2):
+    """Tile 37 (csrc/gemm_big.hip: 256 x 320, activation operand global -> VGPR, GEGLU epilogue): the reference formula
+    (sgm/modules/attention.py:89-91), bitwise repeatability, agreement with the 256 x 160 tile, the LayerNorm fold from partial
+    and from finalised row statistics, a strided A operand, and rejection of shapes the tile does not fit."""
+    from supir_amd.weights import fold_layernorm, interleave_geglu
+    a = rnd(M, K).to(BF)
+    w = rnd(N2, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N2, seed=2)
+    w16, b16 = interleave_geglu(w, bias, 16)
+    out = ops.gemm(a, w16, b16, act=2, tile=37)
+    y = a.float() @ w.float().T + bias
+    v, g = y.chunk(2, dim=-1)
+    check(out, v * F.gelu(g), name="geglu big")
+    assert torch.equal(out, ops.gemm(a, w16, b16, act=2, tile=37))
+    if N2 % 160 == 0 and K >= 128:
+        check(out, ops.gemm(a, w16, b16, act=2, tile=34).float(), rel=3e-3, name="geglu big vs tile 34")
+    v0, g0 = (a.float() @ w.float().T).chunk(2, dim=-1)
+    check(ops.gemm(a, w16, None, act=2, tile=37), v0 * F.gelu(g0), name="geglu big, no bias")
+    # strided A (a column slice of a wider buffer)
+    wide = torch.zeros(M, K + 64, dtype=BF, device=DEV)
+    wide[:, :K] = a
+    assert torch.equal(ops.gemm(wide[:, :K], w16, b16, act=2, tile=37), out)
+    # LayerNorm fold, statistics as the producer GEMM leaves them (partials) and finalised
+    C = K
+    wp = rnd(C, C, scale=C ** -0.5, seed=5).to(BF)
+    x, st = ops.gemm_ln(a, wp, None, emit_stats=True)
+    gamma, beta = rnd(C, seed=6) * 0.2 + 1.0, rnd(C, seed=7) * 0.2
+    wf, cs, bf_ = fold_layernorm(w.float(), bias, gamma, beta)
+    wf16, bf16_ = interleave_geglu(wf, bf_, 16)
+    _, cs16 = interleave_geglu(wf, cs, 16)
+    yr = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T + bias
+    vr, gr = yr.chunk(2, dim=-1)
+    o_ln = ops.gemm_ln(x, wf16, bf16_, act=2, ln=st, colsum=cs16, tile=37)
+    check(o_ln, vr * F.gelu(gr), rel=8e-3, name="geglu big ln-fold")
+    o_fin = ops.gemm_ln(x, wf16, bf16_, act=2, ln=ops.rowstats_finalize(st, C, 1e-5), colsum=cs16, tile=37)
+    check(o_fin, vr * F.gelu(gr), rel=8e-3, name="geglu big ln-fold (finalised statistics)")
+    # autotuned call with both layouts available stays correct whichever tile wins
+    w32, b32 = interleave_geglu(w, bias, 32)
+    check(ops.gemm(a, w32, b32, act=2, alt16=(w16, b16)), v * F.gelu(g), name="geglu auto")
+    # shapes the tile does not fit are refused, not mis-computed
+    from supir_amd._lib import SupirHipError
+    with pytest.raises(SupirHipError):
+        ops.gemm(a[: M - 64], w16, b16, act=2, tile=37)
+
+
 G16_CONV_CASES = [
     # B, H, W, Cin, Cout, stride, pad(top,left), upsample, out_hw   (UNet / VAE shapes whose output grid is an exact tile multiple)
     (2, 32, 32, 1280, 1280, 1, (1, 1), False, None),

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 CSRC = os.path.join(ROOT, "supir_amd", "csrc")
 OUT = "/tmp/libsupir_hip_tl.so"
-srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "gemm16.hip", "attention.hip", "norm.hip", "edge.hip", "api.hip")]
+srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "gemm16.hip", "gemm_big.hip", "attention.hip", "norm.hip", "edge.hip", "api.hip")]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
        "-DSUPIR_G16_TIMELINE"] + srcs + ["-o", OUT]
 subprocess.check_call(cmd)
@@ -20,20 +20,29 @@ lib = ctypes.CDLL(OUT)
 P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 lib.supir_gemm_bf16.argtypes = [P, P, P, I, I, I, I, I, P, P, I, I, P, I, I, I, F, I, P]
 lib.supir_g16_tl_set.argtypes = [P]
+lib.supir_big_tl_set.argtypes = [P]
 BF = torch.bfloat16
-for (M, N, K, tile) in [(2048, 1280, 1280, 35), (2048, 1280, 1280, 32), (2048, 1280, 5120, 35), (2048, 2560, 1280, 33), (2048, 10240, 1280, 34)]:
+CASES = [(2048, 1280, 1280, 35), (2048, 1280, 1280, 32), (2048, 1280, 5120, 35), (2048, 2560, 1280, 33), (2048, 10240, 1280, 34)]
+if len(sys.argv) > 1 and sys.argv[1] == "geglu":   # the GEGLU projection on the 256 x 160 and the 256 x 320 tile, several K and M
+    CASES = [(2048, 10240, 1280, 34), (2048, 10240, 1280, 37), (2048, 10240, 640, 37), (2048, 10240, 2560, 37), (4096, 10240, 1280, 37),
+             (8192, 5120, 640, 37)]
+for (M, N, K, tile) in CASES:
     a = torch.randn(M, K, device="cuda").to(BF)
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
     res = torch.randn(M, N, device="cuda").to(BF)
     bias = torch.randn(N, device="cuda")
     out = torch.empty(M, N, device="cuda", dtype=BF)
-    bm, bn = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80)}[tile]
+    geglu = len(sys.argv) > 1 and sys.argv[1] == "geglu"
+    bm, bn = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320)}[tile]
     nwg = (M // bm) * (N // bn)
     buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device="cuda")
-    lib.supir_g16_tl_set(buf.data_ptr())
+    (lib.supir_big_tl_set if tile == 37 else lib.supir_g16_tl_set)(buf.data_ptr())
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
+        if geglu:
+            return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, K, N // 2, bias.data_ptr(), None, 0, 0,
+                                       None, 0, 2, 0, 1.0, tile, st)
         return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, K, N, bias.data_ptr(), None, 0, 0,
                                    res.data_ptr(), N, 0, 0, 1.0, tile, st)
     for _ in range(5):
@@ -47,8 +56,10 @@ for (M, N, K, tile) in [(2048, 1280, 1280, 35), (2048, 1280, 1280, 32), (2048, 1
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     t = buf.view(nwg * 8, 8).cpu().double()
-    nk = (K // 64) // (1 if tile == 34 else 2)
+    nk = (K // 64) // (1 if tile in (34, 37) else 2)
     print(f"M={M} N={N} K={K} tile={tile} wgs={nwg} | event {us:.1f} us | per wave (cycles): prologue "
           f"{t[:, 1].mean():.0f}  loop {t[:, 2].mean():.0f} ({t[:, 2].mean() / nk:.0f} per K step x {nk})  exchange {t[:, 3].mean():.0f}  "
           f"epilogue {t[:, 4].mean():.0f}  total {t[:, 5].mean():.0f} (max {t[:, 5].max():.0f})", flush=True)
-    lib.supir_g16_tl_set(None)
+    (lib.supir_big_tl_set if tile == 37 else lib.supir_g16_tl_set)(None)
+    t0 = t[:, 0]
+    print(f"    start skew over waves: {t0.max() - t0.min():.0f} ticks; end skew {t[:, 6].max() - t[:, 6].min():.0f}; first start -> last end {t[:, 6].max() - t0.min():.0f}", flush=True)
