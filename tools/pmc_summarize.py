@@ -13,8 +13,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in files:
     with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
-            name = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"]))
-            if not (name.startswith("gemm") or name.startswith("attn") or name.startswith("gn_")):
+            name = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", ""))
+            if not (name.startswith("gemm") or name.startswith("geglu") or name.startswith("attn") or name.startswith("gn_")):
                 continue
             key = f"{name} grid={r['Grid_Size']}"
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -14,5 +14,5 @@ done
 python $GRAFT_REPO_ROOT/tools/pmc_summarize.py $O/pmc_summary.json $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/pmc_SQ_WAVE_CYCLES.csv
 rm -rf $O/raw_*
 # keep the CSVs small: only our kernels
-for f in $O/pmc_*.csv; do (head -1 $f; grep -E "gemm16_kernel|gemm_bf16_kernel|attn_d64|gn_" $f) > $f.tmp && mv $f.tmp $f; done
+for f in $O/pmc_*.csv; do (head -1 $f; grep -E "gemm16_kernel|gemm_bf16_kernel|geglu_big|attn_d64|gn_" $f) > $f.tmp && mv $f.tmp $f; done
 ls -la $O
