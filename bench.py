@@ -324,32 +324,52 @@ def main():
                          "gbps": round(v["bytes"] / v["us"] / 1e3, 1),
                          "frac_of_peak": round(v["flops"] / v["us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 3) if v["flops"]
                          else round(v["bytes"] / v["us"] / 1e3 / HBM_PEAK_GBPS, 3)} for k, v in agg.items()}
-        # the dominant kernel = the (instantiation, problem shape) with the largest share of the step: one instantiation serves
-        # shapes of very different work per launch (128x80 tile: K = 1280 and K = 5120), and the roofline figure is per launch
-        (name, dom_shape), v = max(by_shape.items(), key=lambda kv: kv[1]["us"])
-        if v["flops"] > 0:
-            ach = v["flops"] / v["launches"] / (v["us"] / v["launches"] * 1e-6) / 1e12
-            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                        "launches_per_unet_step": v["launches"], "avg_launch_us": round(v["us"] / v["launches"], 2),
-                        "algorithmic_gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3),
-                        "algorithmic_mb_per_launch": round(v["bytes"] / v["launches"] / 1e6, 3), "shape": dom_shape,
-                        "share_of_step_time": round(v["us"] / total_us, 3)}
-        else:
-            ach = v["bytes"] / (v["us"] * 1e-6) / 1e9
-            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None}
+        # the dominant kernel = the kernel (instantiation) with the largest share of the step; achieved = its algorithmic FLOPs (bytes)
+        # over its launch time, i.e. the average over its launches -- the figure rocprofv3's per-kernel average duration can be held
+        # against.  One instantiation serves shapes of very different work per launch (128x80 tile: K = 1280 and K = 5120), so the
+        # per-shape figures and the counter-measured traffic of each shape are listed under `shapes`.
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         traffic = {}
         if os.path.exists(pmc):   # HBM / fabric-side bytes per launch from the committed rocprofv3 --pmc passes (per shape)
             try:
                 traffic = json.load(open(pmc))
-                tr_e = traffic.get(name)
-                if isinstance(tr_e, list):   # per-shape entries: pick this shape's
-                    tr_e = next((e for e in tr_e if dom_shape and e.get("shape", "").replace(" geglu", "") in dom_shape), tr_e)
-                roofline["traffic"] = tr_e
             except Exception:
-                pass
+                traffic = {}
+
+        def shape_traffic(kname, shp):
+            tr_e = traffic.get(kname)
+            if isinstance(tr_e, list):
+                return next((e for e in tr_e if shp and e.get("shape", "").replace(" geglu", "") in shp), None)
+            return tr_e
+
+        name, v = max(agg.items(), key=lambda kv: kv[1]["us"])
+        shapes = []
+        for (kn, shp), sv in sorted(by_shape.items(), key=lambda kv: -kv[1]["us"]):
+            if kn != name:
+                continue
+            e = {"shape": shp, "launches": sv["launches"], "avg_launch_us": round(sv["us"] / sv["launches"], 2),
+                 "share_of_step_time": round(sv["us"] / total_us, 3)}
+            if sv["flops"] > 0:
+                e.update(tflops=round(sv["flops"] / sv["us"] / 1e6, 1), frac=round(sv["flops"] / sv["us"] / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4),
+                         algorithmic_gflop_per_launch=round(sv["flops"] / sv["launches"] / 1e9, 3))
+            else:
+                e.update(gbps=round(sv["bytes"] / sv["us"] / 1e3, 1), frac=round(sv["bytes"] / sv["us"] / 1e3 / HBM_PEAK_GBPS, 4))
+            e["algorithmic_mb_per_launch"] = round(sv["bytes"] / sv["launches"] / 1e6, 3)
+            e["traffic"] = shape_traffic(kn, shp)
+            shapes.append(e)
+        if v["flops"] > 0:
+            ach = v["flops"] / v["us"] / 1e6
+            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4)}
+        else:
+            ach = v["bytes"] / v["us"] / 1e3
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBPS, 4)}
+        roofline.update(traffic=(shapes[0]["traffic"] if shapes else None), launches_per_unet_step=v["launches"],
+                        avg_launch_us=round(v["us"] / v["launches"], 2),
+                        algorithmic_gflop_per_launch=round(v["flops"] / v["launches"] / 1e9, 3),
+                        algorithmic_mb_per_launch=round(v["bytes"] / v["launches"] / 1e6, 3),
+                        share_of_step_time=round(v["us"] / total_us, 3), shapes=shapes)
         # the same figures for every kernel class that takes >= 3 % of the step (the dominant one is `roofline`)
         by_kernel = []
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):

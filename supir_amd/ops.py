@@ -62,7 +62,7 @@ def finish_timing(trace):
 
 def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
     if tile == 37:
-        return "geglu_big_kernel<256,320,4x2,a-direct>"
+        return "geglu_big_kernel<256,320,4x2>"
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}>"
