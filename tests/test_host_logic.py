@@ -376,3 +376,23 @@ def test_builtin_config_mirrors_the_reference_yaml_scalars():
     assert p["scale_factor"] == 0.13025 and p["ae_dtype"] == "bf16" and p["disable_first_stage_autocast"] is True
     assert p["network_wrapper"] == "sgm.modules.diffusionmodules.wrappers.ControlWrapper"
     assert p["sampler_config"]["params"]["guider_config"]["params"] == {"scale": 7.5, "scale_min": 4.0}
+
+
+def test_gemm_autotune_candidate_lists_follow_the_kernel_predicates():
+    """The Python mirror offers a forced tile to the autotuner only where the C-ABI accepts it (supir_gemm16_supported /
+    supir_gemm_big_supported): exact tile multiples, ring depth vs K, GEGLU only with the 16-row interleave on tiles 34 / 37."""
+    from supir_amd import ops
+    c = ops._gemm_candidates
+    base = (0, 1, 2, 3, 4, 5, 6)
+    assert set(c(2048, 1360, 1280, 0, 0, 1360)) == set(base) | {32, 35}            # 128 x 80; not 33 / 34 (N % 160)
+    assert set(c(2048, 1280, 1280, 0, 0, 1280)) == set(base) | {32, 33, 34, 35}
+    assert set(c(2048, 1280, 64, 0, 0, 1280)) == set(base)                         # K too short for two K groups
+    assert set(c(2048, 1280, 1280, 0, 1, 1280)) == set(base)                       # fp32 output: old tiles only
+    assert set(c(2048, 1280, 1280, 0, 0, 1284)) == set(base)                       # ldc % 8
+    geglu = (0, 2, 4, 5, 6)
+    assert set(c(2048, 10240, 1280, 2, 0, 5120)) == set(geglu)                     # no 16-row interleave supplied
+    assert set(c(2048, 10240, 1280, 2, 0, 5120, geglu16=True)) == set(geglu) | {34, 37}
+    assert set(c(8192, 5120, 640, 2, 0, 2560, geglu16=True)) == set(geglu) | {34, 37}
+    assert set(c(2048, 2400, 1280, 2, 0, 1200, geglu16=True)) == set(geglu) | {34}   # N % 320
+    assert set(c(2048 + 128, 10240, 1280, 2, 0, 5120, geglu16=True)) == set(geglu)   # M % 256
+    assert ops.gemm_tile_name(2048, 10240, act=2, tile=37).startswith("geglu_big_kernel")
