@@ -281,6 +281,20 @@ def main():
 
     for i in range(args.warmup):
         out = one_image(model, x, (c, uc), 1234 + rank, args.edm_steps)
+    autotune_resynced = None
+    if world > 1 and args.warmup > 0:
+        # every rank runs the kernels rank 0 picked (per-process autotune can otherwise differ at near-ties, i.e. replicas that
+        # differ at the bf16 noise floor); a rank whose picks changed re-captures its graphs in one more untimed image
+        from supir_amd import parallel
+        changed = parallel.sync_autotune(src=0)
+        if changed and not args.no_graph:
+            model.model.enable_graph(False)
+            model.model.enable_graph(True)
+        ch = torch.tensor([changed], device=device)
+        dist.all_reduce(ch, op=dist.ReduceOp.MAX)
+        if int(ch.item()) > 0:   # all ranks run the extra image (keeps them in step; the unchanged ones just replay)
+            out = one_image(model, x, (c, uc), 1234 + rank, args.edm_steps)
+        autotune_resynced = int(ch.item())
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -426,7 +440,7 @@ def main():
                        "images_per_gpu_per_step": ipg, "parallelism": f"dp{world} (replicated weights, no collective inside a sample)",
                        "hip_graph": not args.no_graph,
                        "two_stream_overlap": bool(model.model.overlap_branches)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "autotune_entries_resynced_max_over_ranks": autotune_resynced,
             "output_finite": finite, "weight_fill_s": round(t_fill, 2), "weight_broadcast_s": round(t_bcast, 2),
             "end_to_end_tflops_per_gpu": IMAGE_TFLOP_1024 * args.steps * ipg / dt if P == 1024 and args.edm_steps == 50 else None,
             "kernel_breakdown_unet_step": breakdown,

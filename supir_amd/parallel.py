@@ -68,3 +68,27 @@ def gather_images(local, n_items, device="cpu"):
     for o in objs:
         merged.update(o)
     return [merged[i] for i in range(n_items)]
+
+
+def sync_autotune(src=0, group=None):
+    """Every rank adopts rank `src`'s autotune winners (ops._TUNE: tile per GEMM / conv shape; ops._CHOICE: launch-sequence
+    alternatives such as fused vs separate q|k|v).  Tuning is per process and two near-equal candidates can win on different
+    ranks, which makes the ranks' results differ at the bf16 noise floor; after this call they run the same kernels, so replicas
+    (and the tiles of a tile-parallel sample) are bit-identical given identical inputs.  Call it after a warm-up pass has tuned
+    the shapes in use and BEFORE graphs are captured for the timed / production calls (a changed pick invalidates captured
+    graphs: re-run ControlWrapper.enable_graph).  Returns the number of entries that changed on this rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    from . import ops
+    payload = [None]
+    if dist.get_rank(group) == src:
+        payload = [(list(ops._TUNE.items()), list(ops._CHOICE.items()))]
+    dist.broadcast_object_list(payload, src=src, group=group)
+    tune, choice = payload[0]
+    changed = sum(1 for k, v in tune if ops._TUNE.get(k) != v) + sum(1 for k, v in choice if ops._CHOICE.get(k) != v)
+    changed += sum(1 for k in list(ops._TUNE) if k not in dict(tune)) + sum(1 for k in list(ops._CHOICE) if k not in dict(choice))
+    ops._TUNE.clear()
+    ops._TUNE.update(dict(tune))
+    ops._CHOICE.clear()
+    ops._CHOICE.update(dict(choice))
+    return changed

@@ -44,6 +44,17 @@ def _worker(rank, world, port, q):
     parallel.broadcast_module_(vae2, src=0, bucket_elems=50_000, payload_dtype=torch.bfloat16)
     same = same and all(torch.equal(a, b.to(torch.bfloat16).to(b.dtype)) and a.dtype == torch.float32
                         for (k, a), b in zip(vae2.state_dict().items(), ref.state_dict().values()) if a.is_floating_point())
+    # autotune winners: ranks that tuned differently end with rank 0's picks
+    from supir_amd import ops
+    ops._TUNE.clear(); ops._CHOICE.clear()
+    ops._TUNE[("gemm", 2048, 1280, 1280, 0, 0)] = 35 if rank == 0 else 32
+    ops._TUNE[("gemm", 2048, 10240, 1280, 2, 0)] = 37
+    if rank == 1:
+        ops._TUNE[("gemm", 64, 64, 64, 0, 0)] = 3            # only rank 1 saw this shape: dropped (rank 0 will tune it when it meets it)
+    ops._CHOICE[("qkv", 2048, 1280)] = 1 if rank == 0 else 0
+    n_changed = parallel.sync_autotune()
+    same = same and n_changed == (0 if rank == 0 else 3) and ops._TUNE == {("gemm", 2048, 1280, 1280, 0, 0): 35, ("gemm", 2048, 10240, 1280, 2, 0): 37} \
+        and ops._CHOICE == {("qkv", 2048, 1280): 1}
     mine = parallel.shard_items(5)
     t = parallel.max_over_ranks(1.0 + rank)
     imgs = parallel.gather_images({i: torch.full((3, 2, 2), float(i)) for i in mine}, 5)
