@@ -146,6 +146,22 @@ int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, cons
                          const void* mod_b, int ldm, float control_scale, void* out, int ldo, float* workspace,
                          size_t workspace_bytes, const float* given_mean_var, void* stream);
 
+/* GroupNorm with the statistics supplied by the PRODUCER of its input(s) instead of a statistics pass over the tensor:
+ *   supir_set_next_gn_partials(buf) -- per calling thread, one-shot (like supir_set_next_prefetch): the next supir_gemm_bf16 /
+ *     supir_gemm_bf16_ln / supir_conv3x3_bf16 launch (tiles 32..35 only, bf16 row-major output, rows_per_batch % BM == 0,
+ *     N % 10 == 0; anything else -> SUPIR_ERR_SHAPE) also writes, per batch b, tile row c (BM = 128 or 256 tokens) and 10-channel
+ *     unit u, the (sum, sum of squares) of the bf16 values it stored: buf[((b * (rows_per_batch / BM) + c) * (N / 10) + u) * 2 + {0,1}];
+ *   supir_groupnorm_nhwc_parts(..., part1, nchunk1, part2, nchunk2, stream) -- supir_groupnorm_nhwc with those buffers for x1
+ *     (and x2 when C1 < C; each source with its own chunk count) in place of workspace / given_mean_var: one launch, no
+ *     statistics pass.  Needs (C / 32) % 10 == 0 and C1 % 10 == 0 (every GroupNorm32 of the UNet / control net qualifies).
+ * Replaces the statistics half of GroupNorm32 (sgm/modules/diffusionmodules/util.py:258-276) wherever the input comes straight
+ * out of a convolution or linear layer (openaimodel.py:295-308 out_layers, :260-264 in_layers, attention.py:583-586 norm). */
+int supir_set_next_gn_partials(float* part_out);
+int supir_groupnorm_nhwc_parts(const void* x1, const void* x2, const void* x1raw, const void* x2raw, int B, int HW, int C, int C1,
+                               int ld1, int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
+                               const void* mod_b, int ldm, float control_scale, void* out, int ldo, const float* part1, int nchunk1,
+                               const float* part2, int nchunk2, void* stream);
+
 /* Statistics half of GroupNorm alone: sums_out[b][g] = (sum, sum of squares) over group g of batch b, fp32 [B][32][2].
  * With given_mean_var ([B][32][2] = mean, biased variance) supir_groupnorm_nhwc skips its own statistics pass and
  * normalises with the supplied ones.  Together they are the tiled VAE's cross-tile GroupNorm

@@ -38,6 +38,8 @@ SIGNATURES = {
     "supir_gemm_tile_for": [I, I, I],
     "supir_prefetch": [P, c_size_t, P, P],
     "supir_set_next_prefetch": [P, c_size_t],
+    "supir_set_next_gn_partials": [P],
+    "supir_groupnorm_nhwc_parts": [P, P, P, P, I, I, I, I, I, I, P, P, F, I, P, P, I, F, P, I, P, I, P, I, P],
     "supir_rowstats_finalize": [P, P, I, I, I, I, F, P],
     "supir_gemm_bf16_qkv": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, F, P],
     "supir_gemm_bf16_ln": [P, P, P, I, I, I, I, I, P, P, I, I, I, I, F, I, P, I, P, I, I, P, F, P],

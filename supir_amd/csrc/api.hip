@@ -13,11 +13,15 @@ int supir_note_hip_status(hipError_t e) {
 // one-shot prefetch request, consumed by the next GEMM / conv launch issued from this thread
 static thread_local const char* g_pf_ptr = nullptr;
 static thread_local unsigned g_pf_lines = 0;
+// one-shot request for GroupNorm partial statistics from the producer (supir_set_next_gn_partials), same scope and lifetime
+static thread_local float* g_gn_part_out = nullptr;
 static void take_prefetch(GemmArgs& a) {
     a.pf_ptr = g_pf_ptr;
     a.pf_lines = g_pf_lines;
     g_pf_ptr = nullptr;
     g_pf_lines = 0;
+    a.gn_part_out = g_gn_part_out;
+    g_gn_part_out = nullptr;
 }
 
 extern "C" {
@@ -27,6 +31,11 @@ int supir_set_next_prefetch(const void* p, size_t bytes) {
     const size_t lines = bytes / 128;
     g_pf_ptr = (const char*)p;
     g_pf_lines = lines > 0x7fffffffu ? 0x7fffffffu : (unsigned)lines;
+    return SUPIR_OK;
+}
+
+int supir_set_next_gn_partials(float* part_out) {
+    g_gn_part_out = part_out;
     return SUPIR_OK;
 }
 
@@ -175,6 +184,22 @@ int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, cons
     GnArgs a{};
     a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.x1raw = (const bf16_t*)x1raw; a.x2raw = (const bf16_t*)x2raw;
     a.partial = workspace; a.gamma = gamma; a.beta = beta; a.given = given_mean_var;
+    a.mod_g = (const bf16_t*)mod_g; a.mod_b = (const bf16_t*)mod_b; a.out = (bf16_t*)out;
+    a.B = B; a.HW = HW; a.C = C; a.C1 = C1; a.ld1 = ld1; a.ld2 = ld2; a.ldm = ldm; a.ldo = ldo;
+    a.act = act; a.eps = eps; a.cscale = control_scale;
+    return supir_groupnorm_launch(a, (hipStream_t)stream);
+}
+
+int supir_groupnorm_nhwc_parts(const void* x1, const void* x2, const void* x1raw, const void* x2raw, int B, int HW, int C, int C1,
+                               int ld1, int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
+                               const void* mod_b, int ldm, float control_scale, void* out, int ldo, const float* part1, int nchunk1,
+                               const float* part2, int nchunk2, void* stream) {
+    if (!x1 || !gamma || !beta || !out || !part1) return SUPIR_ERR_ARG;
+    if (C1 <= 0 || C1 > C) return SUPIR_ERR_ARG;
+    GnArgs a{};
+    a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.x1raw = (const bf16_t*)x1raw; a.x2raw = (const bf16_t*)x2raw;
+    a.gamma = gamma; a.beta = beta;
+    a.part_u1 = part1; a.nch1 = nchunk1; a.part_u2 = part2; a.nch2 = nchunk2;
     a.mod_g = (const bf16_t*)mod_g; a.mod_b = (const bf16_t*)mod_b; a.out = (bf16_t*)out;
     a.B = B; a.HW = HW; a.C = C; a.C1 = C1; a.ld1 = ld1; a.ld2 = ld2; a.ldm = ldm; a.ldo = ldo;
     a.act = act; a.eps = eps; a.cscale = control_scale;

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     constexpr int C_RS = WTN * 2 + 16;                         // staged row stride (bytes): 16-byte pad against bank conflicts
     constexpr int C_STAGE = 16 * C_RS;                         // one 16-token block per wave
     constexpr int OFF_CST = XCH, OFF_BIAS = OFF_CST + 8 * C_STAGE, OFF_RED = OFF_BIAS + 2 * BN * 4;
-    static_assert(OFF_RED + WN * BM * 8 <= KS * RING, "epilogue scratch must fit the LDS rings");
+    constexpr int OFF_GN = OFF_RED + WN * BM * 8;               // GroupNorm column partials: [wave 0..7][WTN][2] fp32
+    static_assert(OFF_GN + 8 * WTN * 8 <= KS * RING, "epilogue scratch must fit the LDS rings");
 
     // wave-uniform ids as scalars (readfirstlane): LDS destinations / branches on them stay on the scalar unit
     const int bwave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // wave inside the workgroup, 0..7
@@ -500,6 +501,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
         auto run = [&](auto kg_c, auto silu_c) {
             constexpr int KG = decltype(kg_c)::value;
             constexpr bool SILU = decltype(silu_c)::value;
+            constexpr int GP = (WTN + 63) / 64;
+            float gsum[GP], gsq[GP];   // GroupNorm statistics from the producer: this lane's columns, summed over the wave's token blocks
+#pragma unroll
+            for (int g = 0; g < GP; ++g) gsum[g] = gsq[g] = 0.f;
 #pragma unroll
             for (int h = 0; h < MIH; ++h) {
                 const int mrow = wm * WTM + (KG * MIH + h) * 16;    // first token of this 16-token block inside the tile
@@ -549,6 +554,23 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                     *(u32x2*)(c_stage + l15 * C_RS + (j * 16 + 4 * quad) * 2) = o;
                 }
                 flush_block(m0 + mrow, n0 + wn * WTN, std::integral_constant<int, WTN>{});
+                if (p.gn_part_out) {   // column sums of the staged 16 x WTN block, of the bf16 values as stored: lane = column
+#pragma unroll
+                    for (int g = 0; g < GP; ++g) {
+                        const int col = g * 64 + lane;
+                        if (WTN % 64 == 0 || col < WTN) {
+                            float cs_ = 0.f, cq_ = 0.f;
+#pragma unroll
+                            for (int row = 0; row < 16; ++row) {
+                                const float f = bf2f(*(const u16*)(c_stage + row * C_RS + col * 2));
+                                cs_ += f;
+                                cq_ += f * f;
+                            }
+                            gsum[g] += cs_;
+                            gsq[g] += cq_;
+                        }
+                    }
+                }
                 if (p.rowstats_out) {
                     rsum += __shfl_xor(rsum, 16, 64);
                     rsq += __shfl_xor(rsq, 16, 64);
@@ -564,6 +586,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                             red[0] = rsum;
                             red[1] = rsq;
                         }
+                    }
+                }
+            }
+            if (p.gn_part_out) {
+                float* red = (float*)(smem + OFF_GN) + (size_t)bwave * WTN * 2;
+#pragma unroll
+                for (int g = 0; g < GP; ++g) {
+                    const int col = g * 64 + lane;
+                    if (WTN % 64 == 0 || col < WTN) {
+                        red[col * 2] = gsum[g];
+                        red[col * 2 + 1] = gsq[g];
                     }
                 }
             }
@@ -589,6 +622,30 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
                     dst[0] = sm;
                     dst[1] = sq;
                 }
+            }
+        }
+        if (p.gn_part_out) {
+            // one (sum, sum of squares) per 10-channel unit of this tile: every wave that covered the unit's columns (all wave rows,
+            // both K groups), in a fixed order (reproducible); tile rows never straddle a batch (dispatcher)
+            __syncthreads();
+            if ((int)threadIdx.x < BN / 10) {
+                const float* red = (const float*)(smem + OFF_GN);
+                float sm = 0.f, sq = 0.f;
+                for (int c = (int)threadIdx.x * 10; c < (int)threadIdx.x * 10 + 10; ++c) {
+                    const int wn_c = c / WTN, cl = c - wn_c * WTN;
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                        for (int wx = 0; wx < WM; ++wx) {
+                            const int bw = kx * NW + wx * WN + wn_c;
+                            sm += red[((size_t)bw * WTN + cl) * 2];
+                            sq += red[((size_t)bw * WTN + cl) * 2 + 1];
+                        }
+                }
+                const int b = m0 / p.rows_per_batch, chunk = (m0 - b * p.rows_per_batch) / BM, nchunk = p.rows_per_batch / BM;
+                float* dst = p.gn_part_out + (((size_t)b * nchunk + chunk) * (p.N / 10) + n0 / 10 + threadIdx.x) * 2;
+                dst[0] = sm;
+                dst[1] = sq;
             }
         }
 #ifdef SUPIR_G16_TIMELINE
@@ -633,6 +690,7 @@ bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
     const int ks = tile == 34 ? 1 : 2, s = (tile == 34 || tile == 35) ? 3 : 2;
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
+    if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch % bm || a.N % 10)) return false;
     if (conv) {
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }

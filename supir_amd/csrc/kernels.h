@@ -32,6 +32,9 @@ struct GemmArgs {
     // ---- fused q|k|v projection (supir_gemm_bf16_qkv): columns >= n_split go, transposed per batch, to C2 [batch][N - n_split][ldc2]
     void* C2;
     int ldc2, n_split;
+    // ---- GroupNorm statistics from the producer (supir_set_next_gn_partials): per (batch, tile row of BM tokens, 10-channel unit) the
+    // (sum, sum of squares) of the bf16 values this launch stores: gn_part_out[((b * (rows_per_batch / BM) + chunk) * (N / 10) + unit) * 2]
+    float* gn_part_out;
 };
 
 struct AttnArgs {
@@ -52,6 +55,9 @@ struct GnArgs {
     const bf16_t* x2raw;  // ZeroSFT lerp only: un-projected skip (h before + zero_conv(c)); null -> x2 itself
     float* partial;     // [B][nchunk][32][2]  (sum, sumsq)
     const float* given; // optional [B][32][2] (mean, var): normalise with these instead of this tensor's own statistics
+    const float* part_u1;  // optional producer partials of x1: [B][nch1][C1 / 10][2] (see GemmArgs::gn_part_out); with C1 < C also part_u2
+    const float* part_u2;  //          ... of x2: [B][nch2][(C - C1) / 10][2].  When set, no statistics launch is made
+    int nch1, nch2;
     const float* gamma; // [C]
     const float* beta;  // [C]
     const bf16_t* mod_g;  // [B][HW][ldm] ZeroSFT gamma map or null

@@ -85,7 +85,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchun
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cv = p.C >> 3, cpg = p.C >> 5;
-    if (!p.given) {
+    if (p.part_u1) {
+        // statistics left behind by the producer GEMM / conv epilogues (GemmArgs::gn_part_out): (sum, sum of squares) per tile row
+        // and 10-channel unit of each source tensor.  Group g = units [g * upg, (g + 1) * upg) of the concatenation; every group
+        // width on the path is a multiple of 10 (dispatcher).  Same fixed order on every workgroup -> reproducible.
+        const int v = tid & 63, sub = tid >> 6, g = v >> 1, st = v & 1;
+        const int upg = cpg / 10, U1 = p.C1 / 10, U2 = (p.C - p.C1) / 10;
+        double a = 0.0;
+        for (int uu = g * upg; uu < (g + 1) * upg; ++uu) {
+            const bool first = uu < U1;
+            const float* src = first ? p.part_u1 : p.part_u2;
+            const int nch = first ? p.nch1 : p.nch2, U = first ? U1 : U2, u = first ? uu : uu - U1;
+            for (int k = sub; k < nch; k += 4) a += (double)src[(((size_t)b * nch + k) * U + u) * 2 + st];
+        }
+        s_part[sub][v] = a;
+    } else if (!p.given) {
         // all 256 threads reduce the per-chunk partials (fixed order -> reproducible): value v = tid&63, chunks sub, sub+4, ...
         const int v = tid & 63, sub = tid >> 6;
         double a = 0.0;
@@ -167,7 +181,10 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
     if (a.nchunk > 128 && (long)a.HW * a.C <= (8L << 20)) a.nchunk = 128;  // UNet-sized maps: fewer partials to re-reduce
     if (a.nchunk > 1024) a.nchunk = 1024;   // workspace contract: B * 1024 * 64 floats
     a.rows_per_chunk = (a.HW + a.nchunk - 1) / a.nchunk;
-    if (!a.given) {
+    if (a.part_u1) {
+        // producer-side statistics: no statistics launch.  Needs 10-channel units that tile every group and both sources.
+        if (a.given || (a.C / 32) % 10 || a.C1 % 10 || a.nch1 <= 0 || (a.C1 < a.C && (!a.part_u2 || a.nch2 <= 0))) return SUPIR_ERR_ARG;
+    } else if (!a.given) {
         const int cv = a.C / 8, cvb = cv < 256 ? cv : 256, TY = 256 / cvb;
         const size_t smem_stats = (size_t)TY * a.C * 2 * sizeof(float);
         if (smem_stats > 64 * 1024) return SUPIR_ERR_SHAPE;

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .. import ops
 from .. import weights as Wt
-from .base import BF16, Linear, Norm, Normalize, Passthrough, Prep, to_nchw, to_nhwc, tokens_bf16
+from .base import BF16, Linear, Norm, Normalize, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc, tokens_bf16
 
 
 FOLD_LAYERNORM = True   # SpatialTransformer runs its blocks through BasicTransformerBlock.forward_fused
@@ -250,7 +250,7 @@ class SpatialTransformer(nn.Module):
             context = context[0]
         xh = to_nhwc(x)
         B, H, W, C = xh.shape
-        n = ops.groupnorm(xh, self.norm.g32(), self.norm.b32(), self.norm.eps)
+        n = ops.groupnorm(xh, self.norm.g32(), self.norm.b32(), self.norm.eps, part=gn_part_of(x))
         fused = FOLD_LAYERNORM and context is not None and all(
             (not b.disable_self_attn) and (not b.attn2.is_self) for b in self.transformer_blocks)
         if fused:
@@ -261,5 +261,5 @@ class SpatialTransformer(nn.Module):
             t = ops.gemm(n.view(B, H * W, C), self.proj_in.w(), self.proj_in.b32())
             for blk in self.transformer_blocks:
                 t = blk(t, context=context, inplace=True)
-        out = ops.gemm(t, self.proj_out.w(), self.proj_out.b32(), residual=xh.view(B, H * W, C))
-        return to_nchw(out.view(B, H, W, C))
+        out, po = ops.gemm(t, self.proj_out.w(), self.proj_out.b32(), residual=xh.view(B, H * W, C), rows_per_batch=H * W, gn_part=True)
+        return attach_gn_part(to_nchw(out.view(B, H, W, C)), po)

@@ -31,6 +31,19 @@ def to_nchw(x_nhwc):
     return x_nhwc.permute(0, 3, 1, 2)
 
 
+def attach_gn_part(t, part):
+    """Tag a module OUTPUT (the exact tensor object handed to the next module) with the GroupNorm statistics its producing epilogue
+    left behind (ops.GnPart).  Valid as long as nobody writes the tensor in place -- module outputs on this path are never written
+    again -- and lost (harmlessly: the consumer falls back to a statistics pass) by any copy / cast / clone."""
+    if part is not None:
+        t._gn_part = part
+    return t
+
+
+def gn_part_of(t):
+    return getattr(t, "_gn_part", None)
+
+
 def tokens_bf16(x):
     x = x if x.dtype == BF16 else x.to(BF16)
     return x if x.is_contiguous() else x.contiguous()

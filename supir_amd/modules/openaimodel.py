@@ -11,7 +11,7 @@ import torch.nn as nn
 from .. import ops
 from .. import weights as Wt
 from .attention import SpatialTransformer
-from .base import BF16, Conv3x3, GroupNorm32, Linear, Passthrough, Prep, to_nchw, to_nhwc
+from .base import BF16, Conv3x3, GroupNorm32, Linear, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc
 
 
 def timestep_embedding(timesteps, dim, max_period=10000):
@@ -63,7 +63,8 @@ class Upsample(nn.Module):
         self.conv = Conv3x3(channels, self.out_channels)
 
     def forward(self, x):
-        return to_nchw(ops.conv3x3(to_nhwc(x), self.conv.w(), self.conv.b32(), upsample=True))
+        out, po = ops.conv3x3(to_nhwc(x), self.conv.w(), self.conv.b32(), upsample=True, gn_part=True)
+        return attach_gn_part(to_nchw(out), po)
 
 
 class Downsample(nn.Module):
@@ -76,7 +77,8 @@ class Downsample(nn.Module):
         self.op = Conv3x3(channels, self.out_channels)
 
     def forward(self, x):
-        return to_nchw(ops.conv3x3(to_nhwc(x), self.op.w(), self.op.b32(), stride=2, pad=(1, 1)))
+        out, po = ops.conv3x3(to_nhwc(x), self.op.w(), self.op.b32(), stride=2, pad=(1, 1), gn_part=True)
+        return attach_gn_part(to_nchw(out), po)
 
 
 class ResBlock(TimestepBlock):
@@ -112,15 +114,18 @@ class ResBlock(TimestepBlock):
             el = self.emb_layers[1]
             e = ops.gemm(torch.nn.functional.silu(raw.float()).to(BF16), el.w(), el.b32())
         n0, c0 = self.in_layers[0], self.in_layers[2]
-        h = ops.groupnorm(xh, n0.g32(), n0.b32(), n0.eps, silu=True)
-        h = ops.conv3x3(h, c0.w(), c0.b32(), rowbias=e)
+        # GroupNorm statistics ride the producer's epilogue where there is one (ops.GnPart): the input's from whichever module made
+        # it, conv1's output for out_layers, and this block's output for whoever normalises it next
+        h = ops.groupnorm(xh, n0.g32(), n0.b32(), n0.eps, silu=True, part=gn_part_of(x))
+        h, p1 = ops.conv3x3(h, c0.w(), c0.b32(), rowbias=e, gn_part=True)
         n1, c1 = self.out_layers[0], self.out_layers[3]
-        h = ops.groupnorm(h, n1.g32(), n1.b32(), n1.eps, silu=True, out=h)
+        h = ops.groupnorm(h, n1.g32(), n1.b32(), n1.eps, silu=True, out=h, part=p1)
         if isinstance(self.skip_connection, Linear):
             sk = ops.gemm(xh, self.skip_connection.w(), self.skip_connection.b32())
         else:
             sk = xh
-        return to_nchw(ops.conv3x3(h, c1.w(), c1.b32(), residual=sk))
+        out, po = ops.conv3x3(h, c1.w(), c1.b32(), residual=sk, gn_part=True)
+        return attach_gn_part(to_nchw(out), po)
 
 
 def _as_list(v):

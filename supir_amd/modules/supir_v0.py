@@ -8,7 +8,7 @@ import torch.nn as nn
 from .. import ops
 from .. import weights as Wt
 from .attention import CrossAttention, MemoryEfficientCrossAttention, SpatialTransformer
-from .base import BF16, Conv3x3, GroupNorm32, Linear, Passthrough, Prep, to_nchw, to_nhwc
+from .base import BF16, Conv3x3, GroupNorm32, Linear, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc
 from .openaimodel import TimestepBlock, TimestepEmbedSequential, UNetModel, Upsample
 
 
@@ -50,7 +50,7 @@ class ZeroSFT(nn.Module):
         assert self.mask is False
         ch, hh = to_nhwc(c), to_nhwc(h)
         B, H, W, Cs = hh.shape
-        hz = ops.gemm(ch, self.zero_conv.w(), self.zero_conv.b32(), residual=hh)        # h + zero_conv(c)
+        hz, pz = ops.gemm(ch, self.zero_conv.w(), self.zero_conv.b32(), residual=hh, rows_per_batch=H * W, gn_part=True)   # h + zero_conv(c)
         gb = pre if pre is not None else self.control_side(c)
         n = self.param_free_norm
         Ccat = n.num_channels
@@ -58,11 +58,11 @@ class ZeroSFT(nn.Module):
         if h_ori is not None and self.pre_concat:
             ho = to_nhwc(h_ori)
             out = ops.groupnorm(ho, n.g32(), n.b32(), n.eps, x2=hz, mod_g=gb[..., :Ccat], mod_b=gb[..., Ccat:],
-                                control_scale=cs, x2raw=hh if cs != 1.0 else None)
+                                control_scale=cs, x2raw=hh if cs != 1.0 else None, part=gn_part_of(h_ori), part2=pz)
         else:
             assert h_ori is None, "h_ori without pre_concat is not built by LightGLVUNet"
             out = ops.groupnorm(hz, n.g32(), n.b32(), n.eps, mod_g=gb[..., :Ccat], mod_b=gb[..., Ccat:],
-                                control_scale=cs, x1raw=hh if cs != 1.0 else None)
+                                control_scale=cs, x1raw=hh if cs != 1.0 else None, part=pz)
         return to_nchw(out)
 
 
@@ -90,7 +90,7 @@ class ZeroCrossAttn(nn.Module):
         assert self.mask is False
         xh = to_nhwc(x)
         B, H, W, C = xh.shape
-        xn = ops.groupnorm(xh, self.norm1.g32(), self.norm1.b32(), self.norm1.eps).view(B, H * W, C)
+        xn = ops.groupnorm(xh, self.norm1.g32(), self.norm1.b32(), self.norm1.eps, part=gn_part_of(x)).view(B, H * W, C)
         k, vt = pre if pre is not None else self.control_side(context)
         a = self.attn
         T, Tk = H * W, k.shape[1]

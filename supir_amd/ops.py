@@ -242,11 +242,39 @@ def _pf(w):
         _PF.touch(w)
 
 
+# --------------------------------------------------------------------------------------------- GroupNorm statistics from producers
+class GnPart:
+    """What a producer GEMM / conv epilogue left behind for a GroupNorm over its output (supir_set_next_gn_partials): fp32
+    [B, nchunk, C // 10, 2] = (sum, sum of squares) per batch, tile row and 10-channel unit of the bf16 values it stored."""
+    __slots__ = ("buf", "nchunk", "C")
+
+    def __init__(self, buf, nchunk, C):
+        self.buf, self.nchunk, self.C = buf, nchunk, C
+
+
+USE_GN_PARTS = _os.environ.get("SUPIR_GN_PARTS", "1") != "0"   # producers emit GroupNorm statistics where the kernels support it
+
+
+def _gn_part_request(lib, tile, nbatch, rows_per_batch, N, device):
+    """Arm the one-shot request for the launch that follows, if the chosen tile can serve it; returns the GnPart or None."""
+    if not USE_GN_PARTS or tile not in _G16:
+        return None
+    bm = _G16[tile][0]
+    if rows_per_batch <= 0 or rows_per_batch % bm or N % 10:
+        return None
+    nchunk = rows_per_batch // bm
+    buf = torch.empty(nbatch, nchunk, N // 10, 2, dtype=torch.float32, device=device)
+    lib.supir_set_next_gn_partials(buf.data_ptr())
+    return GnPart(buf, nchunk, N)
+
+
 # --------------------------------------------------------------------------------------------- GEMM family
 def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=0, alpha=1.0, out=None,
-         out_dtype=BF16, tile=-1, alt16=None):
+         out_dtype=BF16, tile=-1, alt16=None, gn_part=False):
     """out[M,N] = alpha*act(a[M,K] @ w[N,K]^T + bias + rowbias[batch]) + residual.  act=2 (GEGLU) -> N/2 columns.
-    alt16 = (w, bias) in the 16-row GEGLU interleave: lets the autotuner also try tile 34 (csrc/gemm16.hip)."""
+    alt16 = (w, bias) in the 16-row GEGLU interleave: lets the autotuner also try tile 34 (csrc/gemm16.hip).
+    gn_part=True: returns (out, GnPart or None) -- GroupNorm statistics of `out` per batch of `rows_per_batch` rows, when the tile
+    that runs can emit them."""
     lib = _lib.load()
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
@@ -289,11 +317,14 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         if tile >= 32 and tile not in cands:   # a winner cached for this shape under friendlier strides / layouts
             tile = -1
     _pf(w)
+    part = None
+    if gn_part and om == 0 and act != 2:
+        part = _gn_part_request(lib, tile, M // rows_per_batch if rows_per_batch else 1, rows_per_batch or M, N, a.device)
     ev = _ev()
     rc = launch(tile)
     _lib.check(rc, "supir_gemm_bf16")
     _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act, tile=tile)
-    return out
+    return (out, part) if gn_part else out
 
 
 _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
@@ -511,8 +542,9 @@ def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
 
 
 def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=None, rowbias=None, residual=None,
-            act=0, alpha=1.0, out=None, tile=-1):
-    """x [B,H,W,Cin(ld)] bf16 -> [B,OH,OW,Cout]. w [Cout,3,3,Cin] bf16. pad=(top,left); bottom/right implied by out_hw."""
+            act=0, alpha=1.0, out=None, tile=-1, gn_part=False):
+    """x [B,H,W,Cin(ld)] bf16 -> [B,OH,OW,Cout]. w [Cout,3,3,Cin] bf16. pad=(top,left); bottom/right implied by out_hw.
+    gn_part=True: returns (out, GnPart or None) -- GroupNorm statistics of `out` from the epilogue, when the tile that runs can emit them."""
     lib = _lib.load()
     _check_dev(x, w)
     B, H, W, Cin = x.shape
@@ -561,13 +593,14 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
         if tile >= 32 and tile not in cands:
             tile = -1
     _pf(w)
+    part = _gn_part_request(lib, tile, B, OH * OW, Cout, x.device) if (gn_part and om == 0) else None
     ev = _ev()
     rc = launch(tile)
     _lib.check(rc, "supir_conv3x3_bf16")
     M = B * OH * OW
     _rec("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout), ev, M=M, N=Cout, K=9 * Cin,
          act=act, tile=tile)
-    return out
+    return (out, part) if gn_part else out
 
 
 # --------------------------------------------------------------------------------------------- attention
@@ -626,8 +659,9 @@ def groupnorm_stats(x):
 
 
 def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=None, control_scale=1.0, x1raw=None,
-              x2raw=None, out=None, given=None):
-    """GroupNorm(32) over channels-last x (optionally the channel concat [x | x2]); see supir_groupnorm_nhwc."""
+              x2raw=None, out=None, given=None, part=None, part2=None):
+    """GroupNorm(32) over channels-last x (optionally the channel concat [x | x2]); see supir_groupnorm_nhwc.
+    part / part2 = GnPart of x / x2 from their producers: one launch, no statistics pass (supir_groupnorm_nhwc_parts)."""
     lib = _lib.load()
     _check_dev(x, gamma, beta)
     B = x.shape[0]
@@ -648,14 +682,24 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
         _, Cm, ldm = _rows_ld(mod_g)
         _, Cm2, ldm2 = _rows_ld(mod_b)
         assert Cm == C and Cm2 == C and ldm == ldm2
-    ws = _gn_workspace(B, x.device)
+    use_parts = (part is not None and given is None and (x2 is None or part2 is not None) and (C // 32) % 10 == 0 and C1 % 10 == 0
+                 and part.C == C1 and part.buf.shape[0] == B and (part2 is None or (part2.C == C - C1 and part2.buf.shape[0] == B)))
     ev = _ev()
-    rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
-                                  beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
-                                  out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _p(given), _stream())
-    _lib.check(rc, "supir_groupnorm_nhwc")
+    if use_parts:
+        rc = lib.supir_groupnorm_nhwc_parts(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
+                                            beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
+                                            out.data_ptr(), ldo, part.buf.data_ptr(), part.nchunk,
+                                            0 if part2 is None else part2.buf.data_ptr(), 0 if part2 is None else part2.nchunk,
+                                            _stream())
+        _lib.check(rc, "supir_groupnorm_nhwc_parts")
+    else:
+        ws = _gn_workspace(B, x.device)
+        rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
+                                      beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
+                                      out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _p(given), _stream())
+        _lib.check(rc, "supir_groupnorm_nhwc")
     n = B * HW * C
-    _rec("groupnorm", 0, 2.0 * n * (2 + (2 if mod_g is not None else 0)), ev, B=B, HW=HW, C=C)
+    _rec("groupnorm", 0, 2.0 * n * (2 + (2 if mod_g is not None else 0)), ev, B=B, HW=HW, C=C, parts=use_parts)
     return out
 
 

@@ -644,6 +644,72 @@ def test_gemm_big_geglu(M, K, N2):
         ops.gemm(a[: M - 64], w16, b16, act=2, tile=37)
 
 
+def _unit_sums(y, B, rows_per_batch, bm):
+    """(sum, sum of squares) per (batch, tile row of bm rows, 10-channel unit) of a bf16 [B * rows, C] tensor, in fp64."""
+    C = y.shape[-1]
+    yf = y.double().view(B, rows_per_batch // bm, bm, C // 10, 10)
+    return torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 1280, 1280, 35), (2, 64, 64, 640, 640, 33), (2, 128, 128, 320, 320, 34), (2, 32, 32, 640, 1280, 32)])
+def test_groupnorm_statistics_from_the_conv_epilogue(case):
+    """supir_set_next_gn_partials: a gemm16 conv launch also leaves (sum, sum of squares) per (batch, tile row, 10-channel unit) of the
+    bf16 values it stored; supir_groupnorm_nhwc_parts normalises with them in one launch (openaimodel.py:295-308: conv -> GroupNorm32
+    -> SiLU).  Checked: the partials themselves, the GroupNorm against torch and against the two-launch path, repeatability."""
+    B, H, W, Cin, Cout, tile = case
+    x = rnd(B, H, W, Cin).to(BF)
+    w = rnd(Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
+    bias, emb = rnd(Cout, seed=2), rnd(B, Cout, seed=3).to(BF)
+    y, part = ops.conv3x3(x, w, bias, rowbias=emb, tile=tile, gn_part=True)
+    assert part is not None and part.C == Cout
+    bm = ops._G16[tile][0]
+    ref = _unit_sums(y.view(B * H * W, Cout), B, H * W, bm)
+    assert part.buf.shape == ref.shape
+    assert torch.allclose(part.buf.double(), ref, rtol=2e-5, atol=2e-3), (part.buf.double() - ref).abs().max()
+    y2, part2 = ops.conv3x3(x, w, bias, rowbias=emb, tile=tile, gn_part=True)
+    assert torch.equal(y, y2) and torch.equal(part.buf, part2.buf)
+    assert torch.equal(y, ops.conv3x3(x, w, bias, rowbias=emb, tile=tile))          # the request does not change the output
+    g, b = rnd(Cout, seed=4) * 0.2 + 1.0, rnd(Cout, seed=5) * 0.2
+    o_parts = ops.groupnorm(y, g, b, 1e-5, silu=True, part=part)
+    o_two = ops.groupnorm(y, g, b, 1e-5, silu=True)
+    gn = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, g, b, 1e-5)).permute(0, 2, 3, 1)
+    check(o_parts, gn, name="gn from conv partials")
+    check(o_parts, o_two.float(), rel=1e-3, name="gn partials vs two-launch")
+    assert torch.equal(o_parts, ops.groupnorm(y, g, b, 1e-5, silu=True, part=part))
+    # in place, as the ResBlock uses it
+    yc = y.clone()
+    ops.groupnorm(yc, g, b, 1e-5, silu=True, out=yc, part=part)
+    assert torch.equal(yc, o_parts)
+
+
+def test_groupnorm_statistics_from_gemm_epilogues_and_concat():
+    """proj_out-style GEMM (+ residual) as the producer, and the concat GroupNorm of a decoder ResBlock (1280 + 640 channels: groups of
+    60 channels straddle neither 10-channel units nor the two sources' own partial buffers, which have different chunk counts)."""
+    B, T = 2, 1024
+    a = rnd(B * T, 1280).to(BF)
+    w = rnd(1280, 1280, scale=1280 ** -0.5, seed=1).to(BF)
+    res = rnd(B * T, 1280, seed=2).to(BF)
+    h, p1 = ops.gemm(a, w, rnd(1280, seed=3), residual=res, rows_per_batch=T, tile=35, gn_part=True)
+    assert p1 is not None and p1.nchunk == T // 128
+    assert torch.allclose(p1.buf.double(), _unit_sums(h, B, T, 128), rtol=2e-5, atol=2e-3)
+    x2 = rnd(B, 32, 32, 320, seed=4).to(BF)
+    w2 = rnd(640, 3, 3, 320, scale=(9 * 320) ** -0.5, seed=5).to(BF)
+    skip, p2 = ops.conv3x3(x2, w2, None, tile=34, gn_part=True)                    # 640 channels, another tile -> another chunk count
+    assert p2 is not None and p2.nchunk == 1024 // 256 != p1.nchunk
+    g, b = rnd(1920, seed=6) * 0.2 + 1.0, rnd(1920, seed=7) * 0.2
+    hv = h.view(B, 32, 32, 1280)
+    o = ops.groupnorm(hv, g, b, 1e-5, silu=True, x2=skip, part=p1, part2=p2)
+    cat = torch.cat([hv, skip], -1).float()
+    gn = F.silu(F.group_norm(cat.permute(0, 3, 1, 2), 32, g, b, 1e-5)).permute(0, 2, 3, 1)
+    check(o, gn, name="concat gn from two producers")
+    check(o, ops.groupnorm(hv, g, b, 1e-5, silu=True, x2=skip).float(), rel=1e-3, name="concat gn partials vs two-launch")
+    # a tile that cannot emit the statistics says so (None) and the output is still right; a missing part2 falls back to two launches
+    h3, p3 = ops.gemm(a, w, None, rows_per_batch=T, tile=3, gn_part=True)
+    assert p3 is None
+    o2 = ops.groupnorm(hv, g, b, 1e-5, silu=True, x2=skip, part=p1)
+    assert torch.equal(o2, ops.groupnorm(hv, g, b, 1e-5, silu=True, x2=skip))
+
+
 G16_CONV_CASES = [
     # B, H, W, Cin, Cout, stride, pad(top,left), upsample, out_hw   (UNet / VAE shapes whose output grid is an exact tile multiple)
     (2, 32, 32, 1280, 1280, 1, (1, 1), False, None),
