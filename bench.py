@@ -98,6 +98,8 @@ def kernel_profile(model, latent, device):
             shape = f"B{r['B']} H{r['H']} Tq{r['Tq']} Tk{r['Tk']}"
         elif k == "groupnorm":
             shape = f"B{r['B']} HW{r['HW']} C{r['C']}"
+        if r["kernel"] == "groupnorm" and r.get("parts"):
+            k = "groupnorm(statistics from the producer)"   # one launch; the others are a statistics + an apply launch
         for d, key in ((agg, k), (by_shape, (k, shape))):
             a = d.setdefault(key, dict(launches=0, us=0.0, flops=0.0, bytes=0.0))
             a["launches"] += 1

@@ -256,7 +256,7 @@ class UNetModel(nn.Module):
 
     def _out(self, h):
         n, c = self.out[0], self.out[2]
-        hn = ops.groupnorm(to_nhwc(h), n.g32(), n.b32(), n.eps, silu=True)
+        hn = ops.groupnorm(to_nhwc(h), n.g32(), n.b32(), n.eps, silu=True, part=gn_part_of(h))
         return ops.conv3x3_smallcout(hn, c.w9(), c.b32())
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):

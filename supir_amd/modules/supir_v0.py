@@ -80,7 +80,7 @@ class ZeroCrossAttn(nn.Module):
         """K and V^T of the (group-normalised) control feature: independent of the decoder state."""
         chh = to_nhwc(context)
         B, Cc = chh.shape[0], chh.shape[-1]
-        cn = ops.groupnorm(chh, self.norm2.g32(), self.norm2.b32(), self.norm2.eps).view(B, -1, Cc)
+        cn = ops.groupnorm(chh, self.norm2.g32(), self.norm2.b32(), self.norm2.eps, part=gn_part_of(context)).view(B, -1, Cc)
         a, Tk = self.attn, cn.shape[1]
         return ops.gemm(cn, a.to_k.w()), ops.gemm_t(cn, a.to_v.w(), None, B, Tk, (Tk + 63) // 64 * 64)
 
