@@ -12,7 +12,7 @@
  *     (b) the per-thread last-HIP-error code read by supir_last_hip_error; results never depend on either;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and stream ordered, never synchronise;
  *   - return 0 on success, <0 on error (SUPIR_ERR_*); never throws;
- *   - "bf16" buffers are raw 16-bit bfloat16; activations are NHWC / token-major: element (b, y, x, c) of a
+ *   - "bf16" buffers are raw 16-bit bfloat16 (IEEE binary16 in the f16 build, see supir_elem_type); activations are NHWC / token-major: element (b, y, x, c) of a
  *     [B,H,W,C] feature map lives at ((b*H + y)*W + x)*ld + c where ld >= C is the row stride in elements;
  *   - leading dimensions of bf16 operands must be multiples of 8 elements (16 bytes) unless noted.
  */
@@ -47,6 +47,12 @@ extern "C" {
 int supir_abi_version(void);
 /* Static string naming the compiled target ("gfx950"). Host pointer. */
 const char* supir_target_arch(void);
+/* Static string naming the 16-bit element type this build's "bf16" buffers hold: "bf16" for libsupir_hip.so (the product
+ * default) or "f16" for libsupir_hip_f16.so -- the same sources compiled with -DSUPIR_F16 (csrc/common.h): every entry point
+ * below, same names and signatures, with IEEE binary16 buffers and v_mfma_*_f16 operands, fp32 accumulation and epilogues
+ * unchanged.  It serves the reference's default `diff_dtype: fp16` (options/SUPIR_v0.yaml:5, test.py:67-68) at the
+ * reference's own precision.  The host mirror picks the library by the dtype of the operands (supir_amd/_lib.py). Host pointer. */
+const char* supir_elem_type(void);
 
 /* Diagnostics for SUPIR_ERR_HIP: the hipError_t of the last failed launch on this thread, and its text. Host only. */
 int supir_last_hip_error(void);

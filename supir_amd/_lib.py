@@ -13,6 +13,8 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsupir_hip.so")
+# the same sources built with -DSUPIR_F16: every 16-bit buffer of the ABI holds IEEE binary16, MFMA operands are fp16 (csrc/common.h)
+LIB_PATH_F16 = os.path.join(_HERE, "libsupir_hip_f16.so")
 
 _ERR = {-1: "SUPIR_ERR_ARG (null pointer / bad size)", -2: "SUPIR_ERR_SHAPE (unsupported shape or alignment)",
         -3: "SUPIR_ERR_HIP (launch failed)"}
@@ -45,23 +47,29 @@ SIGNATURES = {
     "supir_gemm_bf16_ln": [P, P, P, I, I, I, I, I, P, P, I, I, I, I, F, I, P, I, P, I, I, P, F, P],
 }
 
-_lib = None
+_lib = None       # the bf16 library (the product default)
+_lib_f16 = None   # the fp16 build, loaded on first use
 
 
 class SupirHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load the library (building is __graft_entry__.build()'s / supir_amd.build's job, never done implicitly)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(dtype=None):
+    """Load the library (building is __graft_entry__.build()'s / supir_amd.build's job, never done implicitly).
+    dtype: element type of the 16-bit operands the caller is about to pass -- torch.float16 selects libsupir_hip_f16.so,
+    anything else (None, torch.bfloat16) the bf16 library."""
+    global _lib, _lib_f16
+    f16 = dtype is torch.float16
+    cur = _lib_f16 if f16 else _lib
+    if cur is not None:
+        return cur
+    path = LIB_PATH_F16 if f16 else LIB_PATH
+    if not os.path.exists(path):
         raise SupirHipError(
-            f"{LIB_PATH} not found: run `python -m supir_amd.build` (hipcc, gfx950). The HIP extension is mandatory; "
+            f"{path} not found: run `python -m supir_amd.build` (hipcc, gfx950). The HIP extension is mandatory; "
             "there is no CPU / PyTorch fallback on the product path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)   # RTLD_LOCAL: the two builds export the same names and must not see each other's symbols
     lib.supir_abi_version.restype = c_int
     lib.supir_abi_version.argtypes = []
     lib.supir_target_arch.restype = c_char_p
@@ -74,16 +82,30 @@ def load():
     lib.supir_last_hip_error.argtypes = []
     lib.supir_hip_error_string.restype = c_char_p
     lib.supir_hip_error_string.argtypes = [c_int]
+    lib.supir_elem_type.restype = c_char_p
+    lib.supir_elem_type.argtypes = []
     if lib.supir_abi_version() != 1:
-        raise SupirHipError("libsupir_hip.so ABI version mismatch")
-    _lib = lib
+        raise SupirHipError(f"{os.path.basename(path)} ABI version mismatch")
+    want = b"f16" if f16 else b"bf16"
+    if lib.supir_elem_type() != want:
+        raise SupirHipError(f"{os.path.basename(path)} was built for {lib.supir_elem_type()!r} elements, expected {want!r}")
+    if f16:
+        _lib_f16 = lib
+    else:
+        _lib = lib
     return lib
 
 
-def check(rc, name):
+def loaded():
+    """The libraries this process has dlopen'ed so far (bf16 first)."""
+    return [lib for lib in (_lib, _lib_f16) if lib is not None]
+
+
+def check(rc, name, lib=None):
     if rc != 0:
         detail = ""
-        if rc == -3 and _lib is not None:
-            code = _lib.supir_last_hip_error()
-            detail = f" [hipError {code}: {_lib.supir_hip_error_string(code).decode()}]"
+        lib = lib if lib is not None else _lib
+        if rc == -3 and lib is not None:
+            code = lib.supir_last_hip_error()
+            detail = f" [hipError {code}: {lib.supir_hip_error_string(code).decode()}]"
         raise SupirHipError(f"{name} failed: {_ERR.get(rc, rc)}{detail}")

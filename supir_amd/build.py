@@ -1,6 +1,8 @@
-"""Build libsupir_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""Build libsupir_hip.so (bf16 elements, the product default) and libsupir_hip_f16.so (the same sources with -DSUPIR_F16: fp16
+elements and MFMA operands, for callers that request the reference's default diff_dtype) in-tree with hipcc for gfx950
+(cross-compiles without a GPU).
 
-The .so is git-ignored but travels to the GPU box with the working-tree snapshot; nothing is JIT-compiled at run time.
+The .so files are git-ignored but travel to the GPU box with the working-tree snapshot; nothing is JIT-compiled at run time.
 """
 import os
 import subprocess
@@ -11,12 +13,16 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["gemm.hip", "gemm16.hip", "gemm_big.hip", "attention.hip", "norm.hip", "edge.hip", "api.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "supir_hip.h")]
 LIB = os.path.join(HERE, "libsupir_hip.so")
+LIB_F16 = os.path.join(HERE, "libsupir_hip_f16.so")
+# (library, object sub-directory, extra compile flags, extra link flags).  -Bsymbolic on the fp16 build: both libraries define the
+# same C++ symbols; each must bind to its own even if a host application loads them RTLD_GLOBAL.
+VARIANTS = [(LIB, "", [], []), (LIB_F16, "f16", ["-DSUPIR_F16"], ["-Wl,-Bsymbolic"])]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
@@ -26,28 +32,33 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def build(force=False, verbose=True):
-    if not force and not _stale():
+    """Compile every stale variant (all translation units of all variants in parallel), link, return the bf16 library's path."""
+    todo = [v for v in VARIANTS if force or _stale(v[0])]
+    if not todo:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
-    objdir = os.path.join(CSRC, "_obj")
-    os.makedirs(objdir, exist_ok=True)
-    procs, objs = [], []
-    for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = base + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print("[supir_amd.build]", " ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
+    procs, objs = [], {}
+    for lib, sub, cflags, _ in todo:
+        objdir = os.path.join(CSRC, "_obj", sub)
+        os.makedirs(objdir, exist_ok=True)
+        objs[lib] = []
+        for src in SOURCES:
+            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            cmd = base + cflags + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print("[supir_amd.build]", " ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs[lib].append(obj)
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
-    if verbose:
-        print("[supir_amd.build]", " ".join(link), flush=True)
-    subprocess.check_call(link)
-    os.replace(LIB + ".tmp", LIB)
+    for lib, _, _, lflags in todo:
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + lflags + objs[lib] + ["-o", lib + ".tmp"]
+        if verbose:
+            print("[supir_amd.build]", " ".join(link), flush=True)
+        subprocess.check_call(link)
+        os.replace(lib + ".tmp", lib)
     return LIB
 
 

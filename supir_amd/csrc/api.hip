@@ -44,6 +44,7 @@ const char* supir_hip_error_string(int code) { return hipGetErrorString((hipErro
 
 int supir_abi_version(void) { return 1; }
 const char* supir_target_arch(void) { return "gfx950"; }
+const char* supir_elem_type(void) { return SUPIR_ELEM_NAME; }
 int supir_gemm_tile_for(int M, int N, int act) { return supir_gemm_select_tile(M, N, act, -1); }
 
 int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,

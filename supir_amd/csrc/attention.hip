@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgs p
     load_k(kA, 0, 0);
     sa = nm;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[ks], qf[ks], sa, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) sa = SUPIR_MFMA_32x32x16(kA[ks], qf[ks], sa, 0, 0, 0);
     load_k(kA, 0, 1);
     {
         const bool mk = (nt == 1 && tail_mask) || p.causal;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgs p
         // ================= half 0: P(t,0) from sa, S(t,1) into sb =================
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[j], qf[j], j == 0 ? nm : sb, 0, 0, 0);
+            sb = SUPIR_MFMA_32x32x16(kA[j], qf[j], j == 0 ? nm : sb, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (j == 0) load_v(vA, boff, 0);   // after the MFMA: it must not wait for these reads, only for kA's
             exp4(sa, pf, j);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgs p
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            o[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[j], pf[j >> 1], o[j & 1], 0, 0, 0);
+            o[j & 1] = SUPIR_MFMA_32x32x16(vA[j], pf[j >> 1], o[j & 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (j == 0) load_k(kA, nboff, 0);   // past the last tile: a ring slot nobody waits for; its products are never used
             mx = max4(sb, mx, t * 64 + 32, j, MASKED);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgs p
         if (MASKED && t == nt - 1 && last_half_empty) return;   // nothing but masked keys left (Tk % 64 in 1..32): P = 0
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[j], qf[j], j == 0 ? nm : sa, 0, 0, 0);
+            sa = SUPIR_MFMA_32x32x16(kA[j], qf[j], j == 0 ? nm : sa, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (j == 0) load_v(vA, boff, 1);
             exp4(sb, pf, j);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgs p
         mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            o[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[j], pf[j >> 1], o[j & 1], 0, 0, 0);
+            o[j & 1] = SUPIR_MFMA_32x32x16(vA[j], pf[j >> 1], o[j & 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (j == 0) load_k(kA, nboff, 1);
             mx = max4(sa, mx, (t + 1) * 64, j, MASKED);

@@ -4,10 +4,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit element type of every activation / weight buffer.  The product library (libsupir_hip.so) is built with bfloat16;
+// the SAME sources compiled with -DSUPIR_F16 give libsupir_hip_f16.so, in which every "bf16" buffer of the C ABI holds IEEE
+// binary16 instead (the reference's default diff_dtype, options/SUPIR_v0.yaml:5, test.py:67-68): same kernels, same tiles, same
+// fp32 accumulation, v_mfma_*_f16 in place of v_mfma_*_bf16.  Only the few helpers below know which of the two it is.
+#ifdef SUPIR_F16
+typedef _Float16 bf16_t;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+#define SUPIR_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define SUPIR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define SUPIR_ELEM_NAME "f16"
+#else
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define SUPIR_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define SUPIR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define SUPIR_ELEM_NAME "bf16"
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
@@ -31,6 +48,18 @@ int supir_note_hip_status(hipError_t e);
 
 // fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
 typedef float supir_f32x2 __attribute__((ext_vector_type(2)));
+#ifdef SUPIR_F16
+// fp32 -> fp16, round to nearest even (v_cvt_f16_f32; values beyond 65504 become +-inf exactly as torch's .half() does)
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {   // (lo, hi) -> two fp16 in one dword
+    const supir_f32x2 v = {lo, hi};
+    const bf16x2 b = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (_Float16)f); }
+__device__ __forceinline__ float bf2f(u16 h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ float bflo2f(uint32_t w) { return bf2f((u16)(w & 0xffffu)); }
+__device__ __forceinline__ float bfhi2f(uint32_t w) { return bf2f((u16)(w >> 16)); }
+#else
 typedef __bf16 supir_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {   // (lo, hi) -> two bf16 in one dword
     const supir_f32x2 v = {lo, hi};
@@ -41,6 +70,7 @@ __device__ __forceinline__ u16 f2bf(float f) { return (u16)(f2bf_pk(f, 0.f) & 0x
 __device__ __forceinline__ float bflo2f(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi2f(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+#endif
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf GELU (F.gelu default; reference: sgm/modules/attention.py:91).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,

@@ -303,9 +303,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     if constexpr (TRANS)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & (FB - 1)][i], bfr[ks & (FB - 1)][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SUPIR_MFMA_32x32x16(af[ks & (FB - 1)][i], bfr[ks & (FB - 1)][j], acc[i][j], 0, 0, 0);
                     else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & (FB - 1)][j], af[ks & (FB - 1)][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SUPIR_MFMA_32x32x16(bfr[ks & (FB - 1)][j], af[ks & (FB - 1)][i], acc[i][j], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);   // keep the slice order: the scheduler must not regroup loads and MFMAs
         }

@@ -318,9 +318,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     if constexpr (TR)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SUPIR_MFMA_16x16x32(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
                     else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SUPIR_MFMA_16x16x32(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }

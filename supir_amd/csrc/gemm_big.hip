@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgs p) {
             if (q + 2 < 20) wf[(q + 2) % 3] = read_w(q + 2);
             if (j == 2 && ks < 3) read_a(ks + 1, (ks + 1) & 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q % 3], af[ks & 1][i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) acc[i][j] = SUPIR_MFMA_32x32x16(wf[q % 3], af[ks & 1][i], acc[i][j], 0, 0, 0);
             if constexpr (MORE) {
                 // 9 loads on ticks 0 .. 8: as early as the slot is free (they are awaited at the top of the next step, so the last
                 // one needs its whole latency inside this step), but not back to back (that stalls on the vector-memory path)

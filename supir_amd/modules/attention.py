@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .. import ops
 from .. import weights as Wt
-from .base import BF16, Linear, Norm, Normalize, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc, tokens_bf16
+from .base import cdt, Linear, Norm, Normalize, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc, tokens_bf16
 
 
 FOLD_LAYERNORM = True   # SpatialTransformer runs its blocks through BasicTransformerBlock.forward_fused
@@ -56,7 +56,7 @@ class CrossAttention(nn.Module):
         if cache is None:
             cache = {}
             object.__setattr__(self, "_kv_cache", cache)
-        key = (tuple(context.shape), context.device)
+        key = (tuple(context.shape), context.device) + ops._k(cdt())   # fp16 scopes keep their own buffers (other element type)
         c = cache.get(key)
         if c is not None and c[0] is context and c[1] == context._version and c[2] is wk and c[3] is wv:
             return c[4], c[5]
@@ -191,7 +191,7 @@ class BasicTransformerBlock(nn.Module):
 
         if T % 64 == 0 and ops.gemm_qkv_supported(B * T, 3 * inner, 2 * inner, C, T):
             # one launch for q | k | v^T instead of two when it is faster for this shape (timed once, outside graph capture)
-            which = ops.choose(("qkv", B * T, 3 * inner, C), (qkv_separate, qkv_fused))
+            which = ops.choose(("qkv", B * T, 3 * inner, C) + ops._k(x.dtype), (qkv_separate, qkv_fused))
             qk, vt = qkv_fused() if which == 1 else qkv_separate()
         else:
             qk, vt = qkv_separate()

@@ -5,7 +5,8 @@ Boundary convention (what lets these classes stand in for the reference's module
     channels-last bf16 -- `to_nhwc` turns them into the [B, H, W, C] view the kernels consume without moving a byte,
     `to_nchw` goes back.  An fp32 / NCHW-contiguous tensor handed in by an outside caller is converted once on entry;
   * parameters stay fp32 tensors with the reference's names and shapes (drop-in `load_state_dict`); the bf16 kernel
-    layouts are derived lazily and cached, keyed on (data_ptr, version) so `load_state_dict` / `.to()` invalidate them.
+    layouts are derived lazily and cached, keyed on (data_ptr, version) so `load_state_dict` / `.to()` invalidate them
+    (and on the compute dtype: a module driven in an fp16 scope -- weights.compute_dtype -- holds fp16 layouts instead).
 
 Parameters are allocated uninitialised (torch.empty): the reference's random init is unusable anyway (zero_module) and
 real use always loads a checkpoint; tests / bench fill them with supir_amd.synth.
@@ -16,12 +17,13 @@ import torch.nn as nn
 from .. import weights as Wt
 
 BF16 = torch.bfloat16
+cdt = Wt.cdt   # the 16-bit element type of the current call scope (bf16 by default, fp16 inside weights.compute_dtype(torch.float16))
 
 
 def to_nhwc(x):
-    """[B,C,H,W] logical (any dtype/strides) -> bf16 [B,H,W,C] contiguous view/copy."""
-    if x.dtype != BF16:
-        x = x.to(BF16)
+    """[B,C,H,W] logical (any dtype/strides) -> 16-bit (compute dtype) [B,H,W,C] contiguous view/copy."""
+    if x.dtype != cdt():
+        x = x.to(cdt())
     v = x.permute(0, 2, 3, 1)
     return v if v.is_contiguous() else v.contiguous()
 
@@ -45,7 +47,8 @@ def gn_part_of(t):
 
 
 def tokens_bf16(x):
-    x = x if x.dtype == BF16 else x.to(BF16)
+    """Token tensor in the compute dtype (bf16 by default; the name predates the fp16 build), contiguous."""
+    x = x if x.dtype == cdt() else x.to(cdt())
     return x if x.is_contiguous() else x.contiguous()
 
 
@@ -59,7 +62,8 @@ class Prep:
         self.val = None
 
     def get(self, srcs, fn):
-        key = tuple((t.data_ptr(), t._version, t.device) for t in srcs if t is not None)
+        # the compute dtype is part of the key: the derived layouts are stored in it (bf16, or fp16 inside an fp16 scope)
+        key = tuple((t.data_ptr(), t._version, t.device) for t in srcs if t is not None) + (cdt(),)
         if key != self.key:
             with torch.no_grad():
                 self.val = fn()

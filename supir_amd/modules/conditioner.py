@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import ops
 from .. import weights as Wt
-from .base import BF16, Linear, Norm, Prep
+from .base import cdt, Linear, Norm, Prep
 
 MAX_LENGTH = 77
 
@@ -152,7 +152,7 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
         tm = self.transformer.text_model
         dev = tm.embeddings.token_embedding.weight.device
         tokens = tokens.to(dev)
-        x = (tm.embeddings.token_embedding.weight[tokens] + tm.embeddings.position_embedding.weight[None, :tokens.shape[1]]).to(BF16)
+        x = (tm.embeddings.token_embedding.weight[tokens] + tm.embeddings.position_embedding.weight[None, :tokens.shape[1]]).to(cdt())
         x = x.contiguous()
         n_layers = self.layer_idx if self.layer_idx >= 0 else len(tm.encoder.layers) + 1 + self.layer_idx
         for lyr in list(tm.encoder.layers)[:n_layers]:
@@ -245,7 +245,7 @@ class FrozenOpenCLIPEmbedder2(AbstractEmbModel):
         m = self.model
         dev = m.positional_embedding.device
         tokens = tokens.to(dev)
-        x = (m.token_embedding.weight[tokens] + m.positional_embedding[None]).to(BF16).contiguous()
+        x = (m.token_embedding.weight[tokens] + m.positional_embedding[None]).to(cdt()).contiguous()
         blocks = list(m.transformer.resblocks)
         pen = None
         for i, blk in enumerate(blocks):

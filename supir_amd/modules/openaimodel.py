@@ -11,7 +11,7 @@ import torch.nn as nn
 from .. import ops
 from .. import weights as Wt
 from .attention import SpatialTransformer
-from .base import BF16, Conv3x3, GroupNorm32, Linear, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc
+from .base import cdt, Conv3x3, GroupNorm32, Linear, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc
 
 
 def timestep_embedding(timesteps, dim, max_period=10000):
@@ -112,7 +112,7 @@ class ResBlock(TimestepBlock):
             e, raw = None, emb
         if e is None:  # stand-alone use: project this block's embedding here
             el = self.emb_layers[1]
-            e = ops.gemm(torch.nn.functional.silu(raw.float()).to(BF16), el.w(), el.b32())
+            e = ops.gemm(torch.nn.functional.silu(raw.float()).to(cdt()), el.w(), el.b32())
         n0, c0 = self.in_layers[0], self.in_layers[2]
         # GroupNorm statistics ride the producer's epilogue where there is one (ops.GnPart): the input's from whichever module made
         # it, conv1's output for out_layers, and this block's output for whoever normalises it next
@@ -208,7 +208,7 @@ class UNetModel(nn.Module):
     def _embed(self, timesteps, y):
         """emb = time_embed(t_emb) + label_emb(y); then ONE GEMM projects SiLU(emb) for every ResBlock
         (reference: per-block emb_layers Linear, openaimodel.py:287-293,343)."""
-        te = timestep_embedding(timesteps, self.model_channels).to(BF16)
+        te = timestep_embedding(timesteps, self.model_channels).to(cdt())
         l0, l2 = self.time_embed[0], self.time_embed[2]
         emb = ops.gemm(ops.gemm(te, l0.w(), l0.b32(), act=1), l2.w(), l2.b32(), out_dtype=torch.float32)
         emb = emb + self._label(y)
@@ -218,12 +218,12 @@ class UNetModel(nn.Module):
             torch.cat([Wt.linear_w(b.emb_layers[1].weight) for b in blocks], 0).contiguous(),
             torch.cat([Wt.f32(b.emb_layers[1].bias) for b in blocks], 0).contiguous(),
             [b.out_channels for b in blocks]))
-        proj_all = ops.gemm(torch.nn.functional.silu(emb).to(BF16), w_all, b_all)
+        proj_all = ops.gemm(torch.nn.functional.silu(emb).to(cdt()), w_all, b_all)
         proj, o = {}, 0
         for b, n in zip(blocks, offs):
             proj[id(b)] = proj_all[:, o:o + n]
             o += n
-        return EmbBundle(emb.to(BF16), proj)
+        return EmbBundle(emb.to(cdt()), proj)
 
     def _label(self, y):
         """label_emb(y): constant over the sampling loop -> cached per y-shape on tensor identity/version and refreshed in
@@ -232,11 +232,11 @@ class UNetModel(nn.Module):
         if cache is None:
             cache = {}
             object.__setattr__(self, "_label_cache", cache)
-        key = (tuple(y.shape), y.device)
+        key = (tuple(y.shape), y.device) + ops._k(cdt())
         c = cache.get(key)
         if c is None or c[0] is not y or c[1] != y._version:
             m0, m2 = self.label_emb[0][0], self.label_emb[0][2]
-            lab = ops.gemm(ops.gemm(y.to(BF16).contiguous(), m0.w(), m0.b32(), act=1), m2.w(), m2.b32(),
+            lab = ops.gemm(ops.gemm(y.to(cdt()).contiguous(), m0.w(), m0.b32(), act=1), m2.w(), m2.b32(),
                            out_dtype=torch.float32, out=None if c is None else c[2])
             cache[key] = (y, y._version, lab)
         return cache[key][2]
@@ -252,7 +252,7 @@ class UNetModel(nn.Module):
 
     def _conv_in(self, x, add=None):
         c = self.input_blocks[0][0]
-        return to_nchw(ops.conv3x3_smallcin(x.float(), c.wf32(), c.b32(), add=add))
+        return to_nchw(ops.conv3x3_smallcin(x.float(), c.wf32(), c.b32(), add=add, dtype=cdt()))
 
     def _out(self, h):
         n, c = self.out[0], self.out[2]

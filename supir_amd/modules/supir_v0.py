@@ -8,7 +8,7 @@ import torch.nn as nn
 from .. import ops
 from .. import weights as Wt
 from .attention import CrossAttention, MemoryEfficientCrossAttention, SpatialTransformer
-from .base import BF16, Conv3x3, GroupNorm32, Linear, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc
+from .base import cdt, Conv3x3, GroupNorm32, Linear, Passthrough, Prep, attach_gn_part, gn_part_of, to_nchw, to_nhwc
 from .openaimodel import TimestepBlock, TimestepEmbedSequential, UNetModel, Upsample
 
 
@@ -114,7 +114,7 @@ class GLVControl(UNetModel):
     def forward(self, x, timesteps, xt, context=None, y=None, **kwargs):
         emb = self._embed(timesteps, y)
         hint = self.input_hint_block[0]
-        guided_hint = ops.conv3x3_smallcin(x.float(), hint.wf32(), hint.b32())
+        guided_hint = ops.conv3x3_smallcin(x.float(), hint.wf32(), hint.b32(), dtype=cdt())
         h = self._conv_in(xt, add=guided_hint)          # input_blocks[0](xt) + guided_hint in one kernel
         hs = [h]
         for module in list(self.input_blocks)[1:]:

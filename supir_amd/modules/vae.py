@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .base import BF16, Conv3x3, Linear, Normalize, Prep, to_nchw, to_nhwc
+from .base import cdt, Conv3x3, Linear, Normalize, Prep, to_nchw, to_nhwc
 from .. import weights as Wt
 
 
@@ -62,14 +62,14 @@ class AttnBlock(nn.Module):
         else:
             # the padded buffer's batch stride (Tp*C) differs from its dense row extent (T*C), so a [B, T, C] view of it is not
             # a uniform-stride row matrix: project one batch element at a time (tiled-VAE tiles with B > 1 hit this)
-            k = torch.zeros(B, Tp, C, dtype=BF16, device=n.device)
+            k = torch.zeros(B, Tp, C, dtype=cdt(), device=n.device)
             for b in range(B):
                 ops.gemm(n[b], self.k.w(), self.k.b32(), out=k[b, :T])
         vt = ops.gemm_t(n, self.v.w(), self.v.b32(), B, T, Tp)       # [B, C, Tp], zero padded
-        o = torch.empty(B, T, C, dtype=BF16, device=n.device)
+        o = torch.empty(B, T, C, dtype=cdt(), device=n.device)
         for b in range(B):
             s = ops.gemm(q[b], k[b], out_dtype=torch.float32)       # [T, Tp] fp32 scores
-            p = ops.softmax_rows(s, C ** -0.5, valid=T)
+            p = ops.softmax_rows(s, C ** -0.5, valid=T, dtype=cdt())
             ops.gemm(p, vt[b], out=o[b])                            # P [T,Tp] . (V^T [C,Tp])^T
         return o
 
@@ -154,7 +154,7 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         """fp32 NCHW image [N,3,H,W] -> fp32 NCHW moments-before-quant [N,8,H/8,W/8] (model.py:571-596)."""
-        h = to_nchw(ops.conv3x3_smallcin(x.float(), self.conv_in.wf32(), self.conv_in.b32()))
+        h = to_nchw(ops.conv3x3_smallcin(x.float(), self.conv_in.wf32(), self.conv_in.b32(), dtype=cdt()))
         for i_level in range(self.num_resolutions):
             for blk in self.down[i_level].block:
                 h = blk(h)
@@ -196,7 +196,7 @@ class Decoder(nn.Module):
 
     def forward(self, z, **kwargs):
         """fp32 NCHW [N,4,h,w] (after post_quant_conv) -> fp32 NCHW image [N,3,8h,8w] (model.py:710-743)."""
-        h = to_nchw(ops.conv3x3_smallcin(z.float(), self.conv_in.wf32(), self.conv_in.b32()))
+        h = to_nchw(ops.conv3x3_smallcin(z.float(), self.conv_in.wf32(), self.conv_in.b32(), dtype=cdt()))
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         for i_level in reversed(range(self.num_resolutions)):
             for blk in self.up[i_level].block:

@@ -1,16 +1,25 @@
 """ControlWrapper (sgm/modules/diffusionmodules/wrappers.py:68-102): control_model -> diffusion_model -> fp32.
 
-`dtype` is kept for the attribute protocol (`model.model.dtype = ...`, test.py:67-68).  The HIP path has ONE compute type:
-bf16 MFMA operands with fp32 accumulation (`effective_dtype`).  A request for torch.float16 (the reference's default
-`diff_dtype`, options/SUPIR_v0.yaml:5, test.py:68) is NOT silently accepted: the first call emits a RuntimeWarning saying that
-fp16 (10 mantissa bits) is served by bf16 (7 mantissa bits, wider exponent -- no fp16 overflow guards needed), and
-SUPIR_STRICT_DTYPE=1 turns that into an error.  fp32 requests are served by bf16 as well (the reference itself autocasts).
+`dtype` follows the attribute protocol (`model.model.dtype = ...`, test.py:67-68) and selects the element type the kernels run in
+(`effective_dtype`): torch.bfloat16 / torch.float32 -> bf16 MFMA operands with fp32 accumulation (libsupir_hip.so; the reference
+itself autocasts fp32 requests); torch.float16 (the reference's default `diff_dtype`, options/SUPIR_v0.yaml:5, test.py:68) -> the
+fp16 build of the same kernels (libsupir_hip_f16.so: fp16 MFMA operands and activations, fp32 accumulation and epilogues), i.e.
+the reference's own precision for BASELINE config 5.  FP16_NATIVE = False (env SUPIR_FP16_NATIVE=0) restores the earlier
+behaviour for fp16 requests: served by bf16, never silently -- the first call emits a RuntimeWarning saying that fp16 (10 mantissa
+bits) is computed in bf16 (7 bits, wider exponent), and SUPIR_STRICT_DTYPE=1 turns that into an error.
 
 Optional hipGraph replay: one CFG-doubled step is ~1700 kernel launches issued from Python; `enable_graph()` captures
 them once per (shape, control_scale) and replays the graph on later steps (inputs copied into static buffers).
 """
+import os
+
 import torch
 import torch.nn as nn
+
+from .. import weights as Wt
+
+# fp16 requests run on the fp16 build of the kernels (True) or are served by bf16 with a warning (False)
+FP16_NATIVE = os.environ.get("SUPIR_FP16_NATIVE", "0") == "1"
 
 
 class ControlWrapper(nn.Module):
@@ -34,8 +43,12 @@ class ControlWrapper(nn.Module):
         self.prefetch_kind = "inline"
         self._side = None
         self._warm = False
-        self.effective_dtype = torch.bfloat16   # what the kernels compute in, whatever `dtype` asks for
         self._dtype_noted = False
+
+    @property
+    def effective_dtype(self):
+        """What the kernels compute in for the current `dtype` request."""
+        return torch.float16 if (self.dtype == torch.float16 and FP16_NATIVE) else torch.bfloat16
 
     def load_control_model(self, control_model):
         self.control_model = control_model
@@ -90,7 +103,7 @@ class ControlWrapper(nn.Module):
         if ctx is not None and vec is not None:
             # this call (re)filled the shared text-K/V^T / label buffers with ITS conditioning: graphs of the same shape that
             # were captured with another prompt must refresh before their next replay (_forward_graph checks this token)
-            self._resident[(tuple(ctx.shape), tuple(vec.shape))] = (ctx, ctx._version, vec, vec._version)
+            self._resident[(tuple(ctx.shape), tuple(vec.shape), Wt.cdt())] = (ctx, ctx._version, vec, vec._version)
         return out.float()
 
     # ------------------------------------------------------------------ hipGraph replay
@@ -102,14 +115,14 @@ class ControlWrapper(nn.Module):
 
     def _forward_graph(self, x, t, c, control_scale):
         ctx, vec, ctl = c["crossattn"], c["vector"], c["control"]
-        key = (tuple(x.shape), float(control_scale), tuple(ctx.shape), tuple(vec.shape))
+        key = (tuple(x.shape), float(control_scale), tuple(ctx.shape), tuple(vec.shape), Wt.cdt())
         g = self._graphs.get(key)
         if g is None:
             # control_scale is a launch argument baked into the captured kernels.  With use_linear_control_scale
             # (sampling.py:557-559) it changes on every step: capturing a graph per value would cost three network calls per
             # step, so after two CONSECUTIVE misses for a shape such calls run eagerly.  A hit resets the streak, so a new
             # constant scale on a later image (1.0, then 0.9, then 0.8 ...) still gets its graph.
-            skey = (key[0], key[2], key[3])
+            skey = (key[0], key[2], key[3], key[4])
             self._cs_miss[skey] = self._cs_miss.get(skey, 0) + 1
             if self._cs_miss[skey] > 2:
                 return self._forward_eager(x, t, c, control_scale)
@@ -142,9 +155,9 @@ class ControlWrapper(nn.Module):
             g = [graph, sx, st, sc, out]
             self._graphs[key] = g
         else:
-            self._cs_miss[(key[0], key[2], key[3])] = 0
+            self._cs_miss[(key[0], key[2], key[3], key[4])] = 0
         graph, sx, st, sc, out = g[:5]
-        rkey = (key[2], key[3])
+        rkey = (key[2], key[3], key[4])
         res = self._resident.get(rkey)
         if res is None or res[0] is not ctx or res[1] != ctx._version or res[2] is not vec or res[3] != vec._version:
             # the shared buffers hold another prompt's K / V^T / label embedding (a new prompt, or another graph / an eager call
@@ -162,20 +175,19 @@ class ControlWrapper(nn.Module):
         if self._dtype_noted:
             return
         self._dtype_noted = True
-        if self.dtype == torch.float16:
-            import os
+        if self.dtype == torch.float16 and not FP16_NATIVE:
             import warnings
-            msg = ("ControlWrapper.dtype is torch.float16 (the reference's default diff_dtype), but the MI355X path computes in "
+            msg = ("ControlWrapper.dtype is torch.float16 (the reference's default diff_dtype), but SUPIR_FP16_NATIVE=0 serves it in "
                    "bfloat16 MFMA with fp32 accumulation: 7 mantissa bits instead of fp16's 10 (per-call rel-L2 vs fp32 ~7e-3 "
-                   "instead of ~1e-3).  Set model.model.dtype = torch.bfloat16 (test.py --diff_dtype bf16) to acknowledge, or "
-                   "SUPIR_STRICT_DTYPE=1 to make this an error.")
+                   "instead of ~1e-3).  Set model.model.dtype = torch.bfloat16 (test.py --diff_dtype bf16) to acknowledge, "
+                   "SUPIR_FP16_NATIVE=1 to run the fp16 build of the kernels, or SUPIR_STRICT_DTYPE=1 to make this an error.")
             if os.environ.get("SUPIR_STRICT_DTYPE") == "1":
                 raise RuntimeError(msg)
             warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
     def forward(self, x, t, c, control_scale=1, **kwargs):
         self._note_dtype()
-        with torch.no_grad():
+        with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
             if self._graph_on and not kwargs and x.is_cuda:
                 return self._forward_graph(x, t, c, control_scale)
             return self._forward_eager(x, t, c, control_scale, **kwargs)

@@ -9,8 +9,15 @@ import math
 import torch
 
 from . import _lib
+from .weights import HALF_TYPES
 
 BF16 = torch.bfloat16
+
+
+def _k(dtype):
+    """Suffix for autotune / choice keys: the fp16 library's kernels are timed and cached separately from the bf16 ones (the bf16
+    keys stay exactly what they were)."""
+    return () if dtype == BF16 else ("f16",)
 
 # --------------------------------------------------------------------------------------------- op trace (bench / roofline)
 _TRACE = None
@@ -205,7 +212,8 @@ class WeightPrefetch:
             if self.kind == "stream" and self.stream is not None:
                 torch.cuda.current_stream().wait_stream(self.stream)     # join (required inside a capture)
             else:
-                _lib.load().supir_set_next_prefetch(None, 0)
+                for lib in _lib.loaded():   # the one-shot request lives in the library that would have launched next
+                    lib.supir_set_next_prefetch(None, 0)
         self.mode = None
 
     def touch(self, w):
@@ -226,7 +234,7 @@ class WeightPrefetch:
                 self.stream.wait_event(ev)
                 _lib.load().supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
             else:
-                _lib.load().supir_set_next_prefetch(ptr, nb)
+                _lib.load(w.dtype).supir_set_next_prefetch(ptr, nb)
 
 
 _PF = None
@@ -270,30 +278,31 @@ def _gn_part_request(lib, tile, nbatch, rows_per_batch, N, device):
 
 # --------------------------------------------------------------------------------------------- GEMM family
 def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=0, alpha=1.0, out=None,
-         out_dtype=BF16, tile=-1, alt16=None, gn_part=False):
+         out_dtype=None, tile=-1, alt16=None, gn_part=False):
     """out[M,N] = alpha*act(a[M,K] @ w[N,K]^T + bias + rowbias[batch]) + residual.  act=2 (GEGLU) -> N/2 columns.
     alt16 = (w, bias) in the 16-row GEGLU interleave: lets the autotuner also try tile 34 (csrc/gemm16.hip).
     gn_part=True: returns (out, GnPart or None) -- GroupNorm statistics of `out` per batch of `rows_per_batch` rows, when the tile
-    that runs can emit them."""
-    lib = _lib.load()
+    that runs can emit them.  The element type (bf16 or fp16) is that of `a`; every 16-bit operand must share it."""
+    DT = a.dtype
+    lib = _lib.load(DT)
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
     N = w.shape[0]
-    assert w.shape[1] == K and w.is_contiguous() and w.dtype == BF16 and a.dtype == BF16
+    assert DT in HALF_TYPES and w.shape[1] == K and w.is_contiguous() and w.dtype == DT
     n_out = N // 2 if act == 2 else N
     if out is None:
-        out = torch.empty(*a.shape[:-1], n_out, dtype=out_dtype, device=a.device)
+        out = torch.empty(*a.shape[:-1], n_out, dtype=DT if out_dtype is None else out_dtype, device=a.device)
     Mo, No, ldc = _rows_ld(out)
-    assert Mo == M and No == n_out
+    assert Mo == M and No == n_out and out.dtype in (DT, torch.float32)
     ldr = 0
     if residual is not None:
         Mr, Nr, ldr = _rows_ld(residual)
-        assert Mr == M and Nr == n_out and residual.dtype == BF16
+        assert Mr == M and Nr == n_out and residual.dtype == DT
     ld_rb = 0
     if rowbias is not None:
-        assert rowbias.dtype == BF16 and rowbias.stride(-1) == 1 and rowbias.shape[-1] == N
+        assert rowbias.dtype == DT and rowbias.stride(-1) == 1 and rowbias.shape[-1] == N
         ld_rb = rowbias.stride(0)
-    om = 0 if out.dtype == BF16 else 1
+    om = 0 if out.dtype == DT else 1
 
     def launch(t, outp=None):
         wq, bq = (alt16[0], alt16[1]) if (t in (34, 37) and act == 2 and alt16 is not None) else (w, bias)
@@ -301,7 +310,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
                                    _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, act, om, alpha, t, _stream())
 
     if tile == -1:
-        key = ("gemm", M, N, K, act, om)
+        key = ("gemm", M, N, K, act, om) + _k(DT)
         ok = (lda % 8 == 0 and out.data_ptr() % 16 == 0 and (residual is None or ldr % 4 == 0)
               and (rowbias is None or ld_rb % 4 == 0))
         cands = _gemm_candidates(M, N, K, act, om, ldc, epilogue_ok=ok, geglu16=alt16 is not None)
@@ -322,7 +331,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         part = _gn_part_request(lib, tile, M // rows_per_batch if rows_per_batch else 1, rows_per_batch or M, N, a.device)
     ev = _ev()
     rc = launch(tile)
-    _lib.check(rc, "supir_gemm_bf16")
+    _lib.check(rc, "supir_gemm_bf16", lib)
     _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act, tile=tile)
     return (out, part) if gn_part else out
 
@@ -387,22 +396,23 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
     """GEMM with LayerNorm folding (see supir_gemm_bf16_ln).  ln = RowStats of `a` (consumer side), emit_stats=True makes
     this call a producer and returns (out, RowStats).  trans=(B, T, Tpad) selects the transposed (V^T) output.
     alt16 = (w, colsum, bias) in the 16-row GEGLU interleave (act = 2): lets the autotuner also try tile 34."""
-    lib = _lib.load()
+    DT = a.dtype
+    lib = _lib.load(DT)
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
     N = w.shape[0]
-    assert w.shape[1] == K and w.is_contiguous() and w.dtype == BF16 and a.dtype == BF16
+    assert DT in HALF_TYPES and w.shape[1] == K and w.is_contiguous() and w.dtype == DT
     n_out = N // 2 if act == 2 else N
     if trans is not None:
         B, T, Tpad = trans
         assert M == B * T
         if out is None:
-            out = torch.zeros(B, N, Tpad, dtype=BF16, device=a.device) if Tpad != T else \
-                torch.empty(B, N, Tpad, dtype=BF16, device=a.device)
+            out = torch.zeros(B, N, Tpad, dtype=DT, device=a.device) if Tpad != T else \
+                torch.empty(B, N, Tpad, dtype=DT, device=a.device)
         ldc, om, rpb = Tpad, 2, T
     else:
         if out is None:
-            out = torch.empty(*a.shape[:-1], n_out, dtype=BF16, device=a.device)
+            out = torch.empty(*a.shape[:-1], n_out, dtype=DT, device=a.device)
         _, _, ldc = _rows_ld(out)
         om, rpb = 0, 0
     ldr = 0
@@ -426,7 +436,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
                                       _p(cq), ln_eps, _stream())
 
     if tile == -1:
-        key = ("gemm", M, N, K, act, om)
+        key = ("gemm", M, N, K, act, om) + _k(DT)
         ok = (lda % 8 == 0 and out.data_ptr() % 16 == 0 and (residual is None or ldr % 4 == 0)
               and (trans is None or rpb % 4 == 0))
         cands = _gemm_candidates(M, N, K, act, om, ldc, ln_slots=ln_slots, epilogue_ok=ok, geglu16=alt16 is not None)
@@ -442,7 +452,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
     _pf(w)
     ev = _ev()
     rc = launch(tile)
-    _lib.check(rc, "supir_gemm_bf16_ln")
+    _lib.check(rc, "supir_gemm_bf16_ln", lib)
     _rec("gemm_t" if trans is not None else "gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act,
          tile=tile)
     if emit_stats:
@@ -464,15 +474,16 @@ def gemm_qkv_supported(M, N, n_split, K, T):
 def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, out_qk=None, out_vt=None):
     """Fused q | k | v projection: a [B*T, K] -> (qk [B, T, n_split] bf16, v^T [B, N - n_split, T] bf16) in one launch; optional
     LayerNorm fold as in gemm_ln.  Callers check gemm_qkv_supported first."""
-    lib = _lib.load()
+    DT = a.dtype
+    lib = _lib.load(DT)
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
     N = w.shape[0]
-    assert M == B * T and w.shape[1] == K and w.is_contiguous() and w.dtype == BF16 and a.dtype == BF16
+    assert DT in HALF_TYPES and M == B * T and w.shape[1] == K and w.is_contiguous() and w.dtype == DT
     if out_qk is None:
-        out_qk = torch.empty(B, T, n_split, dtype=BF16, device=a.device)
+        out_qk = torch.empty(B, T, n_split, dtype=DT, device=a.device)
     if out_vt is None:
-        out_vt = torch.empty(B, N - n_split, T, dtype=BF16, device=a.device)
+        out_vt = torch.empty(B, N - n_split, T, dtype=DT, device=a.device)
     ln_p, ln_ld, ln_slots = 0, 0, 0
     if ln is not None:
         ln_p, ln_ld, ln_slots = ln.buf.data_ptr(), ln.ld, ln.slots
@@ -481,7 +492,7 @@ def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, ou
     ev = _ev()
     rc = lib.supir_gemm_bf16_qkv(a.data_ptr(), w.data_ptr(), out_qk.data_ptr(), out_vt.data_ptr(), M, N, n_split, K, lda, n_split, T, T,
                                  _p(bias), ln_p, ln_ld, ln_slots, _p(colsum), ln_eps, _stream())
-    _lib.check(rc, "supir_gemm_bf16_qkv")
+    _lib.check(rc, "supir_gemm_bf16_qkv", lib)
     _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev, M=M, N=N, K=K, act=0, tile=36)
     return out_qk, out_vt
 
@@ -515,14 +526,16 @@ def choose(key, fns):
 
 def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
     """Transposed projection: out[b][n][t] = (a[b*T+t] @ w[n]) (+bias); out is [B, N, Tpad] (zero padded)."""
-    lib = _lib.load()
+    DT = a.dtype
+    lib = _lib.load(DT)
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
-    assert M == B * T
+    assert M == B * T and DT in HALF_TYPES and w.dtype == DT
     N = w.shape[0]
     if out is None:
-        out = torch.zeros(B, N, Tpad, dtype=BF16, device=a.device) if Tpad != T else \
-            torch.empty(B, N, Tpad, dtype=BF16, device=a.device)
+        out = torch.zeros(B, N, Tpad, dtype=DT, device=a.device) if Tpad != T else \
+            torch.empty(B, N, Tpad, dtype=DT, device=a.device)
+    assert out.dtype == DT
 
     def launch(t):
         return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, Tpad, _p(bias), 0, 0, T, 0, 0, 0, 2,
@@ -530,13 +543,13 @@ def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
 
     if tile == -1:
         cands = _gemm_candidates(M, N, K, 0, 2, Tpad, epilogue_ok=(lda % 8 == 0 and T % 4 == 0))
-        tile = _autotune(("gemm", M, N, K, 0, 2), cands, launch)
+        tile = _autotune(("gemm", M, N, K, 0, 2) + _k(DT), cands, launch)
         if tile >= 32 and tile not in cands:
             tile = -1
     _pf(w)
     ev = _ev()
     rc = launch(tile)
-    _lib.check(rc, "supir_gemm_bf16(T)")
+    _lib.check(rc, "supir_gemm_bf16(T)", lib)
     _rec("gemm_t", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev, M=M, N=N, K=K, act=0, tile=tile)
     return out
 
@@ -545,12 +558,13 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
             act=0, alpha=1.0, out=None, tile=-1, gn_part=False):
     """x [B,H,W,Cin(ld)] bf16 -> [B,OH,OW,Cout]. w [Cout,3,3,Cin] bf16. pad=(top,left); bottom/right implied by out_hw.
     gn_part=True: returns (out, GnPart or None) -- GroupNorm statistics of `out` from the epilogue, when the tile that runs can emit them."""
-    lib = _lib.load()
+    DT = x.dtype
+    lib = _lib.load(DT)
     _check_dev(x, w)
     B, H, W, Cin = x.shape
     _, _, ldx = _rows_ld(x)
     Cout = w.shape[0]
-    assert w.shape[1:] == (3, 3, Cin) and w.is_contiguous() and w.dtype == BF16 and x.dtype == BF16
+    assert DT in HALF_TYPES and w.shape[1:] == (3, 3, Cin) and w.is_contiguous() and w.dtype == DT
     if out_hw is None:
         if upsample:
             out_hw = (2 * H, 2 * W)
@@ -560,17 +574,18 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
             out_hw = ((H + 2 * pad[0] - 3) // stride + 1, (W + 2 * pad[1] - 3) // stride + 1)
     OH, OW = out_hw
     if out is None:
-        out = torch.empty(B, OH, OW, Cout, dtype=BF16, device=x.device)
+        out = torch.empty(B, OH, OW, Cout, dtype=DT, device=x.device)
     _, _, ldy = _rows_ld(out)
+    assert out.dtype in (DT, torch.float32)
     ldr = 0
     if residual is not None:
-        assert residual.shape == out.shape and residual.dtype == BF16
+        assert residual.shape == out.shape and residual.dtype == DT
         _, _, ldr = _rows_ld(residual)
     ld_rb = 0
     if rowbias is not None:
-        assert rowbias.dtype == BF16 and rowbias.shape == (B, Cout) and rowbias.stride(-1) == 1
+        assert rowbias.dtype == DT and rowbias.shape == (B, Cout) and rowbias.stride(-1) == 1
         ld_rb = rowbias.stride(0)
-    om = 0 if out.dtype == BF16 else 1
+    om = 0 if out.dtype == DT else 1
 
     def launch(t):
         return lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cin, ldx, Cout, ldy, OH, OW, stride,
@@ -585,7 +600,7 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
             for t, (bm, bn, ks, s_) in _G16.items():   # same predicate as supir_gemm16_supported(conv)
                 if t in G16_TILES and M_ % bm == 0 and Cout % bn == 0 and Cin % (64 * ks) == 0 and (9 * Cin // 64) // ks >= s_ - 1:
                     cands.append(t)
-        key = ("conv", B, H, W, Cin, Cout, stride, bool(upsample))
+        key = ("conv", B, H, W, Cin, Cout, stride, bool(upsample)) + _k(DT)
         if residual is not None and residual.data_ptr() == out.data_ptr():
             tile = _TUNE.get(key, -1)
         else:
@@ -596,7 +611,7 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
     part = _gn_part_request(lib, tile, B, OH * OW, Cout, x.device) if (gn_part and om == 0) else None
     ev = _ev()
     rc = launch(tile)
-    _lib.check(rc, "supir_conv3x3_bf16")
+    _lib.check(rc, "supir_conv3x3_bf16", lib)
     M = B * OH * OW
     _rec("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout), ev, M=M, N=Cout, K=9 * Cin,
          act=act, tile=tile)
@@ -607,14 +622,16 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
 def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     """q [B,Tq,>=H*64] k [B,Tk,>=H*64] (views with row stride), vt [B,H*64,Tpad]; returns [B,Tq,H*64].
     causal=True (text towers): query i sees keys j <= i."""
-    lib = _lib.load()
+    DT = q.dtype
+    lib = _lib.load(DT)
     _check_dev(q, k, vt)
-    assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16
+    assert DT in HALF_TYPES and k.dtype == DT and vt.dtype == DT
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and vt.is_contiguous()
     ldq, ldk, ldvt = q.stride(-2), k.stride(-2), vt.shape[-1]
     assert q.shape[0] == B and q.stride(0) == Tq * ldq and k.stride(0) == Tk * ldk
     if out is None:
-        out = torch.empty(B, Tq, H * 64, dtype=BF16, device=q.device)
+        out = torch.empty(B, Tq, H * 64, dtype=DT, device=q.device)
+    assert out.dtype == DT
     ev = _ev()
     if causal:
         rc = lib.supir_flash_attn_d64_ex(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
@@ -622,23 +639,25 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     else:
         rc = lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
                                       out.stride(-2), 0.125, _stream())
-    _lib.check(rc, "supir_flash_attn_d64")
+    _lib.check(rc, "supir_flash_attn_d64", lib)
     _rec("attn", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * H * 64 * (2 * Tq + 2 * Tk), ev, B=B, H=H, Tq=Tq, Tk=Tk)
     return out
 
 
-def softmax_rows(s, scale, out=None, valid=None):
-    """softmax over the first `valid` columns of fp32 scores [rows, Tpad]; remaining columns of the bf16 output are zero."""
-    lib = _lib.load()
+def softmax_rows(s, scale, out=None, valid=None, dtype=None):
+    """softmax over the first `valid` columns of fp32 scores [rows, Tpad]; remaining columns of the 16-bit output (`dtype`,
+    default: that of `out`, else bf16) are zero."""
+    DT = out.dtype if out is not None else (BF16 if dtype is None else dtype)
+    lib = _lib.load(DT)
     _check_dev(s)
     rows, Tp = s.shape
     T = Tp if valid is None else valid
-    assert s.dtype == torch.float32 and s.stride(1) == 1
+    assert s.dtype == torch.float32 and s.stride(1) == 1 and DT in HALF_TYPES
     if out is None:
-        out = torch.empty(rows, Tp, dtype=BF16, device=s.device)
+        out = torch.empty(rows, Tp, dtype=DT, device=s.device)
     ev = _ev()
     rc = lib.supir_softmax_rows(s.data_ptr(), out.data_ptr(), rows, T, Tp, s.stride(0), out.stride(0), scale, _stream())
-    _lib.check(rc, "supir_softmax_rows")
+    _lib.check(rc, "supir_softmax_rows", lib)
     _rec("softmax", 0, 6.0 * rows * T, ev)
     return out
 
@@ -646,15 +665,16 @@ def softmax_rows(s, scale, out=None, valid=None):
 # --------------------------------------------------------------------------------------------- norms
 def groupnorm_stats(x):
     """(sum, sum of squares) per (batch, group) of a channels-last tensor: fp32 [B, 32, 2]."""
-    lib = _lib.load()
+    lib = _lib.load(x.dtype)
     _check_dev(x)
+    assert x.dtype in HALF_TYPES
     B = x.shape[0]
     HW = int(math.prod(x.shape[1:-1]))
     _, C, ld = _rows_ld(x)
     ws = _gn_workspace(B, x.device)
     out = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
     rc = lib.supir_groupnorm_stats(x.data_ptr(), 0, B, HW, C, C, ld, 0, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
-    _lib.check(rc, "supir_groupnorm_stats")
+    _lib.check(rc, "supir_groupnorm_stats", lib)
     return out
 
 
@@ -662,8 +682,10 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
               x2raw=None, out=None, given=None, part=None, part2=None):
     """GroupNorm(32) over channels-last x (optionally the channel concat [x | x2]); see supir_groupnorm_nhwc.
     part / part2 = GnPart of x / x2 from their producers: one launch, no statistics pass (supir_groupnorm_nhwc_parts)."""
-    lib = _lib.load()
+    DT = x.dtype
+    lib = _lib.load(DT)
     _check_dev(x, gamma, beta)
+    assert DT in HALF_TYPES and all(t is None or t.dtype == DT for t in (x2, mod_g, mod_b, x1raw, x2raw, out))
     B = x.shape[0]
     HW = int(math.prod(x.shape[1:-1]))
     _, C1, ld1 = _rows_ld(x)
@@ -674,7 +696,7 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
         C = C1 + C2
     assert gamma.numel() == C and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     if out is None:
-        out = torch.empty(*x.shape[:-1], C, dtype=BF16, device=x.device)
+        out = torch.empty(*x.shape[:-1], C, dtype=DT, device=x.device)
     _, Co, ldo = _rows_ld(out)
     assert Co == C
     ldm = 0
@@ -691,44 +713,48 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
                                             out.data_ptr(), ldo, part.buf.data_ptr(), part.nchunk,
                                             0 if part2 is None else part2.buf.data_ptr(), 0 if part2 is None else part2.nchunk,
                                             _stream())
-        _lib.check(rc, "supir_groupnorm_nhwc_parts")
+        _lib.check(rc, "supir_groupnorm_nhwc_parts", lib)
     else:
         ws = _gn_workspace(B, x.device)
         rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
                                       beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
                                       out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _p(given), _stream())
-        _lib.check(rc, "supir_groupnorm_nhwc")
+        _lib.check(rc, "supir_groupnorm_nhwc", lib)
     n = B * HW * C
     _rec("groupnorm", 0, 2.0 * n * (2 + (2 if mod_g is not None else 0)), ev, B=B, HW=HW, C=C, parts=use_parts)
     return out
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
-    lib = _lib.load()
+    DT = x.dtype
+    lib = _lib.load(DT)
     _check_dev(x, gamma, beta)
+    assert DT in HALF_TYPES and (out is None or out.dtype == DT)
     rows, C, ldx = _rows_ld(x)
     if out is None:
-        out = torch.empty(*x.shape, dtype=BF16, device=x.device)
+        out = torch.empty(*x.shape, dtype=DT, device=x.device)
     _, _, ldy = _rows_ld(out)
     ev = _ev()
     rc = lib.supir_layernorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, ldx, ldy, eps,
                              _stream())
-    _lib.check(rc, "supir_layernorm")
+    _lib.check(rc, "supir_layernorm", lib)
     _rec("layernorm", 0, 4.0 * rows * C, ev, rows=rows, C=C)
     return out
 
 
 # --------------------------------------------------------------------------------------------- boundary convs
-def conv3x3_smallcin(x_nchw, w, bias, add=None, out=None):
-    """fp32 NCHW [B,Cin<=8,H,W] -> bf16 [B,H,W,Cout]; w fp32 [Cout,Cin,3,3]."""
-    lib = _lib.load()
+def conv3x3_smallcin(x_nchw, w, bias, add=None, out=None, dtype=None):
+    """fp32 NCHW [B,Cin<=8,H,W] -> 16-bit [B,H,W,Cout] (`dtype`; default: that of `out` / `add`, else bf16); w fp32 [Cout,Cin,3,3]."""
+    DT = out.dtype if out is not None else add.dtype if add is not None else (BF16 if dtype is None else dtype)
+    lib = _lib.load(DT)
+    assert DT in HALF_TYPES and (add is None or add.dtype == DT)
     _check_dev(x_nchw, w)
     x_nchw = x_nchw.contiguous()
     assert x_nchw.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous()
     B, Cin, H, W = x_nchw.shape
     Cout = w.shape[0]
     if out is None:
-        out = torch.empty(B, H, W, Cout, dtype=BF16, device=x_nchw.device)
+        out = torch.empty(B, H, W, Cout, dtype=DT, device=x_nchw.device)
     _, _, ldo = _rows_ld(out)
     ld_add = 0
     if add is not None:
@@ -736,25 +762,26 @@ def conv3x3_smallcin(x_nchw, w, bias, add=None, out=None):
     ev = _ev()
     rc = lib.supir_conv3x3_smallcin(x_nchw.data_ptr(), w.data_ptr(), _p(bias), _p(add), out.data_ptr(), B, Cin, H, W, Cout,
                                     ld_add, ldo, _stream())
-    _lib.check(rc, "supir_conv3x3_smallcin")
+    _lib.check(rc, "supir_conv3x3_smallcin", lib)
     _rec("conv_smallcin", 2.0 * B * H * W * Cout * 9 * Cin, B * H * W * (4.0 * Cin + 2.0 * Cout), ev)
     return out
 
 
 def conv3x3_smallcout(x, w9, bias, out=None):
     """bf16 [B,H,W,Cin] -> fp32 NCHW [B,Cout,H,W]; w9 bf16 [9,Cout,Cin]."""
-    lib = _lib.load()
+    DT = x.dtype
+    lib = _lib.load(DT)
     _check_dev(x, w9)
     B, H, W, Cin = x.shape
     _, _, ldx = _rows_ld(x)
     Cout = w9.shape[1]
-    assert w9.shape == (9, Cout, Cin) and w9.dtype == BF16 and w9.is_contiguous()
+    assert DT in HALF_TYPES and w9.shape == (9, Cout, Cin) and w9.dtype == DT and w9.is_contiguous()
     if out is None:
         out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
     ev = _ev()
     rc = lib.supir_conv3x3_smallcout(x.data_ptr(), w9.data_ptr(), _p(bias), out.data_ptr(), B, Cin, H, W, Cout, ldx,
                                      _stream())
-    _lib.check(rc, "supir_conv3x3_smallcout")
+    _lib.check(rc, "supir_conv3x3_smallcout", lib)
     _rec("conv_smallcout", 2.0 * B * H * W * Cout * 9 * Cin, B * H * W * (2.0 * Cin + 4.0 * Cout), ev)
     return out
 

@@ -21,7 +21,7 @@ import math
 import torch
 
 from .. import ops
-from ..modules.base import BF16, to_nchw, to_nhwc
+from ..modules.base import cdt, to_nchw, to_nhwc
 
 
 def get_best_tile_size(lowerbound, upperbound):
@@ -124,7 +124,7 @@ class VAEHook:
         N, height, width = z.shape[0], z.shape[2], z.shape[3]
         in_b, out_b = split_tiles(height, width, self.tile_size, self.pad, dec)
         z = z.float()
-        tiles = [ops.conv3x3_smallcin(z[:, :, b[2]:b[3], b[0]:b[1]].contiguous(), net.conv_in.wf32(), net.conv_in.b32())
+        tiles = [ops.conv3x3_smallcin(z[:, :, b[2]:b[3], b[0]:b[1]].contiguous(), net.conv_in.wf32(), net.conv_in.b32(), dtype=cdt())
                  for b in in_b]
         if dec:
             tiles = _resblock(tiles, net.mid.block_1)

@@ -4,25 +4,55 @@ The state-dict keys/shapes stay exactly the reference's (drop-in `load_state_dic
 device buffers the kernels read, once, instead of autocast re-casting 3.9 G parameters on every step
 (reference: sgm/modules/diffusionmodules/wrappers.py:87).
 """
+import contextlib
+
 import torch
 
 BF16 = torch.bfloat16
+HALF_TYPES = (torch.bfloat16, torch.float16)
+
+# The 16-bit element type the kernels run in ("compute dtype").  bf16 is the product default (libsupir_hip.so); torch.float16
+# selects libsupir_hip_f16.so -- the same kernels built with fp16 MFMA operands (csrc/common.h, SUPIR_F16) -- for callers that ask
+# for the reference's default diff_dtype (options/SUPIR_v0.yaml:5, test.py:67-68: model.model.dtype = torch.float16).  The value
+# is a per-call scope set by the module that owns the request (ControlWrapper / the VAE entry points), never a process global
+# that outlives a call: activations created inside the scope, the derived weight layouts (Prep caches key on it) and the library
+# an op dispatches to (by the dtype of its operands) all follow it.
+_CDT = [BF16]
+
+
+def cdt():
+    """The compute dtype of the innermost active scope (bf16 outside any scope)."""
+    return _CDT[-1]
+
+
+def as_compute_dtype(dtype):
+    """Map a requested module dtype to the kernel element type: fp16 stays fp16, everything else (bf16, fp32) is served by bf16."""
+    return torch.float16 if dtype == torch.float16 else BF16
+
+
+@contextlib.contextmanager
+def compute_dtype(dtype):
+    _CDT.append(as_compute_dtype(dtype))
+    try:
+        yield
+    finally:
+        _CDT.pop()
 
 
 def linear_w(w):
     """nn.Linear / 1x1 conv weight [N, K(,1,1)] -> bf16 [N, K]."""
-    return w.detach().reshape(w.shape[0], -1).to(BF16).contiguous()
+    return w.detach().reshape(w.shape[0], -1).to(cdt()).contiguous()
 
 
 def conv3x3_w(w):
     """nn.Conv2d weight [Cout, Cin, 3, 3] -> bf16 [Cout, 3, 3, Cin] (K = (ky, kx, cin), cin fastest)."""
-    return w.detach().permute(0, 2, 3, 1).to(BF16).contiguous()
+    return w.detach().permute(0, 2, 3, 1).to(cdt()).contiguous()
 
 
 def conv3x3_w9(w):
     """nn.Conv2d weight [Cout<=8, Cin, 3, 3] -> bf16 [9, Cout, Cin] for supir_conv3x3_smallcout."""
     co, ci = w.shape[:2]
-    return w.detach().permute(2, 3, 0, 1).reshape(9, co, ci).to(BF16).contiguous()
+    return w.detach().permute(2, 3, 0, 1).reshape(9, co, ci).to(cdt()).contiguous()
 
 
 def f32(t):
@@ -49,7 +79,7 @@ def fold_layernorm(w, bias, gamma, beta):
     from the ROUNDED W' so that the mean term cancels exactly), b'[n] = bias[n] + sum_k beta[k] W[n,k]).
     LayerNorm(x).W^T + bias == rstd * (x.W'^T - mean*colsum) + b'  (supir_gemm_bf16_ln)."""
     w32 = w.detach().float().reshape(w.shape[0], -1)
-    wp = (w32 * gamma.detach().float()[None, :]).to(BF16).contiguous()
+    wp = (w32 * gamma.detach().float()[None, :]).to(cdt()).contiguous()
     colsum = wp.float().sum(dim=1).contiguous()
     bp = (w32 * beta.detach().float()[None, :]).sum(dim=1)   # elementwise + reduction: no BLAS call on the product path
     if bias is not None:

@@ -26,6 +26,22 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in supir_hip.h but not exported"
     assert lib.supir_abi_version() == 1
     assert lib.supir_target_arch() == b"gfx950"
+    assert lib.supir_elem_type() == b"bf16"
+
+
+def test_f16_library_exports_the_same_surface():
+    """libsupir_hip_f16.so (same sources, -DSUPIR_F16) loads next to the bf16 library, exports every declared symbol, reports its
+    element type and validates arguments the same way; the two handles are distinct objects with their own state."""
+    import torch
+    lib16 = _lib.load(torch.float16)
+    lib = _lib.load()
+    assert lib16 is not lib and _lib.load(torch.bfloat16) is lib and _lib.load(torch.float16) is lib16
+    for name in _header_functions():
+        assert hasattr(lib16, name), f"{name} not exported by the f16 build"
+    assert lib16.supir_abi_version() == 1 and lib16.supir_target_arch() == b"gfx950" and lib16.supir_elem_type() == b"f16"
+    assert lib16.supir_gemm_bf16(None, None, None, 64, 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 0, 1.0, -1, None) == -1
+    fake = 0x10000
+    assert lib16.supir_gemm_bf16(fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 32, None) == -2
 
 
 def test_ctypes_signatures_match_header():
@@ -33,8 +49,8 @@ def test_ctypes_signatures_match_header():
     for name, argtypes in _lib.SIGNATURES.items():
         assert name in fns, name
         assert len(argtypes) == fns[name], (name, len(argtypes), fns[name])
-    assert set(fns) - set(_lib.SIGNATURES) == {"supir_abi_version", "supir_target_arch", "supir_last_hip_error",
-                                                 "supir_hip_error_string"}
+    assert set(fns) - set(_lib.SIGNATURES) == {"supir_abi_version", "supir_target_arch", "supir_elem_type",
+                                                 "supir_last_hip_error", "supir_hip_error_string"}
 
 
 def test_bad_arguments_return_error_codes_without_a_gpu():

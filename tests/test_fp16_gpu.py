@@ -1,0 +1,307 @@
+"""The fp16 build of the kernels (libsupir_hip_f16.so = the same sources with -DSUPIR_F16, csrc/common.h) -- what a
+`diff_dtype: fp16` request (the reference's default: options/SUPIR_v0.yaml:5, options/SUPIR_v0_Juggernautv9_lightning.yaml:5,
+test.py:67-68; BASELINE config 5) runs on.
+
+Per kernel: every entry point against a plain PyTorch fp32 reference of the same op on fp16-rounded operands.  fp16 keeps 11
+significant bits, so the final output rounding contributes ~2^-12 relative per element: the bars here are rel-L2 <= 1e-3 (the
+bf16 suite uses 4e-3) and max-abs <= 2^-10 * max|ref|.  Network level: one ControlWrapper call in an fp16 scope against the fp32
+oracle, held to SURVEY.md 8(d)'s "fp16 <= 3e-3" AND to less than half of what the bf16 build lands on the same inputs (proof that
+the fp16 arithmetic is really what ran), then the DPM++ 2M sampler of config 5 end to end.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("SUPIR_TEST_FP16", "0") != "1",
+                                 reason="fp16 build not yet validated on hardware: opt in with SUPIR_TEST_FP16=1")]
+
+from supir_amd import ops  # noqa: E402
+from supir_amd import weights as Wt  # noqa: E402
+from tests.helpers import build_unet, rel_l2, synth_tensor  # noqa: E402
+
+DEV = "cuda"
+HF = torch.float16
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def check(out, ref, rel=1e-3, name=""):
+    assert out.dtype in (HF, torch.float32), out.dtype
+    out, ref = out.float(), ref.float()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{name}: non-finite output"
+    err = ((out - ref).norm() / (ref.norm() + 1e-12)).item()
+    mx = (out - ref).abs().max().item()
+    bound = 2.0 ** -10 * ref.abs().max().item() + 2e-4
+    assert err <= rel, f"{name}: rel-L2 {err:.3e} > {rel} (max-abs {mx:.3e})"
+    assert mx <= bound * 1.5, f"{name}: max-abs {mx:.3e} > {bound * 1.5:.3e}"
+    return err
+
+
+def test_f16_library_is_what_fp16_operands_reach():
+    from supir_amd import _lib
+    lib16 = _lib.load(HF)
+    assert lib16.supir_elem_type() == b"f16" and lib16 is not _lib.load()
+    a, w = rnd(64, 64).to(HF), rnd(64, 64, seed=1).to(HF)
+    out = ops.gemm(a, w)
+    assert out.dtype == HF
+    # the bf16 library fed the same BITS would read them as bfloat16 and produce something else entirely
+    check(out, a.float() @ w.float().T, name="gemm 64^3")
+    with pytest.raises(AssertionError):
+        ops.gemm(a, w.to(torch.bfloat16))   # mixed element types are refused, never reinterpreted
+
+
+# every tile family at a shape it accepts: gemm.hip tiles 0-6, gemm16.hip tiles 32-35, autotune (-1)
+@pytest.mark.parametrize("M,N,K,tile", [
+    (2048, 1280, 1280, -1), (2048, 1280, 1280, 32), (2048, 1280, 1280, 33), (2048, 1280, 1280, 34), (2048, 1280, 1280, 35),
+    (2048, 1280, 5120, 35), (8192, 640, 640, -1), (512, 640, 320, 0), (512, 640, 320, 1), (512, 640, 320, 2), (512, 640, 320, 3),
+    (512, 640, 320, 4), (512, 640, 320, 5), (512, 640, 320, 6), (154, 1280, 2048, -1), (2, 1280, 2816, -1), (130, 132, 128, -1)])
+def test_gemm_plain_f16(M, N, K, tile):
+    a = rnd(M, K).to(HF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(HF)
+    bias = rnd(N, seed=2)
+    out = ops.gemm(a, w, bias, tile=tile)
+    check(out, a.float() @ w.float().T + bias, name=f"gemm{(M, N, K)} tile{tile}")
+
+
+def test_gemm_epilogues_f16():
+    B, T, N, K = 2, 128, 640, 384
+    M = B * T
+    a = rnd(M, K).to(HF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(HF)
+    bias = rnd(N, seed=2)
+    res = rnd(M, N, seed=3).to(HF)
+    rb = rnd(B, N, seed=4).to(HF)
+    base = a.float() @ w.float().T + bias
+    for tile in (-1, 3, 32):
+        check(ops.gemm(a, w, bias, residual=res, alpha=0.5, tile=tile), 0.5 * base + res.float(), name=f"res+alpha t{tile}")
+        check(ops.gemm(a, w, bias, rowbias=rb, rows_per_batch=T, act=1, tile=tile),
+              F.silu(base + rb.float().repeat_interleave(T, 0)), name=f"rowbias+silu t{tile}")
+    check(ops.gemm(a, w, None, out_dtype=torch.float32), a.float() @ w.float().T, rel=1e-4, name="fp32out")
+    Tp = 128
+    out = ops.gemm_t(a, w, None, B, T, Tp)
+    check(out, (a.float() @ w.float().T).view(B, T, N).permute(0, 2, 1), name="gemm_t")
+
+
+@pytest.mark.parametrize("M,K,N2,tile,block", [(2048, 1280, 10240, 37, 16), (2048, 1280, 10240, 34, 16), (2048, 1280, 10240, 5, 32),
+                                                (512, 320, 2560, -1, 32)])
+def test_gemm_geglu_f16(M, K, N2, tile, block):
+    a = rnd(M, K).to(HF)
+    w = rnd(N2, K, scale=K ** -0.5, seed=1).to(HF)
+    bias = rnd(N2, seed=2)
+    wi, bi = Wt.interleave_geglu(w, bias, block)
+    out = ops.gemm(a, wi, bi, act=2, tile=tile)
+    v, g = (a.float() @ w.float().T + bias).chunk(2, dim=-1)
+    check(out, v * F.gelu(g), name=f"geglu tile{tile}")
+
+
+def test_layernorm_fold_and_fused_qkv_f16():
+    """supir_gemm_bf16_ln producer -> consumer and supir_gemm_bf16_qkv in the fp16 build (attention.py:465-486)."""
+    B, T, C, H = 2, 1024, 1280, 20
+    M, inner = B * T, H * 64
+    x0 = rnd(M, C).to(HF)
+    w0 = rnd(C, C, scale=C ** -0.5, seed=1).to(HF)
+    with Wt.compute_dtype(HF):
+        x, st = ops.gemm_ln(x0, w0, None, emit_stats=True)
+        gamma, beta = 1.0 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6)
+        wq = rnd(3 * inner, C, scale=C ** -0.5, seed=7)
+        wp, cs, bp = Wt.fold_layernorm(wq, None, gamma, beta)
+        assert wp.dtype == HF
+        qk, vt = ops.gemm_qkv(x, wp, bp, B, T, 2 * inner, ln=st, colsum=cs, ln_eps=1e-5)
+        sep = ops.gemm_ln(x, wp[:2 * inner].contiguous(), bp[:2 * inner].contiguous(), ln=st, colsum=cs[:2 * inner].contiguous(), ln_eps=1e-5)
+    check(x, x0.float() @ w0.float().T, name="producer")
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ wq.T
+    # W' = fp16(gamma * W) is one extra rounding of the weights against the unfolded reference
+    check(qk, ref[:, :2 * inner].view(B, T, -1), rel=1.5e-3, name="qkv: q|k")
+    check(vt, ref[:, 2 * inner:].view(B, T, inner).permute(0, 2, 1), rel=1.5e-3, name="qkv: v^T")
+    check(sep, ref[:, :2 * inner], rel=1.5e-3, name="gemm_ln consumer")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up,tile", [
+    (2, 32, 32, 1280, 1280, 1, False, -1), (2, 32, 32, 1280, 1280, 1, False, 35), (2, 64, 64, 640, 640, 1, False, 34),
+    (2, 64, 64, 320, 320, 2, False, -1), (1, 32, 32, 640, 640, 1, True, -1), (1, 24, 40, 128, 128, 1, False, 0)])
+def test_conv3x3_f16(B, H, W, Cin, Cout, stride, up, tile):
+    x = rnd(B, H, W, Cin).to(HF)
+    w = rnd(Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5, seed=1).to(HF)
+    bias = rnd(Cout, seed=2)
+    rb = rnd(B, Cout, seed=3).to(HF)
+    out = ops.conv3x3(x, w, bias, stride=stride, upsample=up, rowbias=rb, tile=tile)
+    xin = x.float().permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.float().permute(0, 3, 1, 2), bias, stride=stride, padding=1) + rb.float()[:, :, None, None]
+    check(out, ref.permute(0, 2, 3, 1), name=f"conv {Cin}->{Cout} s{stride} up{up} t{tile}")
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal", [(2, 20, 1024, 1024, False), (2, 10, 4096, 4096, False), (2, 20, 1024, 77, False),
+                                              (1, 5, 200, 333, False), (2, 12, 77, 77, True)])
+def test_flash_attn_f16(B, H, Tq, Tk, causal):
+    C = H * 64
+    q, k, v = rnd(B, Tq, C).to(HF), rnd(B, Tk, C, seed=1).to(HF), rnd(B, Tk, C, seed=2).to(HF)
+    Tp = (Tk + 63) // 64 * 64
+    vt = torch.zeros(B, C, Tp, dtype=HF, device=DEV)
+    vt[:, :, :Tk] = v.permute(0, 2, 1)
+    out = ops.flash_attn(q, k, vt, B, H, Tq, Tk, causal=causal)
+    sp = lambda t_, n: t_.float().view(B, n, H, 64).permute(0, 2, 1, 3)   # noqa: E731
+    ref = F.scaled_dot_product_attention(sp(q, Tq), sp(k, Tk), sp(v, Tk), is_causal=causal).permute(0, 2, 1, 3).reshape(B, Tq, C)
+    # P is rounded to fp16 before P.V (2^-11 relative per probability) and Q carries the folded softmax scale
+    check(out, ref, rel=1.5e-3, name=f"attn {Tq}x{Tk}")
+
+
+def test_groupnorm_layernorm_softmax_f16():
+    B, H, W, C = 2, 32, 32, 1280
+    x = rnd(B, H, W, C).to(HF)
+    g, b = 1.0 + 0.1 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
+    out = ops.groupnorm(x, g, b, 1e-5, silu=True)
+    ref = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), 32, g, b, 1e-5)).permute(0, 2, 3, 1)
+    check(out, ref, name="groupnorm+silu")
+    # statistics from a producer epilogue (supir_set_next_gn_partials) in the fp16 build
+    a = rnd(B * H * W, 640).to(HF)
+    w = rnd(C, 640, scale=640 ** -0.5, seed=3).to(HF)
+    y, part = ops.gemm(a, w, None, rows_per_batch=H * W, gn_part=True, tile=35)
+    assert part is not None
+    out = ops.groupnorm(y.view(B, H, W, C), g, b, 1e-5, part=part)
+    ref = F.group_norm(y.float().view(B, H * W, C).permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1).reshape(B, H, W, C)
+    check(out, ref, name="groupnorm from producer statistics")
+    # ZeroSFT tail: concat + modulation + control-scale lerp
+    x2 = rnd(B, H, W, 640, seed=4).to(HF)
+    mg, mb = rnd(B, H, W, C + 640, scale=0.2, seed=5).to(HF), rnd(B, H, W, C + 640, scale=0.2, seed=6).to(HF)
+    g2, b2 = 1.0 + 0.1 * rnd(C + 640, seed=7), 0.1 * rnd(C + 640, seed=8)
+    out = ops.groupnorm(x, g2, b2, 1e-5, x2=x2, mod_g=mg, mod_b=mb, control_scale=0.6)
+    cat = torch.cat([x.float(), x2.float()], -1)
+    gn = F.group_norm(cat.permute(0, 3, 1, 2), 32, g2, b2, 1e-5).permute(0, 2, 3, 1)
+    ref = (gn * (mg.float() + 1) + mb.float()) * 0.6 + cat * 0.4
+    check(out, ref, name="zerosft tail")
+    t = rnd(300, 1280).to(HF)
+    check(ops.layernorm(t, g, b), F.layer_norm(t.float(), (C,), g, b), name="layernorm")
+    s = rnd(64, 256, scale=3.0)
+    p = ops.softmax_rows(s, 0.5, valid=200, dtype=HF)
+    assert p.dtype == HF and p[:, 200:].abs().max().item() == 0
+    check(p[:, :200], torch.softmax(s[:, :200] * 0.5, -1), name="softmax_rows")
+
+
+def test_boundary_convs_f16():
+    x = rnd(2, 4, 32, 32)
+    w, bias = rnd(320, 4, 3, 3, scale=1 / 6.0, seed=1), rnd(320, seed=2)
+    out = ops.conv3x3_smallcin(x, w, bias, dtype=HF)
+    assert out.dtype == HF
+    check(out, F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1), name="smallcin")
+    h = rnd(2, 32, 32, 320).to(HF)
+    w2 = rnd(4, 320, 3, 3, scale=(9 * 320) ** -0.5, seed=3)
+    with Wt.compute_dtype(HF):
+        w9 = Wt.conv3x3_w9(w2)
+    out = ops.conv3x3_smallcout(h, w9, None)
+    check(out, F.conv2d(h.float().permute(0, 3, 1, 2), w9.float().reshape(3, 3, 4, 320).permute(2, 3, 0, 1), None, padding=1),
+          rel=1e-4, name="smallcout")
+
+
+# ------------------------------------------------------------------------------------------------- network level
+@pytest.fixture(scope="module")
+def mini():
+    return build_unet(depth=(1, 1, 2), device=DEV)
+
+
+def _sd_of(wrap):
+    sd = {}
+    for pfx, mod in (("model.diffusion_model.", wrap.diffusion_model), ("model.control_model.", wrap.control_model)):
+        for k, v in mod.state_dict().items():
+            sd[pfx + k] = v
+    return sd
+
+
+def _record(name, **vals):
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    print(f"[parity-fp16] {name}: " + ", ".join(f"{k}={v:.4g}" for k, v in vals.items()))
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_fp16.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = vals
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def test_network_call_fp16_vs_fp32_oracle(mini, monkeypatch):
+    """One CFG-doubled ControlWrapper call (reduced depth, real widths, latent 32^2) with dtype = torch.float16 against the fp32
+    oracle: <= 3e-3, and less than half the error of the bf16 build on the same inputs; eager, hipGraph replay and
+    a return to bf16 afterwards (both libraries alive in one process, separate weight layouts and text K / V buffers)."""
+    from oracle import supir_oracle as O
+    from supir_amd.modules import wrappers
+    monkeypatch.setattr(wrappers, "FP16_NATIVE", True)
+    B, L = 2, 32
+    x = synth_tensor("xt32", (B, 4, L, L)).to(DEV)
+    cond = {"crossattn": synth_tensor("context", (B, 77, 2048)).to(DEV), "vector": synth_tensor("vector", (B, 2816)).to(DEV),
+            "control": synth_tensor("lq32", (B, 4, L, L)).to(DEV)}
+    t = torch.tensor([500, 37], dtype=torch.int64, device=DEV)
+    with torch.no_grad():
+        ref = O.control_wrapper(_sd_of(mini), x, t, cond, 1.0)
+        e_bf_before = rel_l2(mini(x, t, cond, 1.0), ref)
+        mini.dtype = HF
+        try:
+            assert mini.effective_dtype == HF
+            out16 = mini(x, t, cond, 1.0).clone()
+            mini.enable_graph(True)
+            g16 = mini(x, t, cond, 1.0).clone()
+            g16b = mini(x, t, cond, 1.0).clone()
+        finally:
+            mini.enable_graph(False)
+            mini.dtype = torch.bfloat16
+        e_bf_after = rel_l2(mini(x, t, cond, 1.0), ref)
+    e16 = rel_l2(out16, ref)
+    _record("network_call_mini_latent32", fp16_vs_oracle=e16, bf16_vs_oracle=e_bf_before, bf16_after_fp16_vs_oracle=e_bf_after)
+    assert torch.isfinite(out16).all()
+    assert e16 <= 3e-3, e16
+    assert e16 <= 0.5 * e_bf_before, (e16, e_bf_before)
+    assert torch.equal(g16, out16) and torch.equal(g16b, out16)       # graph replay == eager, bitwise
+    assert e_bf_after == e_bf_before                                   # the bf16 path is untouched by the excursion
+
+
+def test_dpmpp2m_config5_sampler_fp16(mini, monkeypatch):
+    """BASELINE config 5's sampler (RestoreDPMPP2MSampler, sampling.py:422-515) driving the fp16 network vs the same sampler
+    driving the fp32 oracle network, scripted noise, 4 and 8 steps: tighter than the bf16 run of the same test (3e-2)."""
+    from oracle import supir_oracle as O
+    from supir_amd.modules import wrappers
+    from supir_amd.modules.sampling import DiscreteDenoiserWithControl, LinearCFG, RestoreDPMPP2MSampler
+    monkeypatch.setattr(wrappers, "FP16_NATIVE", True)
+    h = w = 32
+    ctx, y = synth_tensor("context", (2, 77, 2048)).to(DEV), synth_tensor("vector", (2, 2816)).to(DEV)
+    lq = synth_tensor("lq_tiled", (1, 4, h, w)).to(DEV)
+    c = {"crossattn": ctx[:1], "vector": y[:1], "control": lq}
+    uc = {"crossattn": ctx[1:], "vector": y[1:], "control": lq}
+    den = DiscreteDenoiserWithControl().to(DEV)
+    sd = _sd_of(mini)
+    x0 = synth_tensor("dpm.gpu.x0", (1, 4, h, w)).to(DEV)
+
+    class Scripted:
+        def __init__(self, x, *a, **k):
+            self.i = 0
+
+        def __call__(self, s, sn):
+            self.i += 1
+            return synth_tensor(f"dpm.gpu.eps{self.i}", (1, 4, h, w)).to(DEV)
+
+    res = {}
+    mini.dtype = HF
+    try:
+        for steps in (8, 4):
+            outs = []
+            for net in (mini, lambda a, b_, cc, s: O.control_wrapper(sd, a, b_, cc, s)):
+                smp = RestoreDPMPP2MSampler(num_steps=steps, s_noise=1.0, eta=1.0, restore_cfg=4.0, guider_config=LinearCFG(2.0, 2.0),
+                                            device=DEV, noise_sampler_cls=Scripted)
+                with torch.no_grad():
+                    outs.append(smp(lambda i, s, cc, cs, n=net: den(n, i, s, cc, cs), x0.clone(), cond=dict(c), uc=dict(uc),
+                                    control_scale=1.0).float())
+            res[f"steps{steps}"] = rel_l2(outs[0], outs[1])
+            assert torch.isfinite(outs[0]).all()
+    finally:
+        mini.dtype = torch.bfloat16
+    _record("dpmpp2m_sampler_fp16_32x32", **res)
+    assert max(res.values()) <= 6e-3

@@ -244,7 +244,9 @@ def test_weight_prefetch_plan_is_one_shot_per_op_and_wraps(monkeypatch):
             calls.append((ptr, nbytes))
             return 0
 
-    monkeypatch.setattr(ops._lib, "load", lambda: FakeLib())
+    fake = FakeLib()
+    monkeypatch.setattr(ops._lib, "load", lambda dtype=None: fake)      # the request goes to the library of the weight's dtype
+    monkeypatch.setattr(ops._lib, "loaded", lambda: [fake])
     ws = [torch.zeros(n, 8, dtype=torch.bfloat16) for n in (4, 6, 8)]
     pf = ops.WeightPrefetch(distance=1)
     ops.set_prefetch(pf)
@@ -320,22 +322,25 @@ def test_graph_mode_runs_eagerly_when_control_scale_keeps_changing():
     w.load_control_model(Ctl())
     x, t = torch.ones(2, 4, 8, 8), torch.zeros(2, dtype=torch.int64)
     c = {"crossattn": torch.zeros(2, 77, 8), "vector": torch.zeros(2, 16), "control": torch.full((2, 4, 8, 8), 2.0)}
-    shape_key = (tuple(x.shape), tuple(c["crossattn"].shape), tuple(c["vector"].shape))
+    shape_key = (tuple(x.shape), tuple(c["crossattn"].shape), tuple(c["vector"].shape), torch.bfloat16)
     w._cs_miss[shape_key] = 2                              # two consecutive new scales were already captured for these shapes
     out = w._forward_graph(x, t, c, 0.8)                   # third in a row: eager, no capture attempted (this box has no GPU)
     assert torch.allclose(out, x * 0.5 + (x + 2.0) * 0.8) and out.dtype == torch.float32
     assert w._graphs == {} and w._cs_miss[shape_key] == 3
     # the eager call left ITS conditioning in the shared buffers: recorded, so a graph of the same shape refreshes before replay
-    assert w._resident[(tuple(c["crossattn"].shape), tuple(c["vector"].shape))][0] is c["crossattn"]
+    assert w._resident[(tuple(c["crossattn"].shape), tuple(c["vector"].shape), torch.bfloat16)][0] is c["crossattn"]
     w.enable_graph(False)
     assert w._cs_miss == {}
 
 
 def test_fp16_request_is_not_silently_served_by_bf16(monkeypatch):
-    """diff_dtype=fp16 (the reference's default, test.py:68) must not be silently computed in bf16: the wrapper
-    warns once (RuntimeWarning), raises under SUPIR_STRICT_DTYPE=1, and reports what it computes in."""
+    """diff_dtype=fp16 (the reference's default, test.py:68) must not be silently computed in bf16.  With the fp16
+    build of the kernels switched off (wrappers.FP16_NATIVE = False) the wrapper warns once (RuntimeWarning), raises under
+    SUPIR_STRICT_DTYPE=1, and reports what it computes in; switched on, the request is honoured (next test)."""
     import warnings
+    from supir_amd.modules import wrappers
     from supir_amd.modules.wrappers import ControlWrapper
+    monkeypatch.setattr(wrappers, "FP16_NATIVE", False)
 
     class Ctl(torch.nn.Module):
         def forward(self, x, timesteps, xt, context=None, y=None, **kw):
@@ -366,6 +371,57 @@ def test_fp16_request_is_not_silently_served_by_bf16(monkeypatch):
     w3.load_control_model(Ctl())
     with pytest.raises(RuntimeError, match="float16"):
         w3(x, t, c)
+
+
+def test_fp16_request_runs_in_an_fp16_compute_scope(monkeypatch):
+    """With the fp16 build enabled, a ControlWrapper whose dtype is torch.float16 runs its networks inside an fp16 compute scope
+    (weights.compute_dtype): activations / derived weight layouts are fp16 and ops dispatch to libsupir_hip_f16.so by operand dtype;
+    no warning; bf16 and fp32 requests keep the bf16 scope; the scope ends with the call."""
+    import warnings
+    from supir_amd import weights as Wt
+    from supir_amd.modules import wrappers
+    from supir_amd.modules.base import Linear, tokens_bf16
+    from supir_amd.modules.wrappers import ControlWrapper
+    monkeypatch.setattr(wrappers, "FP16_NATIVE", True)
+    seen = []
+
+    class Ctl(torch.nn.Module):
+        def forward(self, x, timesteps, xt, context=None, y=None, **kw):
+            seen.append(("ctl", Wt.cdt()))
+            return [xt + x]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = Linear(8, 8)
+            torch.nn.init.normal_(self.lin.weight)
+
+        def forward(self, x, timesteps=None, context=None, y=None, control=None, control_scale=1, **kw):
+            seen.append(("net", Wt.cdt(), self.lin.w().dtype, tokens_bf16(context).dtype))
+            return x + control[0]
+
+    x, t = torch.ones(2, 4, 8, 8), torch.zeros(2, dtype=torch.int64)
+    c = {"crossattn": torch.zeros(2, 77, 8), "vector": torch.zeros(2, 16), "control": torch.ones(2, 4, 8, 8)}
+    for req, want in ((torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)):
+        del seen[:]
+        w = ControlWrapper(Net(), dtype=req)
+        w.load_control_model(Ctl())
+        assert w.effective_dtype == want
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            out = w(x, t, c)
+        assert not rec and out.dtype == torch.float32
+        assert seen == [("ctl", want), ("net", want, want, want)]
+        assert Wt.cdt() == torch.bfloat16                      # scope closed
+        assert list(w._resident) == [((2, 77, 8), (2, 16), want)]
+    # one module driven under both scopes keeps separate derived layouts (Prep keys on the compute dtype)
+    lin = Linear(8, 8)
+    torch.nn.init.normal_(lin.weight)
+    a = lin.w()
+    with Wt.compute_dtype(torch.float16):
+        b = lin.w()
+        assert b.dtype == torch.float16 and lin.w() is b
+    assert a.dtype == torch.bfloat16 and lin.w().dtype == torch.bfloat16
 
 
 def test_builtin_config_mirrors_the_reference_yaml_scalars():
