@@ -133,6 +133,14 @@ int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, 
 int supir_flash_attn_d64_ex(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
                             int ldk, int ldvt, int ldo, float scale, int flags, void* stream);
 
+/* softmax(Q K^T * scale) V for ONE head of dimension 512 without materialising the score matrix: the VAE mid-block attention
+ * (sgm/modules/diffusionmodules/model.py:177-192 AttnBlock == :228-256 MemoryEfficientAttnBlock; SUPIR/utils/tilevae.py:276,335).
+ * Q:[B][Tq][ldq], K:[B][Tk][ldk] (512 contiguous channels per token), Vt:[B][512][ldvt] = V transposed per batch
+ * (SUPIR_OUT_BF16_T output of the v projection), ldvt >= roundup(Tk, 32), padding finite; O:[B][Tq][ldo].  Any Tq / Tk >= 1.
+ * ldq, ldk, ldvt multiples of 8, ldo of 4, ldq / ldk / ldo >= 512. */
+int supir_flash_attn_d512(const void* Q, const void* K, const void* Vt, void* O, int B, int Tq, int Tk, int ldq, int ldk, int ldvt,
+                          int ldo, float scale, void* stream);
+
 /* P[r][:] = softmax(S[r][:] * scale): fp32 scores -> bf16 probabilities (VAE mid-block single-head attention,
  * sgm/modules/diffusionmodules/model.py:177-192, 228-256; the score matrix itself comes from supir_gemm_bf16).
  * Columns [T, Tpad) (K padding of the following P.V GEMM) are written as zeros. */

@@ -27,6 +27,7 @@ SIGNATURES = {
     "supir_conv3x3_bf16": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, I, I, I, F, I, P],
     "supir_flash_attn_d64": [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
     "supir_flash_attn_d64_ex": [P, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
+    "supir_flash_attn_d512": [P, P, P, P, I, I, I, I, I, I, I, F, P],
     "supir_softmax_rows": [P, P, I, I, I, L, L, F, P],
     "supir_groupnorm_nhwc": [P, P, P, P, I, I, I, I, I, I, P, P, F, I, P, P, I, F, P, I, P, c_size_t, P, P],
     "supir_groupnorm_stats": [P, P, I, I, I, I, I, I, P, P, c_size_t, P],

@@ -158,6 +158,13 @@ int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, 
     return supir_attn_launch(a, (hipStream_t)stream);
 }
 
+int supir_flash_attn_d512(const void* Q, const void* K, const void* Vt, void* O, int B, int Tq, int Tk, int ldq, int ldk, int ldvt,
+                          int ldo, float scale, void* stream) {
+    if (!Q || !K || !Vt || !O) return SUPIR_ERR_ARG;
+    return supir_attn_d512_launch((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, B, Tq, Tk, ldq, ldk, ldvt, ldo,
+                                  scale, (hipStream_t)stream);
+}
+
 int supir_softmax_rows(const float* S, void* P, int rows, int T, int Tpad, long ld_s, long ld_p, float scale,
                        void* stream) {
     if (!S || !P) return SUPIR_ERR_ARG;

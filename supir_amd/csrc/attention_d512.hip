@@ -1,0 +1,272 @@
+// Flash attention forward for ONE head of dimension 512: the VAE mid-block self attention
+// (sgm/modules/diffusionmodules/model.py:177-192 AttnBlock.attention == :228-256 MemoryEfficientAttnBlock.attention;
+// SUPIR/utils/tilevae.py:276,335 call the same through xformers).  softmax(Q K^T / sqrt(512)) V, no mask, no dropout.
+//
+// Before this kernel the score matrix was materialised: at 1024 x 1024 px the mid block has T = 16 384 tokens, i.e. a
+// 1 GiB fp32 [T][T] matrix written by one GEMM, read and re-written as 0.5 GiB of probabilities by a softmax kernel and read
+// again by a second GEMM (~3 GB of HBM traffic per call, four calls per image); here nothing but Q, K, V^T and O touches HBM.
+//
+// Layout:  Q [B][Tq][ldq], K [B][Tk][ldk] (512 contiguous channels per token), Vt [B][512][ldvt] = V transposed per batch
+// (the SUPIR_OUT_BF16_T output of the v projection; ldvt >= round_up(Tk, 32), padding finite), O [B][Tq][ldo].
+//
+// One workgroup = NW waves = 32*NW query rows; a wave owns 32 queries and the whole 32 x 512 output tile: 16 accumulator
+// blocks of v_mfma_f32_32x32x16 = 256 registers (AGPRs), the Q fragments another 128 VGPRs -- one wave per SIMD, by design:
+// with head dim 512 the register file, not LDS, is what bounds the query tile.  Keys are consumed 32 at a time: K tile
+// [32][512] (32 KB) and V^T tile [512][32] (32 KB), double buffered through LDS by global_load_lds (128 KB).
+//   S^T = K.Q^T  (32 MFMAs, two independent accumulator chains; operands swapped so that a lane owns ONE query column:
+//                 the row maximum is one v_permlane32_swap away and P needs no cross-lane exchange)
+//   P   = exp2(S^T - m)  with the softmax scale * log2(e) folded into Q; m = the EXACT row maximum, found by a first pass over
+//                 the K tiles alone (S^T only) -- with 256 accumulators an online rescale is what must not happen (see pass 1)
+//   O^T += V^T.P  (32 MFMAs)
+// K rows are read with bits 2/3 of the row index swapped, which makes the 8 P values a lane holds per 16-key block the 8
+// CONSECUTIVE keys of one 16-byte chunk of a V^T row (see attention.hip).  Both tiles are stored XOR-swizzled (the swizzle is
+// applied on the global-source side of the LDS DMA) so that every ds_read_b128 lane group hits 16 distinct 16-byte slots.
+#include "kernels.h"
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void d512_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ float d512_xhalf_max(float x) {   // max over lanes l and l ^ 32
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+struct Attn512Args {
+    const bf16_t* Q;
+    const bf16_t* K;
+    const bf16_t* Vt;
+    bf16_t* O;
+    int B, Tq, Tk;
+    int ldq, ldk, ldvt, ldo;
+    float scale_log2e;
+};
+
+constexpr int KT = 32;              // keys per tile
+constexpr int STAGE_BYTES = 65536;  // K tile (32 KB) + V^T tile (32 KB)
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages
+    constexpr int QB = 32 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int nqb = (p.Tq + QB - 1) / QB;
+    const int b = blockIdx.x / nqb, qb = blockIdx.x - b * nqb;
+    const char* Kb = (const char*)(p.K + (size_t)b * p.Tk * p.ldk);
+    const char* Vb = (const char*)(p.Vt + (size_t)b * 512 * p.ldvt);
+
+    const int q = qb * QB + wave * 32 + l31;
+    const bool q_ok = q < p.Tq;
+    const int qc = q_ok ? q : p.Tq - 1;
+    const bf16_t* Qp = p.Q + ((size_t)b * p.Tq + qc) * p.ldq + 8 * half;
+    const float c = p.scale_log2e;
+    const int nt = (p.Tk + KT - 1) / KT;
+
+    // ---- loader: one wave-instruction moves 1 KB.  K: instruction r = key row r of the tile (64 chunks of 16 B); the lane
+    // that fills LDS chunk position `lane` fetches logical chunk lane ^ (r & 15).  V^T: instruction i = channel rows
+    // 16 i .. 16 i + 15 (4 chunks each); position (row, lane & 3) fetches logical chunk (lane & 3) ^ ((row >> 2) & 3).
+    constexpr int LPT = 32 / NW;   // wave-instructions per wave for each of the two tiles
+    auto stage_k = [&](int t, int soff, int i) {   // i in [0, LPT)
+        const int row = i * NW + wave;
+        int kr = t * KT + row;
+        kr = kr < p.Tk ? kr : p.Tk - 1;   // ragged last tile: re-read the last valid key (masked in the softmax)
+        glds16(Kb + (size_t)kr * p.ldk * 2 + ((lane ^ (row & 15)) << 4), smem + soff + row * 1024);
+    };
+    auto stage_v = [&](int t, int soff, int i) {
+        const int ins = i * NW + wave;
+        const int row = ins * 16 + (lane >> 2);
+        const int ch = (lane & 3) ^ ((row >> 2) & 3);
+        glds16(Vb + (size_t)row * p.ldvt * 2 + (size_t)t * (KT * 2) + (ch << 4), smem + soff + 32768 + ins * 1024);
+    };
+
+    // ---- LDS fragment addresses (bytes inside a stage)
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // MFMA row i of S^T holds key swap_bits(2,3)(i)
+    const int kx = (krow & 15) ^ half;      // chunk 2*ks + half lives at position ((2*ks) & 48) | ((((2*ks) & 15)) ^ kx)
+    const int kbase = krow * 1024;
+    const int vx = ((l31 >> 2) & 3) ^ half;  // chunk 2*j + half of V^T row d lives at position (2*j) ^ vx
+    const int vbase = 32768 + l31 * 64;
+
+    f32x16 o[16], nm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nm[r] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 16; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float l_run = 0.f;
+
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) stage_k(0, 0, i);
+    // Q carries the softmax scale in log2 units from here on (one extra rounding of Q, as in attention.hip)
+    bf16x8 qf[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        const bf16x8 raw = *(const bf16x8*)(Qp + 16 * ks);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)((float)raw[e] * c);
+    }
+
+    const int klast = p.Tk - 1;
+    // S^T = K.Q^T + c0 for the tile in stage `sb`, keys past the end -> -inf.  Eight groups of four k steps: the fragments of
+    // group g+1 are read before the MFMAs of group g are issued (explicit double buffer: left to itself the compiler reads,
+    // waits and multiplies one fragment at a time through a single register quad), two independent accumulator chains, and
+    // `between(g)` -- the loader's global_load_lds for the NEXT tile -- spread one call per group instead of clumped.
+    auto scores = [&](const char* sb, const f32x16& c0, int t, auto&& between) {
+        f32x16 s0 = c0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+        bf16x8 kf[2][4];
+        auto ldk = [&](bf16x8 (&k4)[4], int g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ks = 4 * g + i;
+                const int pos = ((2 * ks) & 48) | (((2 * ks) & 15) ^ kx);
+                k4[i] = *(const bf16x8*)(sb + kbase + pos * 16);
+            }
+        };
+        ldk(kf[0], 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) ldk(kf[(g + 1) & 1], g + 1);
+            between(g);
+            s0 = SUPIR_MFMA_32x32x16(kf[g & 1][0], qf[4 * g + 0], s0, 0, 0, 0);
+            s1 = SUPIR_MFMA_32x32x16(kf[g & 1][1], qf[4 * g + 1], s1, 0, 0, 0);
+            s0 = SUPIR_MFMA_32x32x16(kf[g & 1][2], qf[4 * g + 2], s0, 0, 0, 0);
+            s1 = SUPIR_MFMA_32x32x16(kf[g & 1][3], qf[4 * g + 3], s1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = s0[r] + s1[r];
+        if (t == nt - 1) {   // the only tile that can hold keys past the end
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t * KT + 16 * (r >> 3) + 8 * half + (r & 7) > klast) s[r] = -INFINITY;
+        }
+        return s;
+    };
+
+    // ================= pass 1: exact row maxima (K tiles only) =================
+    // An online softmax would have to rescale the 256 accumulators whenever the running maximum moves; as a data-dependent
+    // branch that update drags every accumulator into VGPRs at the join (measured: 1 235 spills, Q fragments in scratch).  With
+    // head dim 512 the score product is a third of the work per key tile, so the maxima are computed first -- K streams through
+    // LDS once more, from L2 -- and the main pass runs with a fixed m: no rescale, P <= 1, l >= 1, no overflow cases.
+    {
+        float mx = -INFINITY;
+        for (int t = 0; t < nt; ++t) {
+            d512_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int noff = ((t + 1) & 1) * STAGE_BYTES;
+            const bool more = t + 1 < nt;
+            const f32x16 s = scores(smem + (t & 1) * STAGE_BYTES, nm, t, [&](int g) {
+                if (more) {
+#pragma unroll
+                    for (int i = g * LPT / 8; i < (g + 1) * LPT / 8; ++i) stage_k(t + 1, noff, i);
+                }
+            });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        }
+        mx = d512_xhalf_max(mx);   // finite: key 0 is visible to every query
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nm[r] = -mx;
+    }
+    __builtin_amdgcn_s_barrier();   // every wave is done with the last K tile before stage 0 is refilled
+    asm volatile("" ::: "memory");
+
+    // ================= pass 2: P = exp2(S^T - m), O^T += V^T.P =================
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        stage_k(0, 0, i);
+        stage_v(0, 0, i);
+    }
+    for (int t = 0; t < nt; ++t) {
+        d512_wait_vmcnt<0>();              // this wave's share of tile t has landed ...
+        __builtin_amdgcn_s_barrier();      // ... and so has everybody else's; all waves are done with tile t-1
+        asm volatile("" ::: "memory");
+        const char* sb = smem + (t & 1) * STAGE_BYTES;
+        const int noff = ((t + 1) & 1) * STAGE_BYTES;
+        const bool more = t + 1 < nt;
+        const f32x16 s = scores(sb, nm, t, [&](int g) {
+            if (more) {
+#pragma unroll
+                for (int i = g * LPT / 8; i < (g + 1) * LPT / 8; ++i) stage_k(t + 1, noff, i);
+            }
+        });
+        // V^T fragments of the first pair of channel blocks are requested before the exponentials
+        bf16x8 va[2][4];
+        auto ldv = [&](bf16x8 (&v4)[4], int g) {
+#pragma unroll
+            for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    v4[dbl * 2 + j] = *(const bf16x8*)(sb + vbase + (2 * g + dbl) * 2048 + (((2 * j) ^ vx) << 4));
+        };
+        ldv(va[0], 0);
+        bf16x8 pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[r]);
+            l_run += pv;
+            pf[r >> 3][r & 7] = (bf16_t)pv;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // eight groups of two channel blocks: two accumulator chains alternate, the next group's fragments are in flight
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) ldv(va[(g + 1) & 1], g + 1);
+            if (more) {
+#pragma unroll
+                for (int i = g * LPT / 8; i < (g + 1) * LPT / 8; ++i) stage_v(t + 1, noff, i);
+            }
+            o[2 * g] = SUPIR_MFMA_32x32x16(va[g & 1][0], pf[0], o[2 * g], 0, 0, 0);
+            o[2 * g + 1] = SUPIR_MFMA_32x32x16(va[g & 1][2], pf[0], o[2 * g + 1], 0, 0, 0);
+            o[2 * g] = SUPIR_MFMA_32x32x16(va[g & 1][1], pf[1], o[2 * g], 0, 0, 0);
+            o[2 * g + 1] = SUPIR_MFMA_32x32x16(va[g & 1][3], pf[1], o[2 * g + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        bf16_t* Op = p.O + ((size_t)b * p.Tq + q) * p.ldo;
+#pragma unroll
+        for (int db = 0; db < 16; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                u16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[db][rg * 4 + e] * inv);
+                *(u16x4*)(Op + db * 32 + 8 * rg + 4 * half) = ov;
+            }
+    }
+}
+
+}  // namespace
+
+int supir_attn_d512_launch(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int B, int Tq, int Tk, int ldq, int ldk,
+                           int ldvt, int ldo, float scale, hipStream_t st) {
+    if (B <= 0 || Tq <= 0 || Tk <= 0) return SUPIR_ERR_ARG;
+    if ((ldq | ldk | ldvt) % 8 != 0 || ldo % 4 != 0 || ldq < 512 || ldk < 512 || ldo < 512) return SUPIR_ERR_SHAPE;
+    if (ldvt < ((Tk + KT - 1) / KT) * KT) return SUPIR_ERR_SHAPE;
+    Attn512Args a{Q, K, Vt, O, B, Tq, Tk, ldq, ldk, ldvt, ldo, scale * 1.4426950408889634f};
+    constexpr int NW = 4;   // 128 queries per workgroup: half the K / V^T stream (and LDS-DMA issue) per FLOP of the 2-wave form
+    const long nwg = (long)B * ((Tq + 32 * NW - 1) / (32 * NW));
+    if (nwg > 0x7fffffffL) return SUPIR_ERR_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (supir_note_hip_status(hipFuncSetAttribute((const void*)attn_d512_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      2 * STAGE_BYTES)) != SUPIR_OK)
+            return SUPIR_ERR_HIP;
+        attr_set = true;
+    }
+    SUPIR_LAUNCH((attn_d512_kernel<NW>), dim3((unsigned)nwg), dim3(64 * NW), 2 * STAGE_BYTES, st, a);
+    return SUPIR_LAUNCH_STATUS();
+}

@@ -83,6 +83,9 @@ int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st);
 bool supir_gemm_big_supported(const GemmArgs& a);
 int supir_gemm_big_launch(const GemmArgs& a, hipStream_t st);
 int supir_attn_launch(const AttnArgs& a, hipStream_t st);
+// attention_d512.hip: one head of dimension 512 (VAE mid block), 32-key tiles, 32 x 512 output tile per wave
+int supir_attn_d512_launch(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int B, int Tq, int Tk, int ldq, int ldk,
+                           int ldvt, int ldo, float scale, hipStream_t st);
 int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, int Tpad, long lds_, long ldp, float scale,
                               hipStream_t st);
 int supir_groupnorm_launch(GnArgs a, hipStream_t st);

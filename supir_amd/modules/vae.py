@@ -52,11 +52,17 @@ class AttnBlock(nn.Module):
         self.proj_out = Linear(in_channels, in_channels, conv1x1=True)
 
     def attend(self, n):
-        """n: normalised tokens [B, T, C] bf16 -> proj_out-less attention output [B, T, C].  Any T: the key axis is padded
-        to a multiple of 64 with zero K rows / zero V^T columns and the softmax masks the padding."""
+        """n: normalised tokens [B, T, C] bf16 -> proj_out-less attention output [B, T, C].  Any T.
+        C == 512 (every SDXL / SUPIR VAE) with ops.USE_FLASH_D512: q, k and v^T projections + ONE flash-attention launch
+        (csrc/attention_d512.hip), no score matrix.  Otherwise the materialised form: the key axis is padded to a multiple of 64
+        with zero K rows / zero V^T columns, a GEMM writes fp32 scores [T, Tp], softmax_rows masks the padding, a GEMM applies P."""
         B, T, C = n.shape
         Tp = (T + 63) // 64 * 64
         q = ops.gemm(n, self.q.w(), self.q.b32())
+        if C == 512 and ops.USE_FLASH_D512:
+            k = ops.gemm(n, self.k.w(), self.k.b32())
+            vt = ops.gemm_t(n, self.v.w(), self.v.b32(), B, T, Tp)   # [B, C, Tp], zero padded
+            return ops.flash_attn_d512(q, k, vt, T)
         if Tp == T:
             k = ops.gemm(n, self.k.w(), self.k.b32())
         else:

@@ -644,6 +644,31 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     return out
 
 
+USE_FLASH_D512 = _os.environ.get("SUPIR_FLASH_D512", "0") == "1"   # VAE mid-block attention through supir_flash_attn_d512
+
+
+def flash_attn_d512(q, k, vt, Tk, out=None):
+    """Single-head, head-dim-512 attention without a score matrix (VAE mid block): q [B,Tq,512], k [B,Tk,512], vt [B,512,Tpad]
+    (V transposed per batch, Tpad >= roundup(Tk, 32), zero padded) -> [B,Tq,512].  scale = 512^-0.5."""
+    DT = q.dtype
+    lib = _lib.load(DT)
+    _check_dev(q, k, vt)
+    assert DT in HALF_TYPES and k.dtype == DT and vt.dtype == DT
+    B, Tq, C = q.shape
+    assert C == 512 and k.shape == (B, Tk, 512) and vt.shape[:2] == (B, 512) and vt.is_contiguous()
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and q.stride(0) == Tq * q.stride(1) and k.stride(0) == Tk * k.stride(1)
+    if out is None:
+        out = torch.empty(B, Tq, 512, dtype=DT, device=q.device)
+    assert out.dtype == DT and out.stride(-1) == 1 and out.stride(0) == Tq * out.stride(1)
+    ev = _ev()
+    rc = lib.supir_flash_attn_d512(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, Tq, Tk, q.stride(1), k.stride(1),
+                                   vt.shape[-1], out.stride(1), 512 ** -0.5, _stream())
+    _lib.check(rc, "supir_flash_attn_d512", lib)
+    # algorithmic FLOPs (Q.K^T and P.V once each; the kernel's own first pass over K is overhead, not work)
+    _rec("attn_d512", 4.0 * B * Tq * Tk * 512, 2.0 * B * 512 * (2 * Tq + 2 * Tk), ev, B=B, H=1, Tq=Tq, Tk=Tk)
+    return out
+
+
 def softmax_rows(s, scale, out=None, valid=None, dtype=None):
     """softmax over the first `valid` columns of fp32 scores [rows, Tpad]; remaining columns of the 16-bit output (`dtype`,
     default: that of `out`, else bf16) are zero."""

@@ -89,6 +89,12 @@ def test_round2_entry_points_validate_arguments_without_a_gpu():
     assert lib.supir_resample_u8(fake, None, None, None, fake, fake, 5, 8, 8, 8, 16, 3, 0, None) == -1                  # no output at all
     assert lib.supir_resample_u8(fake, fake, None, None, fake, fake, 5, 8, 8, 9, 16, 3, 0, None) == -2                  # horizontal pass keeps H
     assert lib.supir_bicubic_f32(None, None, None, 3, 8, 8, 4, 4, None) == -1
+    # supir_flash_attn_d512: null pointers, row strides below the head dim / misaligned, V^T narrower than the key count
+    assert lib.supir_flash_attn_d512(None, None, None, None, 1, 64, 64, 512, 512, 64, 512, 0.044, None) == -1
+    assert lib.supir_flash_attn_d512(fake, fake, fake, fake, 0, 64, 64, 512, 512, 64, 512, 0.044, None) == -1
+    assert lib.supir_flash_attn_d512(fake, fake, fake, fake, 1, 64, 64, 256, 512, 64, 512, 0.044, None) == -2
+    assert lib.supir_flash_attn_d512(fake, fake, fake, fake, 1, 64, 64, 512, 516, 64, 512, 0.044, None) == -2
+    assert lib.supir_flash_attn_d512(fake, fake, fake, fake, 1, 64, 100, 512, 512, 96, 512, 0.044, None) == -2
     # tile 32 (128 x 80) on an inexact shape is refused, not silently run on another tile
     assert lib.supir_gemm_bf16(fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 32, None) == -2
     assert lib.supir_gemm_bf16(fake, fake, fake, 128, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 36, None) == -1   # no such tile
