@@ -222,6 +222,23 @@ int supir_resample_u8(const void* src, void* dst_u8, float* dst_f32, const float
  * False, replicated border) -> out_f32 [C][OH][OW] and / or out_u8 [OH][OW][C] = uint8(clip(v * 127.5 + 127.5, 0, 255)). */
 int supir_bicubic_f32(const float* src, void* out_u8, float* out_f32, int C, int H, int W, int OH, int OW, void* stream);
 
+/* The elementwise halves of ONE restoration-guided EDM sampler step on fp32 latents, around the network call
+ * (RestoreEDMSampler.sampler_step, sgm/modules/diffusionmodules/sampling.py:548-570, with LinearCFG guiders.py:44-74,
+ * NoDynamicThresholding sampling_utils.py:7-9, the EpsScaling denoiser wrapper denoiser.py:66-73 + denoiser_scaling.py:16-22,
+ * to_d / euler_step sampling_utils.py:39-40 + sampling.py:82-83).  Every sigma-derived factor is uniform over the batch
+ * (s_in * sigmas[i]) and passed as a host scalar, computed in fp32 in the reference's operation order.  n = elements of one
+ * copy of the latent batch; reps = 2: classifier-free-guidance doubling, uncond half first (n % 4 == 0); reps = 1: no guider.
+ *   pre :  x_hat = x + (eps * s_noise) * noise_mul      noise_mul = sqrt(sigma_hat^2 - sigma^2); eps NULL -> x_hat = x
+ *          net_in[r*n + i] = x_hat[i] * c_in, r < reps   (x_hat NULL: not stored)
+ *   post:  den_r = net_out[r*n + i] * c_out + x_hat[i] * c_skip;  den = den_0 + cfg_scale * (den_1 - den_0)  (reps 2) | den_0
+ *          den -= (den - x_center[i]) * restore_mul       (x_center NULL: skipped)
+ *          x_next[i] = x_hat[i] + dt * ((x_hat[i] - den) / sigma_hat)          dt = sigma_next - sigma_hat
+ * All pointers 16-byte aligned. */
+int supir_edm_step_pre(const float* x, const float* eps, float s_noise, float noise_mul, float c_in, float* x_hat, float* net_in,
+                       long n, int reps, void* stream);
+int supir_edm_step_post(const float* net_out, const float* x_hat, const float* x_center, float c_out, float c_skip, float cfg_scale,
+                        float restore_mul, float sigma_hat, float dt, float* x_next, long n, int reps, void* stream);
+
 /* Touch one dword per 128-byte line of [p, p+bytes) (a weight matrix) so that it is in flight through the memory-side
  * cache before the kernel that consumes it starts; launched a few ops ahead on a separate stream. `sink`: any 4 writable
  * device bytes (never written in practice). No reference counterpart: the reference re-reads fp32 weights through

@@ -38,6 +38,8 @@ SIGNATURES = {
     "supir_wavelet_level": [P, P, P, I, I, I, I, I, P],
     "supir_resample_u8": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "supir_bicubic_f32": [P, P, P, I, I, I, I, I, P],
+    "supir_edm_step_pre": [P, P, F, F, F, P, P, L, I, P],
+    "supir_edm_step_post": [P, P, P, F, F, F, F, F, F, P, L, I, P],
     "supir_gemm_tile_for": [I, I, I],
     "supir_prefetch": [P, c_size_t, P, P],
     "supir_set_next_prefetch": [P, c_size_t],

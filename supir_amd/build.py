@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm16.hip", "gemm_big.hip", "attention.hip", "attention_d512.hip", "norm.hip", "edge.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm16.hip", "gemm_big.hip", "attention.hip", "attention_d512.hip", "norm.hip", "edge.hip", "sampler.hip", "api.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "supir_hip.h")]
 LIB = os.path.join(HERE, "libsupir_hip.so")
 LIB_F16 = os.path.join(HERE, "libsupir_hip_f16.so")

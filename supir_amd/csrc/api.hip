@@ -263,4 +263,17 @@ int supir_bicubic_f32(const float* src, void* out_u8, float* out_f32, int C, int
     return supir_bicubic_f32_launch(src, (uint8_t*)out_u8, out_f32, C, H, W, OH, OW, (hipStream_t)stream);
 }
 
+int supir_edm_step_pre(const float* x, const float* eps, float s_noise, float noise_mul, float c_in, float* x_hat, float* net_in,
+                       long n, int reps, void* stream) {
+    if (!x || !net_in) return SUPIR_ERR_ARG;   // eps NULL: no churn on this step; x_hat NULL: the caller keeps using x
+    return supir_edm_pre_launch(x, eps, s_noise, noise_mul, c_in, x_hat, net_in, n, reps, (hipStream_t)stream);
+}
+
+int supir_edm_step_post(const float* net_out, const float* x_hat, const float* x_center, float c_out, float c_skip, float cfg_scale,
+                        float restore_mul, float sigma_hat, float dt, float* x_next, long n, int reps, void* stream) {
+    if (!net_out || !x_hat || !x_next) return SUPIR_ERR_ARG;   // x_center NULL: no restoration guidance on this step
+    return supir_edm_post_launch(net_out, x_hat, x_center, c_out, c_skip, cfg_scale, restore_mul, sigma_hat, dt, x_next, n, reps,
+                                 (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -100,6 +100,11 @@ int supir_pointwise_nchw_launch(const float* x, const float* w, const float* bia
                                 long HW, float in_scale, hipStream_t st);
 int supir_wavelet_level_launch(const float* img, float* low, float* high, int planes, int H, int W, int radius, int first,
                                hipStream_t st);
+// sampler.hip: the elementwise halves of one Restore-EDM sampler step around the network call (fp32 latents, host-side scalars)
+int supir_edm_pre_launch(const float* x, const float* eps, float s_noise, float noise_mul, float c_in, float* x_hat, float* net_in,
+                         long n, int reps, hipStream_t st);
+int supir_edm_post_launch(const float* net_out, const float* x_hat, const float* x_center, float c_out, float c_skip, float cfg,
+                          float restore_mul, float sigma_hat, float dt, float* x_next, long n, int reps, hipStream_t st);
 int supir_prefetch_launch(const void* p, size_t bytes, void* sink, hipStream_t st);
 int supir_resample_u8_launch(const uint8_t* src, uint8_t* dst_u8, float* dst_f32, const float* lut, const int* bounds, const int* kk,
                              int ksize, int in_h, int in_w, int out_h, int out_w, int ch, int vertical, hipStream_t st);

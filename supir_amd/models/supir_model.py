@@ -123,6 +123,8 @@ class SUPIRModel(nn.Module):
         else:
             c, uc = self.prepare_condition(_z, p, p_p, n_p, N)
         denoiser = lambda inp, sigma, cc, cs: self.denoiser(self.model, inp, sigma, cc, cs, **kwargs)
+        if not kwargs:   # lets RestoreEDMSampler fuse the elementwise halves of a step around the network call (sampling.py)
+            denoiser.fused = (self.denoiser, self.model)
         noised_z = noises["init"].to(_z).clone() if "init" in noises else torch.randn_like(_z)
         if "steps" in noises:   # parity runs: per-step churn noise instead of torch.randn_like (RestoreEDMSampler only)
             self.sampler.injected_step_noises = list(noises["steps"])

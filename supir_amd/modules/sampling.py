@@ -7,12 +7,16 @@ torch ops on the device; what changes is that the sigma schedule lives on the HO
 sync per step (the reference compares device tensors in Python twice per step, sampling.py:563,581).
 """
 import math
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 SIGMA_MAX = 14.6146
+# RestoreEDMSampler: run the elementwise halves of a step as two fused kernels (csrc/sampler.hip) with host-side scalars when the
+# caller exposes its denoiser / network (SUPIRModel.batchify_sample does); off -> the generic torch-op path for every caller
+FUSED_EDM_STEP = os.environ.get("SUPIR_FUSED_EDM_STEP", "0") == "1"
 
 
 def append_dims(x, ndim):
@@ -88,6 +92,35 @@ class DiscreteDenoiserWithControl(nn.Module):
 
     def w(self, sigma):
         return self.weighting(sigma)
+
+    # ---- host-side mirror of __call__'s scalar arithmetic for a batch-uniform sigma (the fused sampler step)
+    def host_scalars(self, sigma32):
+        """sigma (numpy float32 scalar) -> (table index, c_skip, c_out, c_in) exactly as __call__ computes them on the device in
+        fp32: snap to the nearest table entry (first minimum, like argmin), EpsScaling in the reference's operation order
+        (denoiser.py:49-73, denoiser_scaling.py:16-22).  None when the configuration is not the one SUPIR ships."""
+        if not (isinstance(self.scaling, EpsScaling) and self.quantize_c_noise):
+            return None
+        tab = self.__dict__.get("_host_table")
+        if tab is None:
+            tab = self.sigmas.detach().float().cpu().numpy().astype(np.float32)
+            self.__dict__["_host_table"] = tab
+        idx = int(np.argmin(np.abs(np.float32(sigma32) - tab)))
+        sq = np.float32(tab[idx])
+        c_in = np.float32(1.0) / np.sqrt(sq * sq + np.float32(1.0), dtype=np.float32)
+        return idx, 1.0, float(-sq), float(np.float32(c_in))
+
+    def idx_tensor(self, idx, count, device):
+        """int64 [count] filled with a table index (what the network receives as c_noise); cached: a 50-step schedule visits the
+        same 50 indices for every image."""
+        cache = self.__dict__.setdefault("_idx_cache", {})
+        key = (idx, count, str(device))
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 4096:
+                cache.clear()
+            t = torch.full((count,), idx, dtype=torch.int64, device=device)
+            cache[key] = t
+        return t
 
     def __call__(self, network, input, sigma, cond, control_scale, **kwargs):
         """denoiser.py:66-73: sigma snapped to the 1000-entry table; the network sees the int64 table index."""
@@ -208,12 +241,66 @@ class RestoreEDMSampler(BaseDiffusionSampler):
     def _gamma(self, sig_f, num_sigmas):
         return min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sig_f <= self.s_tmax else 0.0
 
+    # ------------------------------------------------------------------ fused step (two elementwise kernels + the network call)
+    def _fused_ctx(self, denoiser, x):
+        """(denoiser module, network) when this call can take the fused step: fp32 CUDA latents, a caller that exposes what its
+        denoiser closure wraps (`denoiser.fused = (DiscreteDenoiserWithControl, network)`), the guiders SUPIR ships."""
+        f = getattr(denoiser, "fused", None)
+        if not FUSED_EDM_STEP or f is None or not x.is_cuda or x.dtype != torch.float32:
+            return None
+        if not isinstance(self.guider, (LinearCFG, IdentityGuider)):
+            return None
+        if isinstance(self.guider, LinearCFG) and not isinstance(self.guider.dyn_thresh, NoDynamicThresholding):
+            return None
+        den, net = f
+        if not isinstance(den, DiscreteDenoiserWithControl) or den.host_scalars(np.float32(1.0)) is None:
+            return None
+        return den, net
+
+    def _fused_step(self, ctx, sigma_f, next_sigma_f, x, gamma, x_center, eps_noise, control_scale, use_linear_control_scale,
+                    control_scale_start, cond_cat):
+        """sampler_step (sampling.py:548-570) with every sigma-derived factor evaluated on the host in fp32, in the reference's
+        operation order, and the tensor work in supir_edm_step_pre / _post.  Same RNG consumption as the generic path."""
+        from .. import ops
+        den, net = ctx
+        f32 = np.float32
+        sigma, nxt = f32(sigma_f), f32(next_sigma_f)
+        sigma_hat = sigma * f32(gamma + 1.0)
+        eps, noise_mul = None, 0.0
+        if gamma > 0:
+            eps = eps_noise if eps_noise is not None else torch.randn_like(x)
+            noise_mul = float(np.sqrt(sigma_hat * sigma_hat - sigma * sigma, dtype=f32))
+        if use_linear_control_scale:
+            control_scale = (sigma_f / self.sigma_max) * (control_scale_start - control_scale) + control_scale
+        idx, c_skip, c_out, c_in = den.host_scalars(sigma_hat)
+        twice = not isinstance(self.guider, IdentityGuider)
+        reps = 2 if twice else 1
+        x = x if x.is_contiguous() else x.contiguous()
+        x_hat, net_in = ops.edm_step_pre(x, None if eps is None else eps.float().contiguous(), self.s_noise, noise_mul, c_in, reps)
+        out = net(net_in, den.idx_tensor(idx, net_in.shape[0], x.device), cond_cat, control_scale)
+        cfg = 0.0
+        if twice:
+            g = self.guider
+            cfg = float(f32(g.scale - g.scale_min) * sigma_hat / f32(SIGMA_MAX) + f32(g.scale_min))
+        center, restore_mul = None, 0.0
+        if (next_sigma_f > self.restore_cfg_s_tmin) and (self.restore_cfg > 0):
+            center = x_center
+            restore_mul = float(np.power(sigma / f32(self.sigma_max), f32(self.restore_cfg), dtype=f32))
+        return ops.edm_step_post(out.float().contiguous(), x_hat, center, c_out, c_skip, cfg, restore_mul, float(sigma_hat),
+                                 float(nxt - sigma_hat), reps)
+
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None, x_center=None, control_scale=1.0,
                  use_linear_control_scale=False, control_scale_start=0.0):
         x, s_in, sigmas, num_sigmas, cond, uc, sf = self.prepare_sampling_loop(x, cond, uc, num_steps)
         cond_cat = self.guider.prepare_cond(cond, uc)            # constant over the loop: concat once
         inject = self.__dict__.pop("injected_step_noises", None)  # parity runs: the churn noise of every step, given
+        ctx = self._fused_ctx(denoiser, x) if type(self).sampler_step is RestoreEDMSampler.sampler_step else None
         for i in range(num_sigmas - 1):
+            if ctx is not None:
+                x = self._fused_step(ctx, sf[i], sf[i + 1], x, self._gamma(sf[i], num_sigmas), x_center,
+                                     None if inject is None else inject[i].to(x), control_scale, use_linear_control_scale,
+                                     control_scale_start, cond_cat)
+                continue
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, self._gamma(sf[i], num_sigmas),
                                   x_center, eps_noise=None if inject is None else inject[i].to(x), control_scale=control_scale, use_linear_control_scale=use_linear_control_scale,
                                   control_scale_start=control_scale_start, cond_cat=cond_cat, sigma_f=sf[i],

@@ -826,6 +826,42 @@ def pointwise_nchw(x, w, bias, in_scale=1.0):
     return out
 
 
+# --------------------------------------------------------------------------------------------- sampler step (elementwise halves)
+def edm_step_pre(x, eps, s_noise, noise_mul, c_in, reps):
+    """x_hat = x + (eps * s_noise) * noise_mul (eps None: x_hat is x itself); net_in = [x_hat * c_in] * reps along the batch.
+    fp32 contiguous latents; returns (x_hat, net_in).  See supir_edm_step_pre."""
+    lib = _lib.load()
+    _check_dev(x, eps)
+    assert x.dtype == torch.float32 and x.is_contiguous() and (eps is None or (eps.dtype == torch.float32 and eps.is_contiguous()
+                                                                                and eps.shape == x.shape))
+    n = x.numel()
+    x_hat = torch.empty_like(x) if eps is not None else x
+    net_in = torch.empty((reps * x.shape[0],) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    rc = lib.supir_edm_step_pre(x.data_ptr(), _p(eps), float(s_noise), float(noise_mul), float(c_in),
+                                x_hat.data_ptr() if eps is not None else 0, net_in.data_ptr(), n, reps, _stream())
+    _lib.check(rc, "supir_edm_step_pre", lib)
+    return x_hat, net_in
+
+
+def edm_step_post(net_out, x_hat, x_center, c_out, c_skip, cfg_scale, restore_mul, sigma_hat, dt, reps):
+    """den = CFG(net_out * c_out + x_hat * c_skip), restoration guidance towards x_center (None: skipped), Euler step; returns
+    x_next (fp32, new tensor).  See supir_edm_step_post."""
+    lib = _lib.load()
+    _check_dev(net_out, x_hat, x_center)
+    n = x_hat.numel()
+    assert net_out.dtype == torch.float32 and net_out.is_contiguous() and net_out.numel() == reps * n
+    assert x_hat.dtype == torch.float32 and x_hat.is_contiguous()
+    if x_center is not None:
+        if x_center.dtype != torch.float32 or not x_center.is_contiguous():
+            x_center = x_center.float().contiguous()
+        assert x_center.shape == x_hat.shape
+    out = torch.empty_like(x_hat)
+    rc = lib.supir_edm_step_post(net_out.data_ptr(), x_hat.data_ptr(), _p(x_center), float(c_out), float(c_skip), float(cfg_scale),
+                                 float(restore_mul), float(sigma_hat), float(dt), out.data_ptr(), n, reps, _stream())
+    _lib.check(rc, "supir_edm_step_post", lib)
+    return out
+
+
 def wavelet_decomposition(img, levels=5, want_high=True):
     """(high, low) of SUPIR/utils/colorfix.py:96-107 on fp32 [N,3,H,W]: `levels` launches of supir_wavelet_level (radius 2^i),
     ping-ponging two low-pass buffers; `high` accumulates img_i - low_i in place.  want_high=False skips the high band (the style

@@ -452,3 +452,62 @@ def test_gemm_autotune_candidate_lists_follow_the_kernel_predicates():
     assert set(c(2048, 2400, 1280, 2, 0, 1200, geglu16=True)) == set(geglu) | {34}   # N % 320
     assert set(c(2048 + 128, 10240, 1280, 2, 0, 5120, geglu16=True)) == set(geglu)   # M % 256
     assert ops.gemm_tile_name(2048, 10240, act=2, tile=37).startswith("geglu_big_kernel")
+
+
+def test_fused_edm_step_host_scalars_match_the_generic_step(monkeypatch):
+    """RestoreEDMSampler._fused_step evaluates every sigma-derived factor on the host (numpy fp32, reference operation order) and
+    hands the tensor work to supir_edm_step_pre / _post.  Here the two kernels are replaced by torch restatements of their
+    documented formulas (include/supir_hip.h) so the HOST logic -- table snap, EpsScaling factors, linear CFG scale, restoration
+    factor, Euler dt, churn, RNG consumption -- is compared with the generic torch-op sampler_step on the CPU, step by step."""
+    from supir_amd import ops
+    from supir_amd.modules.sampling import DiscreteDenoiserWithControl, IdentityGuider, LinearCFG, RestoreEDMSampler
+
+    def fake_pre(x, eps, s_noise, noise_mul, c_in, reps):
+        x_hat = x if eps is None else x + (eps * s_noise) * noise_mul
+        return x_hat, torch.cat([x_hat * c_in] * reps)
+
+    def fake_post(net_out, x_hat, x_center, c_out, c_skip, cfg, restore_mul, sigma_hat, dt, reps):
+        dens = [h * c_out + x_hat * c_skip for h in net_out.chunk(reps)]
+        den = dens[0] + cfg * (dens[1] - dens[0]) if reps == 2 else dens[0]
+        if x_center is not None:
+            den = den - (den - x_center) * restore_mul
+        return x_hat + dt * ((x_hat - den) / sigma_hat)
+
+    monkeypatch.setattr(ops, "edm_step_pre", fake_pre)
+    monkeypatch.setattr(ops, "edm_step_post", fake_post)
+    den = DiscreteDenoiserWithControl()
+    seen = []
+
+    def net(x, t, c, cs, **kw):
+        seen.append((t.clone(), float(cs)))
+        return torch.tanh(x * 0.7 + c["crossattn"].mean() + t.view(-1, 1, 1, 1).float() * 1e-3) * float(cs)
+
+    def denoiser(i, s, cc, cs):
+        return den(net, i, s, cc, cs)
+
+    c = {"crossattn": synth_tensor("fz.c", (2, 7, 8)), "vector": synth_tensor("fz.v", (2, 6)), "control": synth_tensor("fz.k", (2, 4, 8, 8))}
+    uc = {k: v * 0.5 for k, v in c.items()}
+    x0, xc = synth_tensor("fz.x", (2, 4, 8, 8)), synth_tensor("fz.xc", (2, 4, 8, 8))
+    for guider, restore, steps, lin_cs in ((LinearCFG(1.0, 4.0), 4.0, 6, False), (LinearCFG(7.5, 7.5), -1.0, 5, True),
+                                           (IdentityGuider(), 2.0, 4, False)):
+        smp = RestoreEDMSampler(num_steps=steps, s_churn=5, s_noise=1.01, restore_cfg=restore, guider_config=guider, device="cpu")
+        xa, s_in, sigmas, n, cond, ucond, sf = smp.prepare_sampling_loop(x0.clone(), c, uc, steps)
+        xb = xa.clone()
+        cond_cat = smp.guider.prepare_cond(cond, ucond)
+        for i in range(n - 1):
+            gamma = smp._gamma(sf[i], n)
+            del seen[:]
+            torch.manual_seed(100 + i)
+            xa = smp.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, xa, cond, ucond, gamma, xc, control_scale=0.9,
+                                  use_linear_control_scale=lin_cs, control_scale_start=0.2, cond_cat=cond_cat, sigma_f=sf[i],
+                                  next_sigma_f=sf[i + 1])
+            t_ref, cs_ref = seen[0]
+            del seen[:]
+            torch.manual_seed(100 + i)
+            xb = smp._fused_step((den, net), sf[i], sf[i + 1], xb, gamma, xc, None, 0.9, lin_cs, 0.2, cond_cat)
+            t_fu, cs_fu = seen[0]
+            assert torch.equal(t_ref, t_fu) and cs_ref == cs_fu          # same table index into the network, same control scale
+            assert torch.allclose(xa, xb, rtol=2e-6, atol=2e-6), (i, (xa - xb).abs().max())
+        assert torch.isfinite(xb).all()
+    # callers that do not expose their denoiser keep the generic path; so do CPU latents
+    assert smp._fused_ctx(denoiser, x0) is None

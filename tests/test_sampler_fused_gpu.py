@@ -1,0 +1,102 @@
+"""supir_edm_step_pre / supir_edm_step_post (csrc/sampler.hip): the elementwise halves of RestoreEDMSampler.sampler_step
+(sgm/modules/diffusionmodules/sampling.py:548-570 + guiders.py:44-74 + denoiser.py:66-73) as two launches with host-side
+scalars, against the torch-op form of the same expressions, and the sampler with the fused step against the generic step with
+the real (reduced-depth) network, step by step from the same state.
+
+fp32 elementwise arithmetic: the kernels may contract a*b+c into one fused multiply-add where torch rounds twice, so the bar is
+a few ulp (rtol 1e-6 on values of order 1), not bitwise."""
+import os
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("SUPIR_TEST_FUSED_STEP", "0") != "1",
+                                 reason="fused sampler step not yet validated on hardware: opt in with SUPIR_TEST_FUSED_STEP=1")]
+
+from supir_amd import ops  # noqa: E402
+from tests.helpers import build_unet, rel_l2, synth_tensor  # noqa: E402
+
+DEV = "cuda"
+
+
+def T(name, shape, **kw):
+    return synth_tensor(name, shape, **kw).to(DEV)
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 128, 128), (2, 4, 64, 64), (3, 4, 9, 7), (1, 1, 1, 3)])
+@pytest.mark.parametrize("reps", [2, 1])
+def test_edm_step_kernels_vs_torch(shape, reps):
+    n = 1
+    for d in shape:
+        n *= d
+    if reps == 2 and n % 4:
+        pytest.skip("CFG doubling needs n % 4 == 0 (latents have 4 channels)")
+    x, eps, xc = T("fs.x", shape), T("fs.e", shape), T("fs.c", shape)
+    s_noise, noise_mul, c_in = 1.01, 0.7312, 0.0683
+    x_hat, net_in = ops.edm_step_pre(x, eps, s_noise, noise_mul, c_in, reps)
+    ref_hat = x + (eps * s_noise) * noise_mul
+    assert torch.allclose(x_hat, ref_hat, rtol=1e-6, atol=1e-6)
+    assert net_in.shape[0] == reps * shape[0] and torch.allclose(net_in, torch.cat([ref_hat * c_in] * reps), rtol=1e-6, atol=1e-7)
+    same, net_in2 = ops.edm_step_pre(x, None, s_noise, 0.0, c_in, reps)        # no churn: x_hat is x itself
+    assert same is x and torch.allclose(net_in2, torch.cat([x * c_in] * reps), rtol=1e-6, atol=1e-7)
+    net_out = T("fs.n", (reps * shape[0],) + shape[1:])
+    c_out, c_skip, cfg, rmul, sh, dt = -14.25, 1.0, 2.37, 0.83, 14.25, -1.9
+    for center in (xc, None):
+        out = ops.edm_step_post(net_out, ref_hat, center, c_out, c_skip, cfg, rmul, sh, dt, reps)
+        dens = [h * c_out + ref_hat * c_skip for h in net_out.chunk(reps)]
+        den = dens[0] + cfg * (dens[1] - dens[0]) if reps == 2 else dens[0]
+        if center is not None:
+            den = den - (den - center) * rmul
+        ref = ref_hat + dt * ((ref_hat - den) / sh)
+        assert torch.allclose(out, ref, rtol=2e-6, atol=2e-5), (out - ref).abs().max()
+
+
+def test_sampler_fused_step_vs_generic_step_with_the_real_network(monkeypatch):
+    """RestoreEDMSampler with FUSED_EDM_STEP against the generic sampler_step, teacher-forced from the same state at every step
+    (reduced-depth network, real widths, latent 32^2, 4 steps, churn + linear CFG + restoration guidance), then free-running with
+    the same seed: identical RNG consumption, outputs within the bf16 network's sensitivity to ulp-level input differences."""
+    from supir_amd.modules import sampling
+    from supir_amd.modules.sampling import DiscreteDenoiserWithControl, LinearCFG, RestoreEDMSampler
+    mini = build_unet(depth=(1, 1, 2), device=DEV)
+    den = DiscreteDenoiserWithControl().to(DEV)
+    h = w = 32
+    ctx, y = T("context", (2, 77, 2048)), T("vector", (2, 2816))
+    lq = T("lq_tiled", (1, 4, h, w))
+    c = {"crossattn": ctx[:1], "vector": y[:1], "control": lq}
+    uc = {"crossattn": ctx[1:], "vector": y[1:], "control": lq}
+    xc = T("fs.center", (1, 4, h, w))
+
+    def denoiser(i, s, cc, cs):
+        return den(mini, i, s, cc, cs)
+
+    denoiser.fused = (den, mini)
+    steps = 4
+    smp = RestoreEDMSampler(num_steps=steps, s_churn=5, s_noise=1.01, restore_cfg=4.0, guider_config=LinearCFG(1.0, 4.0), device=DEV)
+    monkeypatch.setattr(sampling, "FUSED_EDM_STEP", True)
+    with torch.no_grad():
+        assert smp._fused_ctx(denoiser, lq) is not None
+        x, s_in, sigmas, n, cond, ucond, sf = smp.prepare_sampling_loop(T("fs.x0", (1, 4, h, w)).clone(), c, uc, steps)
+        cond_cat = smp.guider.prepare_cond(cond, ucond)
+        worst = 0.0
+        for i in range(n - 1):
+            gamma = smp._gamma(sf[i], n)
+            torch.manual_seed(7 + i)
+            a = smp.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, ucond, gamma, xc, control_scale=1.0,
+                                 cond_cat=cond_cat, sigma_f=sf[i], next_sigma_f=sf[i + 1])
+            torch.manual_seed(7 + i)
+            b = smp._fused_step((den, mini), sf[i], sf[i + 1], x, gamma, xc, None, 1.0, False, 0.0, cond_cat)
+            worst = max(worst, rel_l2(b, a))
+            x = a
+        print(f"[fused step] teacher-forced worst rel-L2 over {n - 1} steps: {worst:.3e}")
+        assert worst <= 2e-3, worst
+        outs = []
+        for fused in (False, True):
+            monkeypatch.setattr(sampling, "FUSED_EDM_STEP", fused)
+            torch.manual_seed(1234)
+            outs.append(smp(denoiser, T("fs.x0", (1, 4, h, w)).clone(), cond=dict(c), uc=dict(uc), x_center=xc).float())
+            outs.append(torch.randn(4, device=DEV))   # the next draw: equal iff both paths consumed the same number of values
+        e = rel_l2(outs[2], outs[0])
+        print(f"[fused step] free-running {steps} steps, fused vs generic: rel-L2 {e:.3e}")
+        assert e <= 1e-2, e
+        assert torch.equal(outs[1], outs[3])      # both paths drew the same number of random values
