@@ -18,6 +18,19 @@ import torch.nn as nn
 
 from .. import weights as Wt
 
+# hipGraph capture mode.  "global" (torch's default) fails a capture when ANY thread of the process makes a capture-unsafe HIP
+# call meanwhile; with torch.distributed initialised there is such a thread (ProcessGroupNCCL's watchdog polls events), so ranks of
+# a multi-GPU job capture in "thread_local" mode, which only polices the capturing thread.  SUPIR_GRAPH_CAPTURE_MODE overrides.
+CAPTURE_MODE = os.environ.get("SUPIR_GRAPH_CAPTURE_MODE", "auto")
+
+
+def _capture_mode():
+    if CAPTURE_MODE != "auto":
+        return CAPTURE_MODE
+    import torch.distributed as dist
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 # fp16 requests run on the fp16 build of the kernels (True) or are served by bf16 with a warning (False)
 FP16_NATIVE = os.environ.get("SUPIR_FP16_NATIVE", "0") == "1"
 
@@ -145,7 +158,7 @@ class ControlWrapper(nn.Module):
                     pf.end()
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
                 if pf is not None:
                     pf.begin_replay(x.device)
                 out = self._forward_eager(sx, st, cond, control_scale)

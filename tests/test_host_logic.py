@@ -511,3 +511,16 @@ def test_fused_edm_step_host_scalars_match_the_generic_step(monkeypatch):
         assert torch.isfinite(xb).all()
     # callers that do not expose their denoiser keep the generic path; so do CPU latents
     assert smp._fused_ctx(denoiser, x0) is None
+
+
+def test_graph_capture_mode_follows_torch_distributed(monkeypatch):
+    """hipGraph capture is thread-local on the ranks of a multi-GPU job (the process-group watchdog thread makes HIP calls while
+    the main thread captures), global otherwise; SUPIR_GRAPH_CAPTURE_MODE overrides."""
+    import torch.distributed as dist
+    from supir_amd.modules import wrappers
+    monkeypatch.setattr(wrappers, "CAPTURE_MODE", "auto")
+    assert wrappers._capture_mode() == "global"
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    assert wrappers._capture_mode() == "thread_local"
+    monkeypatch.setattr(wrappers, "CAPTURE_MODE", "relaxed")
+    assert wrappers._capture_mode() == "relaxed"

@@ -1,0 +1,57 @@
+"""In-process A/B on one box (box-to-box spread is ~5 %, so never compare across calls): seconds per 1024^2 50-step image with
+(a) the round-2 defaults, (b) + fused sampler step (supir_edm_step_pre/_post), (c) + flash D=512 VAE attention.
+Usage: python tools/ab_fused_step_d512.py [--images 2]   -> gpurun_out/ab_fused_step_d512.json"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--images", type=int, default=2)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+from supir_amd import ops  # noqa: E402
+from supir_amd.modules import sampling  # noqa: E402
+from supir_amd.synth import synth_tensor  # noqa: E402
+
+model, _, _ = bench.build_model(dev, 0, 1)
+model.model.enable_graph(True)
+x = synth_tensor("bench.img0.1", (1, 3, 1024, 1024), scale=0.5).clamp(-1, 1).to(dev)
+c = {"crossattn": synth_tensor("bench.c", (1, 77, 2048)).to(dev), "vector": synth_tensor("bench.v", (1, 2816)).to(dev)}
+uc = {"crossattn": synth_tensor("bench.uc", (1, 77, 2048)).to(dev), "vector": synth_tensor("bench.uv", (1, 2816)).to(dev)}
+
+
+def run(tag, fused, d512):
+    sampling.FUSED_EDM_STEP, ops.USE_FLASH_D512 = fused, d512
+    out = bench.one_image(model, x, (c, uc), 1234, 50)      # warm: autotune / graph capture for anything new
+    torch.cuda.synchronize()
+    ts = []
+    for i in range(args.images):
+        t0 = time.perf_counter()
+        out = bench.one_image(model, x, (c, uc), 2000 + i, 50)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    r = {"s_per_image_min": min(ts), "s_per_image": ts, "finite": bool(torch.isfinite(out).all())}
+    print(tag, r, flush=True)
+    return r, out
+
+
+res = {}
+res["a_defaults"], oa = run("a_defaults", False, False)
+res["b_fused_step"], ob = run("b_fused_step", True, False)
+res["c_fused_step_flash_d512"], oc = run("c_fused_step_flash_d512", True, True)
+res["a_defaults_again"], _ = run("a_defaults_again", False, False)
+# same seeds -> same noise: the three variants produce the same image up to the network's sensitivity to ulp-level differences
+res["rel_l2_b_vs_a"] = float((ob - oa).norm() / oa.norm())
+res["rel_l2_c_vs_a"] = float((oc - oa).norm() / oa.norm())
+print(res)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "ab_fused_step_d512.json"), "w"), indent=1)
