@@ -304,4 +304,4 @@ def test_dpmpp2m_config5_sampler_fp16(mini, monkeypatch):
     finally:
         mini.dtype = torch.bfloat16
     _record("dpmpp2m_sampler_fp16_32x32", **res)
-    assert max(res.values()) <= 6e-3
+    assert max(res.values()) <= 1e-3   # the bf16 build measures 1.4e-3 / 1.8e-3 on this test (profiles/r02/parity.json)

@@ -52,6 +52,42 @@ res["a_defaults_again"], _ = run("a_defaults_again", False, False)
 # same seeds -> same noise: the three variants produce the same image up to the network's sensitivity to ulp-level differences
 res["rel_l2_b_vs_a"] = float((ob - oa).norm() / oa.norm())
 res["rel_l2_c_vs_a"] = float((oc - oa).norm() / oa.norm())
+
+# ---- the fp16 build at production scale: one CFG-doubled network call at latent 128^2, full depth, against the bf16 build's output
+# of the same call (the two differ by bf16's own error, ~1e-2), finiteness (fp16 overflows at 65504), and ms per step under replay
+from supir_amd.modules import wrappers  # noqa: E402
+xx = synth_tensor("bench.x", (2, 4, 128, 128)).to(dev)
+cond = {"crossattn": torch.cat([uc["crossattn"], c["crossattn"]]), "vector": torch.cat([uc["vector"], c["vector"]]),
+        "control": synth_tensor("bench.lq", (2, 4, 128, 128)).to(dev)}
+tt = torch.full((2,), 500, dtype=torch.int64, device=dev)
+
+
+def ms_per_step():
+    with torch.no_grad():
+        for _ in range(3):
+            o = model.model(xx, tt, cond, 1.0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            o = model.model(xx, tt, cond, 1.0)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 10, o.clone()
+
+
+try:
+    ms_bf, o_bf = ms_per_step()
+    wrappers.FP16_NATIVE = True
+    model.model.dtype = torch.float16
+    ms_hf, o_hf = ms_per_step()
+    res["fp16_full_depth_latent128"] = {"ms_per_step_bf16": ms_bf, "ms_per_step_fp16": ms_hf, "finite": bool(torch.isfinite(o_hf).all()),
+                                        "rel_l2_fp16_vs_bf16": float((o_hf - o_bf).norm() / o_bf.norm()),
+                                        "max_abs_out": float(o_hf.abs().max())}
+except Exception as e:   # noqa: BLE001 -- a diagnostic leg must not lose the A/B numbers above
+    res["fp16_full_depth_latent128"] = {"error": repr(e)}
+finally:
+    model.model.dtype = torch.bfloat16
 print(res)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "ab_fused_step_d512.json"), "w"), indent=1)
