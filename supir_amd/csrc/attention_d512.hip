@@ -15,8 +15,8 @@
 // [32][512] (32 KB) and V^T tile [512][32] (32 KB), double buffered through LDS by global_load_lds (128 KB).
 //   S^T = K.Q^T  (32 MFMAs, two independent accumulator chains; operands swapped so that a lane owns ONE query column:
 //                 the row maximum is one v_permlane32_swap away and P needs no cross-lane exchange)
-//   P   = exp2(S^T - m)  with the softmax scale * log2(e) folded into Q; m = the EXACT row maximum, found by a first pass over
-//                 the K tiles alone (S^T only) -- with 256 accumulators an online rescale is what must not happen (see pass 1)
+//   P   = exp2((S^T - m) * scale * log2(e));  m = the EXACT row maximum of the raw scores, found by a first pass over the K
+//                 tiles alone (S^T only) -- with 256 accumulators an online rescale is what must not happen (see pass 1)
 //   O^T += V^T.P  (32 MFMAs)
 // K rows are read with bits 2/3 of the row index swapped, which makes the 8 P values a lane holds per 16-key block the 8
 // CONSECUTIVE keys of one 16-byte chunk of a V^T row (see attention.hip).  Both tiles are stored XOR-swizzled (the swizzle is
@@ -102,14 +102,12 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
 
 #pragma unroll
     for (int i = 0; i < LPT; ++i) stage_k(0, 0, i);
-    // Q carries the softmax scale in log2 units from here on (one extra rounding of Q, as in attention.hip)
+    // Q fragments as stored.  The softmax scale is applied to the fp32 scores inside the exponential (16 multiplies per key tile
+    // against 64 MFMAs): folding it into Q as attention.hip does costs one more 16-bit rounding of Q, which at T = 16 384 keys
+    // and logits of a few nats was the largest error term of the kernel (measured 4.1e-3 rel-L2 against fp32 SDPA).
     bf16x8 qf[32];
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) {
-        const bf16x8 raw = *(const bf16x8*)(Qp + 16 * ks);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)((float)raw[e] * c);
-    }
+    for (int ks = 0; ks < 32; ++ks) qf[ks] = *(const bf16x8*)(Qp + 16 * ks);
 
     const int klast = p.Tk - 1;
     // S^T = K.Q^T + c0 for the tile in stage `sb`, keys past the end -> -inf.  Eight groups of four k steps: the fragments of
@@ -180,7 +178,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     __builtin_amdgcn_s_barrier();   // every wave is done with the last K tile before stage 0 is refilled
     asm volatile("" ::: "memory");
 
-    // ================= pass 2: P = exp2(S^T - m), O^T += V^T.P =================
+    // ================= pass 2: P = exp2((S^T - m) c), O^T += V^T.P =================
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         stage_k(0, 0, i);
@@ -212,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
         bf16x8 pf[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[r]);
+            const float pv = __builtin_amdgcn_exp2f(s[r] * c);   // s = q.k - max_k q.k <= 0 in raw units; c = scale * log2(e)
             l_run += pv;
             pf[r >> 3][r & 7] = (bf16_t)pv;
         }
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
 
 int supir_attn_d512_launch(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int B, int Tq, int Tk, int ldq, int ldk,
                            int ldvt, int ldo, float scale, hipStream_t st) {
-    if (B <= 0 || Tq <= 0 || Tk <= 0) return SUPIR_ERR_ARG;
+    if (B <= 0 || Tq <= 0 || Tk <= 0 || !(scale > 0.f)) return SUPIR_ERR_ARG;   // the row maxima are taken on the unscaled scores
     if ((ldq | ldk | ldvt) % 8 != 0 || ldo % 4 != 0 || ldq < 512 || ldk < 512 || ldo < 512) return SUPIR_ERR_SHAPE;
     if (ldvt < ((Tk + KT - 1) / KT) * KT) return SUPIR_ERR_SHAPE;
     Attn512Args a{Q, K, Vt, O, B, Tq, Tk, ldq, ldk, ldvt, ldo, scale * 1.4426950408889634f};

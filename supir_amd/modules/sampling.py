@@ -16,7 +16,7 @@ import torch.nn as nn
 SIGMA_MAX = 14.6146
 # RestoreEDMSampler: run the elementwise halves of a step as two fused kernels (csrc/sampler.hip) with host-side scalars when the
 # caller exposes its denoiser / network (SUPIRModel.batchify_sample does); off -> the generic torch-op path for every caller
-FUSED_EDM_STEP = os.environ.get("SUPIR_FUSED_EDM_STEP", "0") == "1"
+FUSED_EDM_STEP = os.environ.get("SUPIR_FUSED_EDM_STEP", "1") == "1"
 
 
 def append_dims(x, ndim):

@@ -32,7 +32,7 @@ def _capture_mode():
 
 
 # fp16 requests run on the fp16 build of the kernels (True) or are served by bf16 with a warning (False)
-FP16_NATIVE = os.environ.get("SUPIR_FP16_NATIVE", "0") == "1"
+FP16_NATIVE = os.environ.get("SUPIR_FP16_NATIVE", "1") == "1"
 
 
 class ControlWrapper(nn.Module):

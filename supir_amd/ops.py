@@ -644,7 +644,20 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     return out
 
 
-USE_FLASH_D512 = _os.environ.get("SUPIR_FLASH_D512", "0") == "1"   # VAE mid-block attention through supir_flash_attn_d512
+# VAE mid-block attention (one head, dim 512): supir_flash_attn_d512 never forms the score matrix but, measured at T = 16 384
+# (1024^2 px), runs at 242 TFLOP/s = 2.27 ms against 1.54 ms for the materialised form (GEMM -> fp32 scores -> softmax_rows -> GEMM;
+# profiles/r02/attn_d512_timing.json): with 288 GB of HBM the 1.5 GB of temporaries are cheap, so the flash kernel takes over only
+# where they stop being so -- "auto": when the fp32 score matrix of ONE batch element would exceed FLASH_D512_AUTO_BYTES (8 GiB:
+# T > 46 340 tokens, i.e. an untiled image beyond ~1720^2 px).  SUPIR_FLASH_D512 = 1 / 0 forces it on / off.
+USE_FLASH_D512 = {"1": True, "0": False}.get(_os.environ.get("SUPIR_FLASH_D512", "auto"), "auto")
+FLASH_D512_AUTO_BYTES = 8 << 30
+
+
+def use_flash_d512(T):
+    """Whether the head-dim-512 attention over T tokens takes the flash kernel (see USE_FLASH_D512)."""
+    if USE_FLASH_D512 == "auto":
+        return 4 * T * ((T + 63) // 64 * 64) > FLASH_D512_AUTO_BYTES
+    return bool(USE_FLASH_D512)
 
 
 def flash_attn_d512(q, k, vt, Tk, out=None):

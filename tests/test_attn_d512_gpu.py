@@ -11,9 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("SUPIR_TEST_D512", "0") != "1",
-                                 reason="flash D=512 kernel not yet validated on hardware: opt in with SUPIR_TEST_D512=1")]
+pytestmark = pytest.mark.gpu
 
 from supir_amd import ops  # noqa: E402
 

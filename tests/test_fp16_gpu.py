@@ -14,9 +14,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("SUPIR_TEST_FP16", "0") != "1",
-                                 reason="fp16 build not yet validated on hardware: opt in with SUPIR_TEST_FP16=1")]
+pytestmark = pytest.mark.gpu
 
 from supir_amd import ops  # noqa: E402
 from supir_amd import weights as Wt  # noqa: E402

@@ -524,3 +524,17 @@ def test_graph_capture_mode_follows_torch_distributed(monkeypatch):
     assert wrappers._capture_mode() == "thread_local"
     monkeypatch.setattr(wrappers, "CAPTURE_MODE", "relaxed")
     assert wrappers._capture_mode() == "relaxed"
+
+
+def test_flash_d512_policy(monkeypatch):
+    """VAE mid-block attention: the flash kernel (no score matrix) is slower than the materialised form at BASELINE sizes
+    (measured), so "auto" switches to it only when one batch element's fp32 score matrix would exceed 8 GiB; 1 / 0 force it."""
+    from supir_amd import ops
+    monkeypatch.setattr(ops, "USE_FLASH_D512", "auto")
+    assert not ops.use_flash_d512(16384) and not ops.use_flash_d512(4096)      # 1024^2 / 512^2 px: 1 GiB / 64 MiB of scores
+    assert not ops.use_flash_d512(46336) and ops.use_flash_d512(46400)         # the 8 GiB boundary
+    assert ops.use_flash_d512(65536)                                           # 2048^2 px untiled: 16 GiB of scores
+    monkeypatch.setattr(ops, "USE_FLASH_D512", True)
+    assert ops.use_flash_d512(64)
+    monkeypatch.setattr(ops, "USE_FLASH_D512", False)
+    assert not ops.use_flash_d512(1 << 20)

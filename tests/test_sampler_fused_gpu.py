@@ -10,9 +10,7 @@ import os
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("SUPIR_TEST_FUSED_STEP", "0") != "1",
-                                 reason="fused sampler step not yet validated on hardware: opt in with SUPIR_TEST_FUSED_STEP=1")]
+pytestmark = pytest.mark.gpu
 
 from supir_amd import ops  # noqa: E402
 from tests.helpers import build_unet, rel_l2, synth_tensor  # noqa: E402
