@@ -231,6 +231,11 @@ def vae_colorfix_profile(model, P, device):
     return out
 
 
+def _fused_step_on():
+    from supir_amd.modules import sampling
+    return bool(sampling.FUSED_EDM_STEP)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,7 +446,8 @@ def main():
                                    f"random-init weights", "edm_steps": args.edm_steps, "resolution": P,
                        "images_per_gpu_per_step": ipg, "parallelism": f"dp{world} (replicated weights, no collective inside a sample)",
                        "hip_graph": not args.no_graph,
-                       "two_stream_overlap": bool(model.model.overlap_branches)},
+                       "two_stream_overlap": bool(model.model.overlap_branches),
+                       "fused_sampler_step": _fused_step_on()},
             "roofline": roofline, "cpu_baseline": cpu, "autotune_entries_resynced_max_over_ranks": autotune_resynced,
             "output_finite": finite, "weight_fill_s": round(t_fill, 2), "weight_broadcast_s": round(t_bcast, 2),
             "end_to_end_tflops_per_gpu": IMAGE_TFLOP_1024 * args.steps * ipg / dt if P == 1024 and args.edm_steps == 50 else None,

@@ -70,18 +70,23 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     // ---- loader: one wave-instruction moves 1 KB.  K: instruction r = key row r of the tile (64 chunks of 16 B); the lane
     // that fills LDS chunk position `lane` fetches logical chunk lane ^ (r & 15).  V^T: instruction i = channel rows
     // 16 i .. 16 i + 15 (4 chunks each); position (row, lane & 3) fetches logical chunk (lane & 3) ^ ((row >> 2) & 3).
+    // Source address = wave-uniform 64-bit base (SGPR pair) + a per-lane UNSIGNED 32-bit byte offset, so that the loads take the
+    // scalar-base form and no 64-bit per-lane address is ever formed (the first version spilled four of them and reloaded them from
+    // scratch between the loads: every reload's vmcnt(0) also waited for the LDS-DMA issued before it).
     constexpr int LPT = 32 / NW;   // wave-instructions per wave for each of the two tiles
-    auto stage_k = [&](int t, int soff, int i) {   // i in [0, LPT)
+    const unsigned lane16 = (unsigned)lane << 4;
+    const unsigned voff = (unsigned)(lane >> 2) * (unsigned)p.ldvt * 2u + ((unsigned)((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto stage_k = [&](int t, int soff, int i) {   // i in [0, LPT); K tile t -> smem + soff
         const int row = i * NW + wave;
         int kr = t * KT + row;
-        kr = kr < p.Tk ? kr : p.Tk - 1;   // ragged last tile: re-read the last valid key (masked in the softmax)
-        glds16(Kb + (size_t)kr * p.ldk * 2 + ((lane ^ (row & 15)) << 4), smem + soff + row * 1024);
+        kr = kr < p.Tk ? kr : p.Tk - 1;   // ragged last tile / tiles past the end: re-read the last valid key (masked or unused)
+        const char* base = Kb + (size_t)kr * p.ldk * 2;
+        glds16(base + (lane16 ^ ((unsigned)(row & 15) << 4)), smem + soff + row * 1024);
     };
-    auto stage_v = [&](int t, int soff, int i) {
+    auto stage_v = [&](int t, int soff, int i) {   // rows 16 ins .. 16 ins + 15 of V^T; (row >> 2) & 3 == (lane >> 4) & 3 for all of them
         const int ins = i * NW + wave;
-        const int row = ins * 16 + (lane >> 2);
-        const int ch = (lane & 3) ^ ((row >> 2) & 3);
-        glds16(Vb + (size_t)row * p.ldvt * 2 + (size_t)t * (KT * 2) + (ch << 4), smem + soff + 32768 + ins * 1024);
+        const char* base = Vb + (size_t)ins * 16 * p.ldvt * 2 + (size_t)t * (KT * 2);
+        glds16(base + voff, smem + soff + 32768 + ins * 1024);
     };
 
     // ---- LDS fragment addresses (bytes inside a stage)
@@ -91,33 +96,39 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     const int vx = ((l31 >> 2) & 3) ^ half;  // chunk 2*j + half of V^T row d lives at position (2*j) ^ vx
     const int vbase = 32768 + l31 * 64;
 
-    f32x16 o[16], nm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) nm[r] = 0.f;
+    f32x16 o[16];
+    float nm = 0.f;   // -m of this lane's query (raw score units), set by pass 1
 #pragma unroll
     for (int db = 0; db < 16; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float l_run = 0.f;
 
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) stage_k(0, 0, i);
     // Q fragments as stored.  The softmax scale is applied to the fp32 scores inside the exponential (16 multiplies per key tile
     // against 64 MFMAs): folding it into Q as attention.hip does costs one more 16-bit rounding of Q, which at T = 16 384 keys
     // and logits of a few nats was the largest error term of the kernel (measured 4.1e-3 rel-L2 against fp32 SDPA).
     bf16x8 qf[32];
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) qf[ks] = *(const bf16x8*)(Qp + 16 * ks);
+    // pass-1 prologue: the 128 KB of LDS are a FOUR-deep ring of K tiles here (no V^T yet): tiles 0..2 in flight
+    constexpr int K_SLOT = 32768;
+#pragma unroll
+    for (int t0 = 0; t0 < 3; ++t0)
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) stage_k(t0, t0 * K_SLOT, i);
 
     const int klast = p.Tk - 1;
-    // S^T = K.Q^T + c0 for the tile in stage `sb`, keys past the end -> -inf.  Eight groups of four k steps: the fragments of
+    // S^T = K.Q^T + c0 (c0 = -m of this lane's query, or 0) for the tile in stage `sb`, keys past the end -> -inf.  Eight groups of four k steps: the fragments of
     // group g+1 are read before the MFMAs of group g are issued (explicit double buffer: left to itself the compiler reads,
     // waits and multiplies one fragment at a time through a single register quad), two independent accumulator chains, and
-    // `between(g)` -- the loader's global_load_lds for the NEXT tile -- spread one call per group instead of clumped.
-    auto scores = [&](const char* sb, const f32x16& c0, int t, auto&& between) {
-        f32x16 s0 = c0, s1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+    // `between(g)` -- where the caller issues the loader's global_load_lds for a LATER tile -- called once per group.
+    auto scores = [&](const char* sb, float c0, int t, auto&& between) {
+        // Both chains start from the instruction's inline-constant 0 and "- m" is added afterwards (16 VALU adds per tile).  As the
+        // C operand of the first MFMA -- attention.hip's trick -- the 16-register splat of m is loop invariant, gets hoisted, does not
+        // fit next to 256 accumulators + 128 Q registers and comes back as a per-tile SCRATCH reload, whose vmcnt(0) then also
+        // waits for the LDS-DMA loads issued just before it.
+        f32x16 s0, s1;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         bf16x8 kf[2][4];
         auto ldk = [&](bf16x8 (&k4)[4], int g) {
 #pragma unroll
@@ -132,15 +143,15 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
         for (int g = 0; g < 8; ++g) {
             if (g + 1 < 8) ldk(kf[(g + 1) & 1], g + 1);
             between(g);
-            s0 = SUPIR_MFMA_32x32x16(kf[g & 1][0], qf[4 * g + 0], s0, 0, 0, 0);
-            s1 = SUPIR_MFMA_32x32x16(kf[g & 1][1], qf[4 * g + 1], s1, 0, 0, 0);
+            s0 = SUPIR_MFMA_32x32x16(kf[g & 1][0], qf[4 * g + 0], g == 0 ? zero : s0, 0, 0, 0);
+            s1 = SUPIR_MFMA_32x32x16(kf[g & 1][1], qf[4 * g + 1], g == 0 ? zero : s1, 0, 0, 0);
             s0 = SUPIR_MFMA_32x32x16(kf[g & 1][2], qf[4 * g + 2], s0, 0, 0, 0);
             s1 = SUPIR_MFMA_32x32x16(kf[g & 1][3], qf[4 * g + 3], s1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x16 s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = s0[r] + s1[r];
+        for (int r = 0; r < 16; ++r) s[r] = (s0[r] + s1[r]) + c0;
         if (t == nt - 1) {   // the only tile that can hold keys past the end
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -157,24 +168,25 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     {
         float mx = -INFINITY;
         for (int t = 0; t < nt; ++t) {
-            d512_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
+            // loads complete in issue order: all but the two newest tiles' have landed, i.e. Q and tile t.  The first version
+            // of this kernel issued a tile's loads DURING the previous tile and then waited for vmcnt(0): the full L2 latency
+            // sat on the critical path of every tile (measured 10.6 k cycles per tile against 3 k of MFMA work).
+            d512_wait_vmcnt<2 * LPT>();
+            __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done with tile t-1, whose slot takes tile t+3
             asm volatile("" ::: "memory");
-            const int noff = ((t + 1) & 1) * STAGE_BYTES;
-            const bool more = t + 1 < nt;
-            const f32x16 s = scores(smem + (t & 1) * STAGE_BYTES, nm, t, [&](int g) {
-                if (more) {
+            const int nslot = ((t + 3) & 3) * K_SLOT;
+            const f32x16 s = scores(smem + (t & 3) * K_SLOT, nm, t, [&](int g) {
+                if (g < 4) {   // past the end the loader re-reads the last tile into a slot nobody reads: the count stays uniform
 #pragma unroll
-                    for (int i = g * LPT / 8; i < (g + 1) * LPT / 8; ++i) stage_k(t + 1, noff, i);
+                    for (int i = g * LPT / 4; i < (g + 1) * LPT / 4; ++i) stage_k(t + 3, nslot, i);
                 }
             });
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
         }
-        mx = d512_xhalf_max(mx);   // finite: key 0 is visible to every query
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nm[r] = -mx;
+        nm = -d512_xhalf_max(mx);   // finite: key 0 is visible to every query
     }
+    d512_wait_vmcnt<0>();           // the ring's trailing (unused) loads still target this workgroup's LDS
     __builtin_amdgcn_s_barrier();   // every wave is done with the last K tile before stage 0 is refilled
     asm volatile("" ::: "memory");
 
@@ -191,10 +203,16 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
         const char* sb = smem + (t & 1) * STAGE_BYTES;
         const int noff = ((t + 1) & 1) * STAGE_BYTES;
         const bool more = t + 1 < nt;
+        // tile t+1: all 2 * LPT loads on the first four score groups, so that they have the rest of this tile to land
         const f32x16 s = scores(sb, nm, t, [&](int g) {
-            if (more) {
+            if (more && g < 4) {
 #pragma unroll
-                for (int i = g * LPT / 8; i < (g + 1) * LPT / 8; ++i) stage_k(t + 1, noff, i);
+                for (int i = (g & 1) * LPT / 2; i < ((g & 1) + 1) * LPT / 2; ++i) {
+                    if (g < 2)
+                        stage_k(t + 1, noff, i);
+                    else
+                        stage_v(t + 1, noff, i);
+                }
             }
         });
         // V^T fragments of the first pair of channel blocks are requested before the exponentials
@@ -219,10 +237,6 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             if (g + 1 < 8) ldv(va[(g + 1) & 1], g + 1);
-            if (more) {
-#pragma unroll
-                for (int i = g * LPT / 8; i < (g + 1) * LPT / 8; ++i) stage_v(t + 1, noff, i);
-            }
             o[2 * g] = SUPIR_MFMA_32x32x16(va[g & 1][0], pf[0], o[2 * g], 0, 0, 0);
             o[2 * g + 1] = SUPIR_MFMA_32x32x16(va[g & 1][2], pf[0], o[2 * g + 1], 0, 0, 0);
             o[2 * g] = SUPIR_MFMA_32x32x16(va[g & 1][1], pf[1], o[2 * g], 0, 0, 0);

@@ -100,10 +100,12 @@ class DiscreteDenoiserWithControl(nn.Module):
         (denoiser.py:49-73, denoiser_scaling.py:16-22).  None when the configuration is not the one SUPIR ships."""
         if not (isinstance(self.scaling, EpsScaling) and self.quantize_c_noise):
             return None
-        tab = self.__dict__.get("_host_table")
-        if tab is None:
-            tab = self.sigmas.detach().float().cpu().numpy().astype(np.float32)
-            self.__dict__["_host_table"] = tab
+        key = (self.sigmas.data_ptr(), self.sigmas._version, self.sigmas.device)   # `denoiser.sigmas` is a checkpoint key
+        cached = self.__dict__.get("_host_table")
+        if cached is None or cached[0] != key:
+            cached = (key, self.sigmas.detach().float().cpu().numpy().astype(np.float32))
+            self.__dict__["_host_table"] = cached
+        tab = cached[1]
         idx = int(np.argmin(np.abs(np.float32(sigma32) - tab)))
         sq = np.float32(tab[idx])
         c_in = np.float32(1.0) / np.sqrt(sq * sq + np.float32(1.0), dtype=np.float32)

@@ -644,19 +644,19 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     return out
 
 
-# VAE mid-block attention (one head, dim 512): supir_flash_attn_d512 never forms the score matrix but, measured at T = 16 384
-# (1024^2 px), runs at 242 TFLOP/s = 2.27 ms against 1.54 ms for the materialised form (GEMM -> fp32 scores -> softmax_rows -> GEMM;
-# profiles/r02/attn_d512_timing.json): with 288 GB of HBM the 1.5 GB of temporaries are cheap, so the flash kernel takes over only
-# where they stop being so -- "auto": when the fp32 score matrix of ONE batch element would exceed FLASH_D512_AUTO_BYTES (8 GiB:
-# T > 46 340 tokens, i.e. an untiled image beyond ~1720^2 px).  SUPIR_FLASH_D512 = 1 / 0 forces it on / off.
+# VAE mid-block attention (one head, dim 512): supir_flash_attn_d512 never forms the score matrix; the materialised form (GEMM -> fp32
+# scores [T, T] -> softmax_rows -> GEMM) moves ~3 GB per call at T = 16 384 but runs on the tuned GEMM tiles.  The flash kernel takes
+# over from FLASH_D512_MIN_TOKENS tokens per batch element upwards (env SUPIR_FLASH_D512_MIN_TOKENS; the default is where one
+# element's fp32 score matrix reaches 8 GiB -- an untiled image beyond ~1720^2 px -- unless a measurement moved it);
+# SUPIR_FLASH_D512 = 1 / 0 forces it on / off for every size.
 USE_FLASH_D512 = {"1": True, "0": False}.get(_os.environ.get("SUPIR_FLASH_D512", "auto"), "auto")
-FLASH_D512_AUTO_BYTES = 8 << 30
+FLASH_D512_MIN_TOKENS = int(_os.environ.get("SUPIR_FLASH_D512_MIN_TOKENS", "46341"))
 
 
 def use_flash_d512(T):
     """Whether the head-dim-512 attention over T tokens takes the flash kernel (see USE_FLASH_D512)."""
     if USE_FLASH_D512 == "auto":
-        return 4 * T * ((T + 63) // 64 * 64) > FLASH_D512_AUTO_BYTES
+        return T >= FLASH_D512_MIN_TOKENS
     return bool(USE_FLASH_D512)
 
 

@@ -101,11 +101,8 @@ def test_vae_attnblock_flash_matches_materialised(monkeypatch):
 
 
 def test_flash_attn_d512_timing_report():
-    """Not a pass / fail test of speed: prints the launch time at the production size next to the materialised path's."""
-    B, T = 1, 16384
-    q, k, v = rnd(B, T, 512).to(BF), rnd(B, T, 512, seed=1).to(BF), rnd(B, T, 512, seed=2).to(BF)
-    vt = _vt(v, T)
-
+    """Not a pass / fail test of speed: prints the launch time at the production sizes (T = 16 384: 1024^2 px, T = 4096: 512^2 px)
+    next to the materialised path's and leaves both in gpurun_out/attn_d512_timing.json (what ops.FLASH_D512_MIN_TOKENS is set from)."""
     def timed(fn, n=5):
         for _ in range(2):
             fn()
@@ -117,21 +114,25 @@ def test_flash_attn_d512_timing_report():
         e1.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
 
-    t_flash = timed(lambda: ops.flash_attn_d512(q, k, vt, T))
+    res = {}
+    for T in (16384, 4096):
+        q, k, v = rnd(1, T, 512).to(BF), rnd(1, T, 512, seed=1).to(BF), rnd(1, T, 512, seed=2).to(BF)
+        vt = _vt(v, T)
+        t_flash = timed(lambda: ops.flash_attn_d512(q, k, vt, T))
 
-    def materialised():
-        s = ops.gemm(q[0], k[0], out_dtype=torch.float32)
-        p = ops.softmax_rows(s, 512 ** -0.5, valid=T)
-        return ops.gemm(p, vt[0])
+        def materialised():
+            s = ops.gemm(q[0], k[0], out_dtype=torch.float32)
+            p = ops.softmax_rows(s, 512 ** -0.5, valid=T)
+            return ops.gemm(p, vt[0])
 
-    t_mat = timed(materialised)
-    fl = 4.0 * T * T * 512
-    print(f"[d512] T={T}: flash {t_flash:.0f} us = {fl / t_flash / 1e6:.0f} TFLOP/s; materialised scores {t_mat:.0f} us")
+        t_mat = timed(materialised)
+        fl = 4.0 * T * T * 512
+        print(f"[d512] T={T}: flash {t_flash:.0f} us = {fl / t_flash / 1e6:.0f} TFLOP/s; materialised scores {t_mat:.0f} us")
+        res[f"T{T}"] = {"flash_us": t_flash, "flash_tflops": fl / t_flash / 1e6, "materialised_us": t_mat}
     try:
         import json
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        json.dump({"T": T, "flash_us": t_flash, "flash_tflops": fl / t_flash / 1e6, "materialised_us": t_mat},
-                  open(os.path.join(out, "attn_d512_timing.json"), "w"))
+        json.dump(res, open(os.path.join(out, "attn_d512_timing.json"), "w"), indent=1)
     except OSError:
         pass

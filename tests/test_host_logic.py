@@ -527,13 +527,15 @@ def test_graph_capture_mode_follows_torch_distributed(monkeypatch):
 
 
 def test_flash_d512_policy(monkeypatch):
-    """VAE mid-block attention: the flash kernel (no score matrix) is slower than the materialised form at BASELINE sizes
-    (measured), so "auto" switches to it only when one batch element's fp32 score matrix would exceed 8 GiB; 1 / 0 force it."""
+    """VAE mid-block attention: "auto" hands sizes from FLASH_D512_MIN_TOKENS tokens upwards to the flash kernel (no score matrix);
+    SUPIR_FLASH_D512 = 1 / 0 force it for every size."""
     from supir_amd import ops
     monkeypatch.setattr(ops, "USE_FLASH_D512", "auto")
+    monkeypatch.setattr(ops, "FLASH_D512_MIN_TOKENS", 46341)                   # the 8 GiB-of-scores default
     assert not ops.use_flash_d512(16384) and not ops.use_flash_d512(4096)      # 1024^2 / 512^2 px: 1 GiB / 64 MiB of scores
-    assert not ops.use_flash_d512(46336) and ops.use_flash_d512(46400)         # the 8 GiB boundary
-    assert ops.use_flash_d512(65536)                                           # 2048^2 px untiled: 16 GiB of scores
+    assert not ops.use_flash_d512(46340) and ops.use_flash_d512(46341) and ops.use_flash_d512(65536)
+    monkeypatch.setattr(ops, "FLASH_D512_MIN_TOKENS", 8192)
+    assert ops.use_flash_d512(16384) and not ops.use_flash_d512(4096)
     monkeypatch.setattr(ops, "USE_FLASH_D512", True)
     assert ops.use_flash_d512(64)
     monkeypatch.setattr(ops, "USE_FLASH_D512", False)

@@ -22,6 +22,10 @@ ap.add_argument("--skip-tiled", action="store_true")
 ap.add_argument("--only-tiled", action="store_true")
 ap.add_argument("--tiled-res", type=int, default=4096)
 ap.add_argument("--tiled-single", action="store_true", help="time ONE tiled call (a warm-up at 2 steps first): for 50-step runs")
+ap.add_argument("--only-config5", action="store_true", help="config 5 alone (DPM++ 2M, 8 and 4 steps)")
+ap.add_argument("--fp16", action="store_true",
+                help="config 5 with diff_dtype fp16 -- the reference YAML's own setting (options/SUPIR_v0_Juggernautv9_lightning.yaml:5): "
+                     "the fp16 build of the kernels (libsupir_hip_f16.so) instead of bf16")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 
@@ -60,15 +64,22 @@ def run(model, P, steps, reps=1, **kw):
 
 res = {}
 m = build("RestoreEDMSampler")
+if args.only_config5:
+    args.skip_tiled = True
 if not args.only_tiled:
-    s, ok, shp = run(m, 512, 2, reps=3)
-    res["config1_512px_2steps"] = {"s_per_image": s, "finite": ok, "shape": shp}
-    print(res, flush=True)
+    if not args.only_config5:
+        s, ok, shp = run(m, 512, 2, reps=3)
+        res["config1_512px_2steps"] = {"s_per_image": s, "finite": ok, "shape": shp}
+        print(res, flush=True)
+    if args.fp16:
+        m.model.dtype = torch.float16
+        assert m.model.effective_dtype == torch.float16, "SUPIR_FP16_NATIVE=0?"
     m.sampler_config["target"] = "sgm.modules.diffusionmodules.sampling.RestoreDPMPP2MSampler"
     m.sampler_config["params"]["eta"] = 1.0
     for steps in (8, 4):
         s, ok, shp = run(m, 1024, steps, reps=2, cfg_scale=2.0, cfg_scale_start=2.0)
-        res[f"config5_1024px_dpmpp2m_{steps}steps"] = {"s_per_image": s, "images_per_s": 1 / s, "finite": ok}
+        res[f"config5_1024px_dpmpp2m_{steps}steps"] = {"s_per_image": s, "images_per_s": 1 / s, "finite": ok,
+                                                       "diff_dtype": "fp16" if args.fp16 else "bf16"}
         print(res, flush=True)
 if not args.skip_tiled:
     m.sampler_config["target"] = "sgm.modules.diffusionmodules.sampling.TiledRestoreEDMSampler"
@@ -94,4 +105,4 @@ if not args.skip_tiled:
                                    "note": "49 latent tiles x steps network calls + tiled VAE (64 tiles) x 4; extrapolate sampler linearly to 50 steps"}
     print(res, flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open("gpurun_out/configs.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/configs_fp16.json" if args.fp16 else "gpurun_out/configs.json", "w"), indent=1)
