@@ -247,6 +247,9 @@ def main():
                     help="images batched into one batchify_sample call per rank (test.py runs 1; >1 raises M of every GEMM)")
     ap.add_argument("--extra-batch", type=int, default=4,
                     help="after the timed region also report throughput with this many images per call (0 = skip)")
+    ap.add_argument("--diff-dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="element type of the UNet + control kernels: bf16 = BASELINE configs[1] (the metric); fp16 = the reference's "
+                         "default diff_dtype, on the fp16 build of the kernels (reported in `dtype`, never the headline line)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -268,6 +271,9 @@ def main():
     from supir_amd.synth import synth_tensor
 
     model, t_fill, t_bcast = build_model(device, rank, world)
+    if args.diff_dtype == "fp16":
+        model.model.dtype = torch.float16
+        assert model.model.effective_dtype == torch.float16, "fp16 requested but SUPIR_FP16_NATIVE=0"
     model.model.enable_graph(not args.no_graph)
     P = args.res
     def make_inputs(n):
@@ -439,10 +445,10 @@ def main():
         line = {
             "metric": "1024px 50-step EDM denoise images/sec", "value": n_img / dt, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.diff_dtype, "data": "synthetic",
             "config": {"workload": ("configs[1]" if world == 1 else f"configs[1] on each of {world} ranks (BASELINE configs[3] shape: "
                                     f"independent images, one per GPU)") + f": {world}xMI355X {P}x{P}, {args.edm_steps} EDM steps (RestoreEDMSampler, s_churn 5, "
-                                   f"linear CFG 1.0->4.0), bf16 MFMA UNet+GLVControl+VAE, SUPIR-v0 config, 1 image per GPU per step, "
+                                   f"linear CFG 1.0->4.0), {args.diff_dtype} MFMA UNet+GLVControl, bf16 VAE, SUPIR-v0 config, 1 image per GPU per step, "
                                    f"random-init weights", "edm_steps": args.edm_steps, "resolution": P,
                        "images_per_gpu_per_step": ipg, "parallelism": f"dp{world} (replicated weights, no collective inside a sample)",
                        "hip_graph": not args.no_graph,
