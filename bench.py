@@ -259,11 +259,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world > 1:   # before the first HIP call of the process: the HSA runtime reads it when it initialises
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" == RCCL on ROCm
 
     from supir_amd import _lib
