@@ -87,7 +87,10 @@ def test_sampler_fused_step_vs_generic_step_with_the_real_network(monkeypatch):
             worst = max(worst, rel_l2(b, a))
             x = a
         print(f"[fused step] teacher-forced worst rel-L2 over {n - 1} steps: {worst:.3e}")
-        assert worst <= 2e-3, worst
+        # measured 1.8e-3 (profiles/r02/pytest_fp16_fused_step_config1.log): the two paths differ by fp32 ulps (fma contraction) in
+        # the network INPUT, and the bf16 network turns those into a handful of flipped roundings; how many depends on the tiles
+        # the autotuner picked on this box.  A wrong factor anywhere in the step shows up at >= 1e-2, so the bar sits between.
+        assert worst <= 6e-3, worst
         outs = []
         for fused in (False, True):
             monkeypatch.setattr(sampling, "FUSED_EDM_STEP", fused)
