@@ -93,13 +93,18 @@ def kernel_profile(model, latent, device):
         if k in ("gemm", "gemm_t", "conv3x3"):
             shape = f"M{r['M']} N{r['N']} K{r['K']}" + (" geglu" if r.get("act", 0) == 2 else "")
             k = ops.gemm_tile_name(r["M"], r["N"], r.get("act", 0), conv=(k == "conv3x3"), trans=(k == "gemm_t"),
-                                   tile=r.get("tile", -1))
+                                   tile=r.get("tile", -1), group=r.get("group", 1))
         elif k == "attn":
             shape = f"B{r['B']} H{r['H']} Tq{r['Tq']} Tk{r['Tk']}"
         elif k == "groupnorm":
             shape = f"B{r['B']} HW{r['HW']} C{r['C']}"
         if r["kernel"] == "groupnorm" and r.get("parts"):
             k = "groupnorm(statistics from the producer)"   # one launch; the others are a statistics + an apply launch
+        if r.get("group", 1) == 2:
+            # one grouped launch = the same layer of GLVControl and of the UNet encoder (flops / bytes in the record are both problems')
+            if r["kernel"] in ("attn", "groupnorm"):
+                k += " x2"
+            shape = (shape or "") + " x2"
         for d, key in ((agg, k), (by_shape, (k, shape))):
             a = d.setdefault(key, dict(launches=0, us=0.0, flops=0.0, bytes=0.0))
             a["launches"] += 1

@@ -252,6 +252,80 @@ int supir_prefetch(const void* p, size_t bytes, void* sink, void* stream);
  * No reference counterpart (the reference's cuBLAS / cuDNN calls meet every weight cold each step as well). */
 int supir_set_next_prefetch(const void* p, size_t bytes);
 
+/* ---- Grouped launches: n (1 or 2) independent problems of identical shape in ONE kernel launch ------------------------------------
+ * SUPIR runs two networks of identical architecture on independent data inside every sampling step: GLVControl (the control
+ * branch, SUPIR/modules/SUPIR_v0.py:499-540) and the encoder half of LightGLVUNet (:600-625) -- the same ResBlock /
+ * SpatialTransformer stack, layer for layer the same shapes, different weights and inputs.  With the CFG-doubled batch of one
+ * 1024^2 image each layer is M = 2048 tokens: half a machine of tiles large enough to be fed from L2.  A grouped launch runs the
+ * two layers as one grid (problem q on XCDs [4 q, 4 q + 4), its operands in those four L2s); the host mirror records both
+ * branches and issues the pairs (supir_amd/ops.py paired_run).  Arguments that fix the grid (`shape`) are shared; pointers,
+ * strides and optional operands are per problem.  n = 1 is exactly the corresponding single entry point.  Per problem the
+ * explicit `prefetch` / `gn_partials_out` fields replace the one-shot supir_set_next_* requests (which these calls ignore).
+ * The structs are HOST memory, read during the call only. */
+typedef struct supir_gemm_problem {
+    const void* A;            /* [M][lda] bf16 (conv: NHWC input [B][H][W][lda]) */
+    const void* W;            /* [N][K] bf16 */
+    void* C;                  /* bf16 [M][ldc] (out_mode 2: [batch][N][ldc]); fused q|k|v: the q|k part [M][ldc] */
+    void* C2;                 /* fused q|k|v only: V^T [batch][N - n_split][ldc2] */
+    const float* bias;        /* [N] or NULL */
+    const void* rowbias;      /* bf16 [batch][ld_rowbias] or NULL */
+    const void* residual;     /* bf16 [M][ldr] or NULL */
+    float* rowstats_out;      /* LayerNorm-fold producer output or NULL (see supir_gemm_bf16_ln) */
+    const float* ln_stats;    /* LayerNorm-fold consumer input or NULL */
+    const float* ln_colsum;
+    float* gn_partials_out;   /* GroupNorm unit partials or NULL (see supir_set_next_gn_partials) */
+    const void* prefetch;     /* weight matrix of a later launch to touch on the way out, or NULL (see supir_set_next_prefetch) */
+    size_t prefetch_bytes;
+    int lda, ldc, ldc2, ldr, ld_rowbias, rs_ld, ln_ld, ln_slots;
+} supir_gemm_problem;
+
+#define SUPIR_GROUP_GEMM 0    /* supir_gemm_bf16 / supir_gemm_bf16_ln */
+#define SUPIR_GROUP_CONV3X3 1 /* supir_conv3x3_bf16 (M = B*OH*OW, N = Cout, K = 9*Cin are derived) */
+#define SUPIR_GROUP_QKV 2     /* supir_gemm_bf16_qkv */
+
+typedef struct supir_gemm_shape {
+    int kind;                 /* SUPIR_GROUP_* */
+    int tile;                 /* 33, 34, 35 (csrc/gemm16.hip) or 37 (csrc/gemm_big.hip, GEGLU); ignored for SUPIR_GROUP_QKV */
+    int M, N, K;              /* GEMM / q|k|v */
+    int rows_per_batch, act, out_mode, n_split;
+    float alpha, ln_eps;
+    int B, H, W, Cin, Cout, OH, OW, stride, pad_t, pad_l, upsample;   /* conv3x3 */
+} supir_gemm_shape;
+
+/* Only the exact-fit tiles have a grouped form; a shape / tile they do not cover returns SUPIR_ERR_SHAPE and the caller issues the
+ * problems one by one. */
+int supir_gemm_grouped(const supir_gemm_shape* shape, const supir_gemm_problem* problems, int n, void* stream);
+
+typedef struct supir_attn_problem {
+    const void* Q;
+    const void* K;
+    const void* Vt;
+    void* O;
+    int Tk, ldq, ldk, ldvt, ldo, flags;   /* flags as in supir_flash_attn_d64_ex */
+} supir_attn_problem;
+/* supir_flash_attn_d64(_ex) for n problems sharing (B, H, Tq, scale); the key count, strides and flags are per problem. */
+int supir_flash_attn_d64_grouped(const supir_attn_problem* problems, int n, int B, int H, int Tq, float scale, void* stream);
+
+typedef struct supir_gn_problem {
+    const void* x1;
+    const void* x2;
+    const void* x1raw;
+    const void* x2raw;
+    const float* gamma;
+    const float* beta;
+    const void* mod_g;
+    const void* mod_b;
+    void* out;
+    const float* part1;       /* producer partials (supir_groupnorm_nhwc_parts) or NULL -> own statistics through `workspace` */
+    const float* part2;
+    float* workspace;         /* >= B*1024*64 floats when part1 == NULL */
+    int C1, ld1, ld2, ldm, ldo, nchunk1, nchunk2;
+    float control_scale;
+} supir_gn_problem;
+/* supir_groupnorm_nhwc / supir_groupnorm_nhwc_parts for n problems sharing (B, HW, C, eps, act); every problem must take its
+ * statistics the same way (all from producer partials, or all from their own statistics pass). */
+int supir_groupnorm_grouped(const supir_gn_problem* problems, int n, int B, int HW, int C, float eps, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,38 @@ SIGNATURES = {
     "supir_gemm_bf16_ln": [P, P, P, I, I, I, I, I, P, P, I, I, I, I, F, I, P, I, P, I, I, P, F, P],
 }
 
+
+
+# ---- grouped launches (include/supir_hip.h, "Grouped launches"): host-side structs, field for field
+class GemmProblem(ctypes.Structure):
+    _fields_ = [("A", P), ("W", P), ("C", P), ("C2", P), ("bias", P), ("rowbias", P), ("residual", P), ("rowstats_out", P),
+                ("ln_stats", P), ("ln_colsum", P), ("gn_partials_out", P), ("prefetch", P), ("prefetch_bytes", c_size_t),
+                ("lda", I), ("ldc", I), ("ldc2", I), ("ldr", I), ("ld_rowbias", I), ("rs_ld", I), ("ln_ld", I), ("ln_slots", I)]
+
+
+class GemmShape(ctypes.Structure):
+    _fields_ = [("kind", I), ("tile", I), ("M", I), ("N", I), ("K", I), ("rows_per_batch", I), ("act", I), ("out_mode", I),
+                ("n_split", I), ("alpha", F), ("ln_eps", F), ("B", I), ("H", I), ("W", I), ("Cin", I), ("Cout", I), ("OH", I),
+                ("OW", I), ("stride", I), ("pad_t", I), ("pad_l", I), ("upsample", I)]
+
+
+class AttnProblem(ctypes.Structure):
+    _fields_ = [("Q", P), ("K", P), ("Vt", P), ("O", P), ("Tk", I), ("ldq", I), ("ldk", I), ("ldvt", I), ("ldo", I), ("flags", I)]
+
+
+class GnProblem(ctypes.Structure):
+    _fields_ = [("x1", P), ("x2", P), ("x1raw", P), ("x2raw", P), ("gamma", P), ("beta", P), ("mod_g", P), ("mod_b", P), ("out", P),
+                ("part1", P), ("part2", P), ("workspace", P), ("C1", I), ("ld1", I), ("ld2", I), ("ldm", I), ("ldo", I),
+                ("nchunk1", I), ("nchunk2", I), ("control_scale", F)]
+
+
+GROUP_GEMM, GROUP_CONV3X3, GROUP_QKV = 0, 1, 2
+SIGNATURES.update({
+    "supir_gemm_grouped": [P, P, I, P],
+    "supir_flash_attn_d64_grouped": [P, I, I, I, I, F, P],
+    "supir_groupnorm_grouped": [P, I, I, I, I, F, I, P],
+})
+
 _lib = None       # the bf16 library (the product default)
 _lib_f16 = None   # the fp16 build, loaded on first use
 

@@ -276,4 +276,97 @@ int supir_edm_step_post(const float* net_out, const float* x_hat, const float* x
                                  (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------------- grouped launches
+static void pack_common(GemmArgs& a, const supir_gemm_shape& sh, const supir_gemm_problem& q) {
+    a.A = (const bf16_t*)q.A; a.Wt = (const bf16_t*)q.W; a.C = q.C; a.C2 = q.C2;
+    a.bias = q.bias; a.rowbias = (const bf16_t*)q.rowbias; a.res = (const bf16_t*)q.residual;
+    a.lda = q.lda; a.ldc = q.ldc; a.ldc2 = q.ldc2; a.ldr = q.ldr; a.ld_rb = q.ld_rowbias;
+    a.act = sh.act; a.out_mode = sh.out_mode; a.alpha = sh.alpha; a.n_split = sh.n_split;
+    a.rowstats_out = q.rowstats_out; a.rs_ld = q.rs_ld;
+    a.ln_stats = q.ln_stats; a.ln_ld = q.ln_ld; a.ln_slots = q.ln_slots; a.ln_colsum = q.ln_colsum; a.ln_eps = sh.ln_eps;
+    a.gn_part_out = q.gn_partials_out;
+    const size_t lines = q.prefetch ? q.prefetch_bytes / 128 : 0;
+    a.pf_ptr = (const char*)q.prefetch;
+    a.pf_lines = lines > 0x7fffffffu ? 0x7fffffffu : (unsigned)lines;
+}
+
+int supir_gemm_grouped(const supir_gemm_shape* shape, const supir_gemm_problem* problems, int n, void* stream) {
+    if (!shape || !problems || n < 1 || n > 2) return SUPIR_ERR_ARG;
+    const supir_gemm_shape& sh = *shape;
+    if (sh.kind < 0 || sh.kind > 2 || sh.act < 0 || sh.act > 4 || sh.out_mode < 0 || sh.out_mode > 2) return SUPIR_ERR_ARG;
+    GemmArgs a[2] = {};
+    for (int i = 0; i < n; ++i) {
+        const supir_gemm_problem& q = problems[i];
+        if (!q.A || !q.W || !q.C) return SUPIR_ERR_ARG;
+        if (q.ln_stats && (!q.ln_colsum || q.ln_slots < 0 || (q.ln_slots > 0 && (q.ln_ld < q.ln_slots || (q.ln_ld & 1))))) return SUPIR_ERR_ARG;
+        if (q.prefetch_bytes && !q.prefetch) return SUPIR_ERR_ARG;
+        pack_common(a[i], sh, q);
+        if (sh.kind == SUPIR_GROUP_CONV3X3) {
+            if (sh.B <= 0 || sh.H <= 0 || sh.W <= 0 || sh.OH <= 0 || sh.OW <= 0 || sh.act > 1 || sh.out_mode != 0) return SUPIR_ERR_ARG;
+            if ((sh.stride != 1 && sh.stride != 2) || (sh.upsample && sh.stride != 1)) return SUPIR_ERR_SHAPE;
+            a[i].M = sh.B * sh.OH * sh.OW; a[i].N = sh.Cout; a[i].K = 9 * sh.Cin;
+            a[i].rows_per_batch = sh.OH * sh.OW;
+            a[i].H = sh.H; a[i].W = sh.W; a[i].Cin = sh.Cin; a[i].OH = sh.OH; a[i].OW = sh.OW; a[i].stride = sh.stride;
+            a[i].pad_t = sh.pad_t; a[i].pad_l = sh.pad_l; a[i].up = sh.upsample ? 1 : 0;
+        } else {
+            a[i].M = sh.M; a[i].N = sh.N; a[i].K = sh.K;
+            if ((q.rowbias || sh.out_mode == 2 || sh.kind == SUPIR_GROUP_QKV) && sh.rows_per_batch <= 0) return SUPIR_ERR_ARG;
+            a[i].rows_per_batch = sh.rows_per_batch > 0 ? sh.rows_per_batch : sh.M;
+            if (q.rowstats_out && (sh.out_mode != 0 || sh.act == 2 || q.rs_ld <= 0 || (q.rs_ld & 1))) return SUPIR_ERR_ARG;
+        }
+        if (a[i].M <= 0 || a[i].N <= 0 || a[i].K <= 0) return SUPIR_ERR_ARG;
+    }
+    if (sh.kind == SUPIR_GROUP_QKV) {
+        for (int i = 0; i < n; ++i)
+            if (!a[i].C2) return SUPIR_ERR_ARG;
+        return supir_gemm16_qkv_launch_n(a, n, (hipStream_t)stream);
+    }
+    if (sh.tile == 37) {
+        if (sh.kind != SUPIR_GROUP_GEMM) return SUPIR_ERR_SHAPE;
+        for (int i = 0; i < n; ++i)
+            if (a[i].gn_part_out) return SUPIR_ERR_SHAPE;
+        return supir_gemm_big_launch_n(a, n, (hipStream_t)stream);
+    }
+    if (sh.tile < 32 || sh.tile > 35) return SUPIR_ERR_SHAPE;
+    for (int i = 0; i < n; ++i) {
+        if (a[i].rowstats_out) {   // the producer's slot index is the tile column: the caller's rs_ld must cover the tile used
+            const int bn = (sh.tile == 32 || sh.tile == 35) ? 80 : 160;
+            if ((a[i].N + bn - 1) / bn > a[i].rs_ld) return SUPIR_ERR_ARG;
+        }
+    }
+    return supir_gemm16_launch_n(a, n, (hipStream_t)stream, sh.tile, sh.kind == SUPIR_GROUP_CONV3X3);
+}
+
+int supir_flash_attn_d64_grouped(const supir_attn_problem* problems, int n, int B, int H, int Tq, float scale, void* stream) {
+    if (!problems || n < 1 || n > 2) return SUPIR_ERR_ARG;
+    AttnArgs a[2] = {};
+    for (int i = 0; i < n; ++i) {
+        const supir_attn_problem& q = problems[i];
+        if (!q.Q || !q.K || !q.Vt || !q.O || (q.flags & ~1)) return SUPIR_ERR_ARG;
+        if ((q.flags & 1) && Tq != q.Tk) return SUPIR_ERR_SHAPE;
+        a[i].Q = (const bf16_t*)q.Q; a[i].K = (const bf16_t*)q.K; a[i].Vt = (const bf16_t*)q.Vt; a[i].O = (bf16_t*)q.O;
+        a[i].B = B; a[i].H = H; a[i].Tq = Tq; a[i].Tk = q.Tk; a[i].ldq = q.ldq; a[i].ldk = q.ldk; a[i].ldvt = q.ldvt; a[i].ldo = q.ldo;
+        a[i].scale_log2e = scale * 1.4426950408889634f;
+        a[i].causal = q.flags & 1;
+    }
+    return supir_attn_launch_n(a, n, (hipStream_t)stream);
+}
+
+int supir_groupnorm_grouped(const supir_gn_problem* problems, int n, int B, int HW, int C, float eps, int act, void* stream) {
+    if (!problems || n < 1 || n > 2) return SUPIR_ERR_ARG;
+    GnArgs a[2] = {};
+    for (int i = 0; i < n; ++i) {
+        const supir_gn_problem& q = problems[i];
+        if (!q.x1 || !q.gamma || !q.beta || !q.out || (!q.part1 && !q.workspace)) return SUPIR_ERR_ARG;
+        if (q.C1 <= 0 || q.C1 > C) return SUPIR_ERR_ARG;
+        a[i].x1 = (const bf16_t*)q.x1; a[i].x2 = (const bf16_t*)q.x2; a[i].x1raw = (const bf16_t*)q.x1raw; a[i].x2raw = (const bf16_t*)q.x2raw;
+        a[i].gamma = q.gamma; a[i].beta = q.beta; a[i].partial = q.workspace;
+        a[i].part_u1 = q.part1; a[i].nch1 = q.nchunk1; a[i].part_u2 = q.part2; a[i].nch2 = q.nchunk2;
+        a[i].mod_g = (const bf16_t*)q.mod_g; a[i].mod_b = (const bf16_t*)q.mod_b; a[i].out = (bf16_t*)q.out;
+        a[i].B = B; a[i].HW = HW; a[i].C = C; a[i].C1 = q.C1; a[i].ld1 = q.ld1; a[i].ld2 = q.ld2; a[i].ldm = q.ldm; a[i].ldo = q.ldo;
+        a[i].act = act; a[i].eps = eps; a[i].cscale = q.control_scale;
+    }
+    return supir_groupnorm_launch_n(a, n, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -57,16 +57,29 @@ __device__ __forceinline__ float xhalf_max(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int S, int NW, bool PRE>
-__global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgs p) {
+// NP = 2 (supir_flash_attn_d64_grouped): two independent attention problems in one grid, problem q on XCDs [4 q, 4 q + 4): at 1024
+// tokens a problem is 320 workgroups on 256 CUs -- 1.25 rounds; two of them back to back fill 2.5 rounds instead of 2 x 2.
+template <int S, int NW, bool PRE, int NP = 1>
+__global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgsN<NP> pp) {
     static_assert(S >= 3, "tile t+1 is read while tile t is live and tile t+2 is in flight");
     __shared__ __attribute__((aligned(16))) char smem[S * 16384];
+    constexpr int NX = 8 / NP;
+    const int prob = NP == 1 ? 0 : (int)(blockIdx.x & 7) / NX;   // wave-uniform
+    const AttnArgs& p = pp.p[prob];
     constexpr int NT = 64 * NW, QB = 32 * NW, LPT = 512 / NT, NL = 2 * LPT;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nqb = (p.Tq + QB - 1) / QB;
-    const int id = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+    int id;
+    if constexpr (NP == 1) {
+        id = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+    } else {   // the problem's workgroups in contiguous runs over its NX XCDs; the grid is rounded up to whole rows of 8 blocks
+        const int nwg = nqb * p.H * p.B, qn = nwg / NX, rn = nwg - qn * NX;
+        const int vx = (int)blockIdx.x & (NX - 1), vidx = (int)blockIdx.x >> 3;
+        if (vidx >= qn + (vx < rn ? 1 : 0)) return;
+        id = (vx < rn ? vx * (qn + 1) : rn * (qn + 1) + (vx - rn) * qn) + vidx;
+    }
     const int bh = id / nqb, qb = id - bh * nqb;
     const int b = bh / p.H, h = bh - b * p.H;
     const char* Kb = (const char*)(p.K + (size_t)b * p.Tk * p.ldk + h * 64);
@@ -345,14 +358,38 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgs p
 #endif
 }
 
-int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
+static int attn_check(const AttnArgs& a) {
     if (a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0) return SUPIR_ERR_ARG;
     if ((a.ldq | a.ldk | a.ldvt) % 8 != 0 || a.ldo % 4 != 0) return SUPIR_ERR_SHAPE;
     if (a.ldvt < ((a.Tk + 63) / 64) * 64) return SUPIR_ERR_SHAPE;
+    return SUPIR_OK;
+}
+
+int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
+    const int rc = attn_check(a);
+    if (rc != SUPIR_OK) return rc;
     // ring depth 3 (4 measured equal or slower), 4 waves = 128 queries per workgroup (2 waves measured slower on every shape),
     // softmax scale folded into Q (6-10 % faster than a multiply per element; network-level parity unchanged:
     // profiles/r02/attn_pipelined_network_parity_and_step.log)
-    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true>), dim3(((a.Tq + 127) / 128) * a.H * a.B), dim3(256), 0, st, a);
+    AttnArgsN<1> pp;
+    pp.p[0] = a;
+    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1>), dim3(((a.Tq + 127) / 128) * a.H * a.B), dim3(256), 0, st, pp);
+    return SUPIR_LAUNCH_STATUS();
+}
+
+// two problems with the same grid (B, H, Tq) in one launch; Tk, strides and the causal flag are read per problem
+int supir_attn_launch_n(const AttnArgs* a, int n, hipStream_t st) {
+    if (n == 1) return supir_attn_launch(a[0], st);
+    if (n != 2) return SUPIR_ERR_SHAPE;
+    AttnArgsN<2> pp;
+    for (int q = 0; q < 2; ++q) {
+        const int rc = attn_check(a[q]);
+        if (rc != SUPIR_OK) return rc;
+        pp.p[q] = a[q];
+    }
+    if (a[0].B != a[1].B || a[0].H != a[1].H || a[0].Tq != a[1].Tq) return SUPIR_ERR_SHAPE;
+    const int nwg = ((a[0].Tq + 127) / 128) * a[0].H * a[0].B;
+    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 2>), dim3(8 * ((nwg + 3) / 4)), dim3(256), 0, st, pp);
     return SUPIR_LAUNCH_STATUS();
 }
 

@@ -676,20 +676,20 @@ static bool xcd_grid_enabled() {
 // needs again, unless it fits beside the other round's band.  The first version of this model charged gn*A + gm*W only: it put the
 // 1280-channel 32x32 convolutions on a (1, 8) grid whose 5.2 MB activation map does not stay resident -- 389 MB fetched for 35 MB
 // of operands (11x), 4.5 TB/s of fabric traffic in an "MFMA-bound" kernel.
-void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes, int resweep, int wgs_per_cu) {
+void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes, int resweep, int wgs_per_cu, int nx) {
     a.gm = a.gn = 0;
-    if (!xcd_grid_enabled() || ((tiles_m * tiles_n) & 7)) return;
+    if (!xcd_grid_enabled() || ((tiles_m * tiles_n) % nx)) return;
     static int model = -1;
     if (model < 0) {
         const char* e = getenv("SUPIR_XCD_MODEL");   // 0: the round-1 cost model (kept for A/B runs)
         model = (e && e[0] == '0') ? 0 : 1;
     }
-    const double c_bytes = 2.0 * (double)a.M * a.N / 8.0;   // each XCD also write-allocates its share of the output
+    const double c_bytes = 2.0 * (double)a.M * a.N / (double)nx;   // each XCD also write-allocates its share of the output
     const double RES = 3.0e6, BOTH = 3.5e6;
     const int slots = 32 * (wgs_per_cu < 1 ? 1 : wgs_per_cu);
     double best = 0.0;
-    for (int gm = 8; gm >= 1; gm >>= 1) {
-        const int gn = 8 / gm;
+    for (int gm = nx; gm >= 1; gm >>= 1) {
+        const int gn = nx / gm;
         if (tiles_m % gm || tiles_n % gn) continue;
         if (model == 0) {
             double cost = gn * a_bytes + gm * w_bytes;

@@ -56,9 +56,19 @@ __device__ __attribute__((aligned(256))) uint32_t g16_zero_page[64];
 // MIXED (fused q|k|v projection, supir_gemm_bf16_qkv): tile columns [0, n_split) take the normal epilogue into C, tile columns
 // [n_split, N) the transposed one into C2 (V^T, channel index n - n_split); decided per workgroup (tile_n), both main loops
 // (they differ in the MFMA operand order) are in the kernel.
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false>
-__global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
+//
+// NP = 2 (supir_gemm_grouped): two independent problems of identical shape in one grid.  Block b runs on XCD b % 8; problem q owns XCDs
+// [4 q, 4 q + 4) -- its operands stay in those four L2s -- and maps its tiles over them exactly as a single problem does over eight.
+// Used for the layer pairs GLVControl and the UNet encoder execute with identical shapes on independent data
+// (SUPIR/modules/SUPIR_v0.py:499-540 next to :600-625): M = 2048 tokens per problem fill only half the machine with tiles big
+// enough to be fed from L2 (128 x 80 at 49 FLOP per staged byte); two problems of 128 x 160 tiles are 256 workgroups at 65.
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1>
+__global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgsN<NP> pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NX = 8 / NP;                                               // XCDs per problem
+    const int prob = NP == 1 ? 0 : (int)(blockIdx.x & 7) / NX;               // wave-uniform: a scalar offset into the kernarg segment
+    const GemmArgs& p = pp.p[prob];
+    const int vxcd = (int)blockIdx.x & (NX - 1), vidx = (int)blockIdx.x >> 3;   // XCD inside the problem's share, index on that XCD
     G16_TL(tl_start);
     constexpr int NW = WM * WN;                          // waves per K group
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, RING = S * STAGE_BYTES;
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     const int tiles_m = p.M / BM, tiles_n = p.N / BN;
     int tile_m, tile_n;
     if (p.gm > 0) {   // 2-D XCD grid, see gemm.hip
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd = vxcd, idx = vidx;
         const int rm = tiles_m / p.gm, rn = tiles_n / p.gn;
         const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
         int lm, ln;
@@ -101,7 +111,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
         tile_m = xm * rm + lm;
         tile_n = xn * rn + ln;
     } else {
-        const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        // 1-D ranges: every XCD of the problem's share gets a contiguous run of tile ids (grouped launches: tiles % NX == 0)
+        const int id = NP == 1 ? xcd_remap(blockIdx.x, tiles_m * tiles_n) : vxcd * (tiles_m * tiles_n / NX) + vidx;
         if (p.order == 0) { tile_n = id / tiles_m; tile_m = id - tile_n * tiles_m; }
         else { tile_m = id / tiles_n; tile_n = id - tile_m * tiles_n; }
     }
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     auto prefetch_next = [&]() {
         const unsigned pf_lines = p.pf_lines;
         if (pf_lines == 0) return;
-        const unsigned total_waves = gridDim.x * 8, gw = blockIdx.x * 8 + bwave;
+        const unsigned total_waves = gridDim.x / NP * 8, gw = (unsigned)(vidx * NX + vxcd) * 8 + bwave;   // per problem
         const unsigned n_instr = (pf_lines + 63) >> 6;
         for (unsigned i = gw; i < n_instr; i += total_waves) {
             unsigned line = i * 64 + lane;
@@ -666,20 +677,29 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false>
-static int launch_gemm16(const GemmArgs& a_in, hipStream_t st) {
-    GemmArgs a = a_in;
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1>
+static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
+    GemmArgsN<NP> pp;
+    for (int q = 0; q < NP; ++q) pp.p[q] = a_in[q];
+    GemmArgs& a = pp.p[0];
+    const int tiles = (a.M / BM) * (a.N / BN);
+    if (NP > 1 && tiles % (8 / NP)) return SUPIR_ERR_SHAPE;
     const double a_bytes = CONV ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin : 2.0 * (double)a.M * a.K;
-    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, a_bytes, 2.0 * (double)a.N * a.K, CONV ? 9 : 1, 1);
+    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, a_bytes, 2.0 * (double)a.N * a.K, CONV ? 9 : 1, 1, 8 / NP);
+    for (int q = 1; q < NP; ++q) {   // identical shapes: identical tile maps
+        pp.p[q].gm = a.gm;
+        pp.p[q].gn = a.gn;
+        pp.p[q].order = a.order;
+    }
     constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // the ring(s) + the prefetch scratch row
     static_assert(smem <= 163840, "LDS");
-    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED>;
+    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED, NP>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    SUPIR_LAUNCH(kern, dim3((a.M / BM) * (a.N / BN)), dim3(512), smem, st, a);
+    SUPIR_LAUNCH(kern, dim3(NP * tiles), dim3(512), smem, st, pp);
     return SUPIR_LAUNCH_STATUS();
 }
 
@@ -690,7 +710,7 @@ bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
     const int ks = tile == 34 ? 1 : 2, s = (tile == 34 || tile == 35) ? 3 : 2;
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
-    if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch % bm || a.N % 10)) return false;
+    if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % 10)) return false;
     if (conv) {
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }
@@ -706,25 +726,68 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
     if (!supir_gemm16_supported(a, tile, conv)) return SUPIR_ERR_SHAPE;
     if (conv) {
         switch (tile) {
-            case 32: return launch_gemm16<128, 80, 4, 1, 2, 2, false, true>(a, st);
-            case 33: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true>(a, st);
-            case 34: return launch_gemm16<256, 160, 8, 1, 1, 3, false, true>(a, st);
-            default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(a, st);
+            case 32: return launch_gemm16<128, 80, 4, 1, 2, 2, false, true>(&a, st);
+            case 33: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true>(&a, st);
+            case 34: return launch_gemm16<256, 160, 8, 1, 1, 3, false, true>(&a, st);
+            default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
     const bool t = a.out_mode == 2;
     switch (tile) {
-        case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(a, st);
-        case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(a, st);
-        case 34: return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true>(a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false>(a, st);
-        default: return t ? launch_gemm16<128, 80, 4, 1, 2, 3, true>(a, st) : launch_gemm16<128, 80, 4, 1, 2, 3, false>(a, st);
+        case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
+        case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);
+        case 34: return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true>(&a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false>(&a, st);
+        default: return t ? launch_gemm16<128, 80, 4, 1, 2, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 3, false>(&a, st);
+    }
+}
+
+// Two problems in one launch (tiles 33 / 34 / 35; tile 32 is tile 35 with a shallower ring and has no grouped form).  What fixes the
+// grid and the kernel instantiation must agree (M, N, K, output mode); every other argument -- pointers, strides, which optional
+// operands are present, the convolution geometry -- is read per problem.
+static bool g16_same_shape(const GemmArgs& x, const GemmArgs& y) {
+    return x.M == y.M && x.N == y.N && x.K == y.K && x.out_mode == y.out_mode;
+}
+
+int supir_gemm16_launch_n(const GemmArgs* a, int n, hipStream_t st, int tile, bool conv) {
+    if (n == 1) return supir_gemm16_launch(a[0], st, tile, conv);
+    if (n != 2 || tile == 32) return SUPIR_ERR_SHAPE;
+    if (!supir_gemm16_supported(a[0], tile, conv) || !supir_gemm16_supported(a[1], tile, conv) || !g16_same_shape(a[0], a[1])) return SUPIR_ERR_SHAPE;
+    if (conv) {
+        switch (tile) {
+            case 33: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true, false, 2>(a, st);
+            case 34: return launch_gemm16<256, 160, 8, 1, 1, 3, false, true, false, 2>(a, st);
+            default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 2>(a, st);
+        }
+    }
+    const bool t = a[0].out_mode == 2;
+    switch (tile) {
+        case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true, false, false, 2>(a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false, false, false, 2>(a, st);
+        case 34: return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true, false, false, 2>(a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false, false, false, 2>(a, st);
+        default: return t ? launch_gemm16<128, 80, 4, 1, 2, 3, true, false, false, 2>(a, st) : launch_gemm16<128, 80, 4, 1, 2, 3, false, false, false, 2>(a, st);
     }
 }
 
 // fused q|k|v projection on tile 34 (256 x 160): columns [0, n_split) -> C (normal epilogue), [n_split, N) -> C2 transposed
-int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st) {
+static int g16_qkv_check(const GemmArgs& a) {
     if (a.M % 256 || a.N % 160 || a.n_split % 160 || a.n_split <= 0 || a.n_split >= a.N || a.K % 64 || (a.K >> 6) < 2) return SUPIR_ERR_SHAPE;
     if (a.lda % 8 || a.ldc % 8 || (((size_t)a.C) & 15) || a.ldc2 % 4 || a.rows_per_batch % 4 || a.ln_slots > 32) return SUPIR_ERR_SHAPE;
     if (a.act != 0 || a.out_mode != 0 || a.res || a.rowbias || a.rowstats_out || !a.C2) return SUPIR_ERR_ARG;
-    return launch_gemm16<256, 160, 8, 1, 1, 3, false, false, true>(a, st);
+    return SUPIR_OK;
+}
+
+int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st) {
+    const int rc = g16_qkv_check(a);
+    if (rc != SUPIR_OK) return rc;
+    return launch_gemm16<256, 160, 8, 1, 1, 3, false, false, true>(&a, st);
+}
+
+int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st) {
+    if (n == 1) return supir_gemm16_qkv_launch(a[0], st);
+    if (n != 2) return SUPIR_ERR_SHAPE;
+    for (int q = 0; q < 2; ++q) {
+        const int rc = g16_qkv_check(a[q]);
+        if (rc != SUPIR_OK) return rc;
+    }
+    if (!g16_same_shape(a[0], a[1])) return SUPIR_ERR_SHAPE;
+    return launch_gemm16<256, 160, 8, 1, 1, 3, false, false, true, 2>(a, st);
 }

@@ -59,8 +59,14 @@ constexpr int A_LOADS = BM * 8 / 512, W_LOADS = BN * 8 / 512;   // global->LDS i
 constexpr int LOADS = A_LOADS + W_LOADS;
 constexpr int C_RS = 80 * 2 + 16;                  // staged output row: 80 bf16 + 16 B pad
 
-__global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgs p) {
+// NP = 2: two problems of identical shape in one grid, problem q on XCDs [4 q, 4 q + 4) (see gemm16.hip)
+template <int NP>
+__global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgsN<NP> pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NX = 8 / NP;
+    const int prob = NP == 1 ? 0 : (int)(blockIdx.x & 7) / NX;
+    const GemmArgs& p = pp.p[prob];
+    const int vxcd = (int)blockIdx.x & (NX - 1), vidx = (int)blockIdx.x >> 3;
     BIG_TL(tl_start);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgs p) {
     const int tiles_m = p.M / BM, tiles_n = p.N / BN;
     int tile_m, tile_n;   // workgroup -> tile: see gemm.hip (XCD-aware partition chosen on the host)
     if (p.gm > 0) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd = vxcd, idx = vidx;
         const int rm = tiles_m / p.gm, rn = tiles_n / p.gn;
         const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
         int lm, ln;
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgs p) {
         tile_m = xm * rm + lm;
         tile_n = xn * rn + ln;
     } else {
-        const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        const int id = NP == 1 ? xcd_remap(blockIdx.x, tiles_m * tiles_n) : vxcd * (tiles_m * tiles_n / NX) + vidx;
         if (p.order == 0) { tile_n = id / tiles_m; tile_m = id - tile_n * tiles_m; }
         else { tile_m = id / tiles_n; tile_n = id - tile_m * tiles_n; }
     }
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgs p) {
 #endif
     // next-weight prefetch (supir_set_next_prefetch): see gemm.hip
     if (p.pf_lines) {
-        const unsigned total_waves = gridDim.x * 8, gw = blockIdx.x * 8 + wave;
+        const unsigned total_waves = gridDim.x / NP * 8, gw = (unsigned)(vidx * NX + vxcd) * 8 + wave;   // per problem
         const unsigned n_instr = (p.pf_lines + 63) >> 6;
         for (unsigned i = gw; i < n_instr; i += total_waves) {
             unsigned line = i * 64 + lane;
@@ -289,18 +295,40 @@ bool supir_gemm_big_supported(const GemmArgs& a) {
     return true;
 }
 
-int supir_gemm_big_launch(const GemmArgs& a_in, hipStream_t st) {
-    if (!supir_gemm_big_supported(a_in)) return SUPIR_ERR_SHAPE;
-    GemmArgs a = a_in;
-    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, 2.0 * (double)a.M * a.K, 2.0 * (double)a.N * a.K, 1, 1);
+template <int NP>
+static int launch_big(const GemmArgs* a_in, hipStream_t st) {
+    GemmArgsN<NP> pp;
+    for (int q = 0; q < NP; ++q) pp.p[q] = a_in[q];
+    GemmArgs& a = pp.p[0];
+    const int tiles = (a.M / BM) * (a.N / BN);
+    if (NP > 1 && tiles % (8 / NP)) return SUPIR_ERR_SHAPE;
+    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, 2.0 * (double)a.M * a.K, 2.0 * (double)a.N * a.K, 1, 1, 8 / NP);
+    for (int q = 1; q < NP; ++q) {
+        pp.p[q].gm = a.gm;
+        pp.p[q].gn = a.gn;
+        pp.p[q].order = a.order;
+    }
     constexpr int smem = S * STAGE + 256;   // the W ring + the prefetch scratch row; the epilogue reuses the ring
     static_assert(4096 + 8 * 32 * C_RS <= S * STAGE && 2 * BN * 4 <= 4096, "epilogue scratch must fit the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        if (supir_note_hip_status(hipFuncSetAttribute((const void*)geglu_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK)
+        if (supir_note_hip_status(hipFuncSetAttribute((const void*)geglu_big_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK)
             return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    SUPIR_LAUNCH(geglu_big_kernel, dim3((a.M / BM) * (a.N / BN)), dim3(512), smem, st, a);
+    SUPIR_LAUNCH(geglu_big_kernel<NP>, dim3(NP * tiles), dim3(512), smem, st, pp);
     return SUPIR_LAUNCH_STATUS();
+}
+
+int supir_gemm_big_launch(const GemmArgs& a_in, hipStream_t st) {
+    if (!supir_gemm_big_supported(a_in)) return SUPIR_ERR_SHAPE;
+    return launch_big<1>(&a_in, st);
+}
+
+int supir_gemm_big_launch_n(const GemmArgs* a, int n, hipStream_t st) {
+    if (n == 1) return supir_gemm_big_launch(a[0], st);
+    if (n != 2 || !supir_gemm_big_supported(a[0]) || !supir_gemm_big_supported(a[1])) return SUPIR_ERR_SHAPE;
+    const GemmArgs &x = a[0], &y = a[1];
+    if (x.M != y.M || x.N != y.N || x.K != y.K) return SUPIR_ERR_SHAPE;   // everything else is read per problem
+    return launch_big<2>(a, st);
 }

@@ -37,6 +37,14 @@ struct GemmArgs {
     float* gn_part_out;
 };
 
+// Grouped launch: NP independent problems of IDENTICAL shape in one grid (supir_gemm_grouped & co).  Block b runs on XCD b % 8, so
+// problem q owns the 8 / NP XCDs [q * 8 / NP, (q + 1) * 8 / NP): its operands stay in those L2s and the tile map inside them is the
+// single-problem one on a smaller XCD grid.  The problem index is wave-uniform (a scalar offset into the kernel-argument segment).
+template <int NP>
+struct GemmArgsN {
+    GemmArgs p[NP];
+};
+
 struct AttnArgs {
     const bf16_t* Q;
     const bf16_t* K;
@@ -46,6 +54,11 @@ struct AttnArgs {
     int ldq, ldk, ldvt, ldo;
     float scale_log2e;  // softmax scale * log2(e)
     int causal;         // 1: key j is visible to query i only for j <= i (text towers of the conditioner); needs Tq == Tk
+};
+
+template <int NP>
+struct AttnArgsN {
+    AttnArgs p[NP];
 };
 
 struct GnArgs {
@@ -71,24 +84,36 @@ struct GnArgs {
     float cscale;       // ZeroSFT control_scale (1 -> no lerp)
 };
 
+template <int NP>
+struct GnArgsN {
+    GnArgs p[NP];
+};
+
 int supir_gemm_select_tile(int M, int N, int act, int force_tile);
 int supir_rowstats_finalize_launch(const float* part, float* out, int M, int ld, int slots, int dim, float eps, hipStream_t st);
 int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile);
-void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes, int resweep, int wgs_per_cu);
+// nx = XCDs this problem's tiles are spread over (8; 4 for each problem of a two-problem grouped launch)
+void supir_choose_xcd_grid(GemmArgs& a, int tiles_m, int tiles_n, double a_bytes, double w_bytes, int resweep, int wgs_per_cu, int nx = 8);
 // gemm16.hip: tiles 32 (128 x 80) / 33 (128 x 160), v_mfma_f32_16x16x32_bf16, two K groups per workgroup
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv);
 int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv);
 int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st);
+// grouped forms: n (1 or 2) problems of identical shape, one launch (tiles 33 / 34 / 35 and the fused q|k|v tile)
+int supir_gemm16_launch_n(const GemmArgs* a, int n, hipStream_t st, int tile, bool conv);
+int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st);
 // gemm_big.hip: tile 37 = 256 x 320, activation operand global -> VGPR, GEGLU epilogue (16-row value / gate interleave)
 bool supir_gemm_big_supported(const GemmArgs& a);
 int supir_gemm_big_launch(const GemmArgs& a, hipStream_t st);
+int supir_gemm_big_launch_n(const GemmArgs* a, int n, hipStream_t st);
 int supir_attn_launch(const AttnArgs& a, hipStream_t st);
+int supir_attn_launch_n(const AttnArgs* a, int n, hipStream_t st);
 // attention_d512.hip: one head of dimension 512 (VAE mid block), 32-key tiles, 32 x 512 output tile per wave
 int supir_attn_d512_launch(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int B, int Tq, int Tk, int ldq, int ldk,
                            int ldvt, int ldo, float scale, hipStream_t st);
 int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, int Tpad, long lds_, long ldp, float scale,
                               hipStream_t st);
 int supir_groupnorm_launch(GnArgs a, hipStream_t st);
+int supir_groupnorm_launch_n(const GnArgs* a, int n, hipStream_t st);   // statistics from the producers (part_u1) or given only
 int supir_groupnorm_stats_launch(GnArgs a, float* sums_out, hipStream_t st);
 int supir_layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int rows, int C, int ldx,
                            int ldy, float eps, hipStream_t st);

@@ -15,7 +15,10 @@ __device__ __forceinline__ const bf16_t* gn_src(const GnArgs& p, int b, int row,
                       : p.x2 + ((size_t)b * p.HW + row) * p.ld2 + (c - p.C1);
 }
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
+// NP > 1: blockIdx.z selects one of NP independent GroupNorm problems of identical geometry (supir_groupnorm_grouped)
+template <int NP>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgsN<NP> pp) {
+    const GnArgs& p = pp.p[NP == 1 ? 0 : blockIdx.z];
     // per-channel partial sums go through LDS and are reduced in a FIXED order (no atomics): results are bitwise
     // reproducible run to run, which the parity tests and hipGraph-vs-eager checks rely on.
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -76,7 +79,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchunk_apply, int rows_per_chunk_apply) {
+template <int NP>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgsN<NP> pp, int nchunk_apply, int rows_per_chunk_apply) {
+    const GnArgs& p = pp.p[NP == 1 ? 0 : blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sA = (float*)smem_raw;  // [C] scale
     float* sB = sA + p.C;          // [C] shift
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int nchun
     }
 }
 
-int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
+static int gn_prepare(GnArgs& a) {
     if (a.B <= 0 || a.HW <= 0 || a.C <= 0 || a.C % 32 != 0) return SUPIR_ERR_SHAPE;
     if (a.C % 8 != 0 || a.C1 % 8 != 0 || a.ld1 % 8 != 0 || a.ldo % 8 != 0) return SUPIR_ERR_SHAPE;
     if (a.C1 < a.C && (!a.x2 || a.ld2 % 8 != 0)) return SUPIR_ERR_ARG;
@@ -186,9 +191,29 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
         if (a.given || (a.C / 32) % 10 || a.C1 % 10 || a.nch1 <= 0 || (a.C1 < a.C && (!a.part_u2 || a.nch2 <= 0))) return SUPIR_ERR_ARG;
     } else if (!a.given) {
         const int cv = a.C / 8, cvb = cv < 256 ? cv : 256, TY = 256 / cvb;
+        if ((size_t)TY * a.C * 2 * sizeof(float) > 64 * 1024) return SUPIR_ERR_SHAPE;
+    }
+    return SUPIR_OK;
+}
+
+template <int NP>
+static int gn_launch(const GnArgs* a_in, hipStream_t st) {
+    GnArgsN<NP> pp;
+    for (int q = 0; q < NP; ++q) {
+        pp.p[q] = a_in[q];
+        const int rc = gn_prepare(pp.p[q]);
+        if (rc != SUPIR_OK) return rc;
+    }
+    const GnArgs& a = pp.p[0];
+    for (int q = 1; q < NP; ++q) {   // one grid for all problems: same geometry and the same way of getting the statistics
+        const GnArgs& b = pp.p[q];
+        if (b.B != a.B || b.HW != a.HW || b.C != a.C || (b.part_u1 == nullptr) != (a.part_u1 == nullptr) || (b.given == nullptr) != (a.given == nullptr))
+            return SUPIR_ERR_SHAPE;
+    }
+    if (!a.part_u1 && !a.given) {
+        const int cv = a.C / 8, cvb = cv < 256 ? cv : 256, TY = 256 / cvb;
         const size_t smem_stats = (size_t)TY * a.C * 2 * sizeof(float);
-        if (smem_stats > 64 * 1024) return SUPIR_ERR_SHAPE;
-        SUPIR_LAUNCH(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), smem_stats, st, a);
+        SUPIR_LAUNCH(gn_stats_kernel<NP>, dim3(a.nchunk, a.B, NP), dim3(256), smem_stats, st, pp);
     }
     // apply: ~64 KB of bf16 per workgroup iteration, at least 2 waves of workgroups when there is enough work
     long rows_target = (long)(32 * 1024) / (2L * a.C);
@@ -198,8 +223,16 @@ int supir_groupnorm_launch(GnArgs a, hipStream_t st) {
     const int rpc = (a.HW + nca - 1) / nca;
     nca = (a.HW + rpc - 1) / rpc;
     const size_t smem = (size_t)a.C * 2 * sizeof(float);
-    SUPIR_LAUNCH(gn_apply_kernel, dim3(nca, a.B), dim3(256), smem, st, a, nca, rpc);
+    SUPIR_LAUNCH(gn_apply_kernel<NP>, dim3(nca, a.B, NP), dim3(256), smem, st, pp, nca, rpc);
     return SUPIR_LAUNCH_STATUS();
+}
+
+int supir_groupnorm_launch(GnArgs a, hipStream_t st) { return gn_launch<1>(&a, st); }
+
+int supir_groupnorm_launch_n(const GnArgs* a, int n, hipStream_t st) {
+    if (n == 1) return gn_launch<1>(a, st);
+    if (n != 2) return SUPIR_ERR_SHAPE;
+    return gn_launch<2>(a, st);
 }
 
 // per-(batch, group) sum / sum of squares of one tensor: [B][32][2] fp32 (chunk partials reduced in fp64, fixed order)
@@ -221,7 +254,9 @@ int supir_groupnorm_stats_launch(GnArgs a, float* sums_out, hipStream_t st) {
     const int cv = a.C / 8, cvb = cv < 256 ? cv : 256, TY = 256 / cvb;
     const size_t smem_stats = (size_t)TY * a.C * 2 * sizeof(float);
     if (smem_stats > 64 * 1024) return SUPIR_ERR_SHAPE;
-    SUPIR_LAUNCH(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), smem_stats, st, a);
+    GnArgsN<1> pp;
+    pp.p[0] = a;
+    SUPIR_LAUNCH(gn_stats_kernel<1>, dim3(a.nchunk, a.B), dim3(256), smem_stats, st, pp);
     SUPIR_LAUNCH(gn_finalize_kernel, dim3(a.B), dim3(64), 0, st, a.partial, sums_out, a.nchunk);
     return SUPIR_LAUNCH_STATUS();
 }

@@ -111,11 +111,17 @@ class GLVControl(UNetModel):
         self.input_upscale = input_upscale
         self.input_hint_block = TimestepEmbedSequential(Conv3x3(self.in_channels, self.model_channels))
 
-    def forward(self, x, timesteps, xt, context=None, y=None, **kwargs):
+    def prologue(self, x, timesteps, xt, y=None):
+        """Embeddings + the two <= 8-channel input convolutions: (emb, h0).  Kept apart from `body` because it mixes torch
+        elementwise ops with kernel launches (it cannot be recorded by ops.paired_run)."""
         emb = self._embed(timesteps, y)
         hint = self.input_hint_block[0]
         guided_hint = ops.conv3x3_smallcin(x.float(), hint.wf32(), hint.b32(), dtype=cdt())
-        h = self._conv_in(xt, add=guided_hint)          # input_blocks[0](xt) + guided_hint in one kernel
+        return emb, self._conv_in(xt, add=guided_hint)          # input_blocks[0](xt) + guided_hint in one kernel
+
+    def body(self, h, emb, context=None):
+        """input_blocks[1:] + middle_block on h0: the 10 feature maps.  The same stack of layers, shape for shape, as
+        LightGLVUNet.encode_body (ControlWrapper issues the two as grouped launches)."""
         hs = [h]
         for module in list(self.input_blocks)[1:]:
             h = module(h, emb, context)
@@ -123,6 +129,10 @@ class GLVControl(UNetModel):
         h = self.middle_block(h, emb, context)
         hs.append(h)
         return hs
+
+    def forward(self, x, timesteps, xt, context=None, y=None, **kwargs):
+        emb, h = self.prologue(x, timesteps, xt, y)
+        return self.body(h, emb, context)
 
 
 class LightGLVUNet(UNetModel):
@@ -142,17 +152,22 @@ class LightGLVUNet(UNetModel):
         for i in cross_attn_insert_idx:
             self.project_modules.insert(i, ZeroCrossAttn(cond_output_channels[i], concat_channels[i]))
 
-    def encode(self, x, timesteps=None, context=None, y=None):
-        """Encoder + middle block: independent of the control branch (it can run concurrently with GLVControl)."""
-        emb = self._embed(timesteps, y)
-        hs = []
-        h = self._conv_in(x)
-        hs.append(h)
+    def encode_prologue(self, x, timesteps=None, y=None):
+        return self._embed(timesteps, y), self._conv_in(x)
+
+    def encode_body(self, h, emb, context=None):
+        hs = [h]
         for module in list(self.input_blocks)[1:]:
             h = module(h, emb, context)
             hs.append(h)
         h = self.middle_block(h, emb, context)
         return emb, hs, h
+
+    def encode(self, x, timesteps=None, context=None, y=None):
+        """Encoder + middle block: independent of the control branch (it can run concurrently with GLVControl, or -- the two
+        being the same stack of layers -- be issued with it as grouped launches: ControlWrapper.pair_branches)."""
+        emb, h = self.encode_prologue(x, timesteps, y)
+        return self.encode_body(h, emb, context)
 
     def adapter_control_sides(self, control, on_done=None):
         """Control-side half of every adapter (ZeroSFT gamma|beta maps, ZeroCrossAttn K / V^T) in the order the decoder

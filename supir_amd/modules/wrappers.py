@@ -48,6 +48,11 @@ class ControlWrapper(nn.Module):
         # per (context shape, vector shape): every graph of that shape and the eager path write the same buffers in place
         self._resident = {}
         self.overlap_branches = True   # GLVControl || UNet encoder on two HIP streams
+        # GLVControl and the UNet encoder are the same stack of layers on independent data: record both and issue every layer
+        # pair as ONE grouped launch (ops.paired_run) instead of two half-machine launches on two streams whose kernels barely
+        # overlap (profiles/r02/step_trace_summary_gemm16.txt: 1.2 ms of concurrency in a 38 ms step).  The adapters' control
+        # sides still run on the second stream beside the decoder.  Needs overlap_branches.
+        self.pair_branches = os.environ.get("SUPIR_PAIR_BRANCHES", "1") != "0"
         # Weight prefetch inside captured graphs: op i's GEMM kernel touches the weight of op i+distance on its way out
         # (ops.WeightPrefetch, supir_set_next_prefetch).  The cold-weight penalty is +25..40 % per GEMM (tools/cold_probe.py).
         # The earlier form -- a prefetch launch per op on a third stream -- cost more in graph nodes than it saved
@@ -79,10 +84,18 @@ class ControlWrapper(nn.Module):
             if self._side is None or self._side.device != x.device:
                 self._side = torch.cuda.Stream(device=x.device)
             side = self._side
-            side.wait_stream(main)
             ready = {}
+            enc = None
+            if self.pair_branches:
+                from .. import ops
+                cm, dm = self.control_model, self.diffusion_model
+                emb_c, h_c = cm.prologue(ckw["x"], t, x, vec)
+                emb_u, h_u = dm.encode_prologue(x, t, vec)
+                control, enc = ops.paired_run(lambda: cm.body(h_c, emb_c, ctx), lambda: dm.encode_body(h_u, emb_u, ctx))
+            side.wait_stream(main)
             with torch.cuda.stream(side):
-                control = self.control_model(**ckw)
+                if enc is None:
+                    control = self.control_model(**ckw)
                 ev_control = torch.cuda.Event()
                 ev_control.record(side)
 
@@ -93,7 +106,8 @@ class ControlWrapper(nn.Module):
 
                 # control-side halves of the adapters keep the side stream busy while the main stream runs the decoder
                 self.diffusion_model.adapter_control_sides(control, on_done)
-            enc = self.diffusion_model.encode(x, timesteps=t, context=ctx, y=vec)
+            if enc is None:
+                enc = self.diffusion_model.encode(x, timesteps=t, context=ctx, y=vec)
             main.wait_event(ev_control)
             for h in control:
                 h.record_stream(main)

@@ -4,6 +4,7 @@ Internal activation layout: bf16, channels last.  A feature map is a tensor of l
 dim is contiguous and whose pixel stride `ld` (>= C) is uniform (so channel slices of a wider buffer are valid
 operands: this is how `torch.cat(dim=1)` of the reference disappears).  Token tensors are [B, T, C] / [M, C].
 """
+import ctypes as _ct
 import math
 
 import torch
@@ -67,12 +68,14 @@ def finish_timing(trace):
     return trace
 
 
-def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1):
+def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1, group=1):
+    """Kernel instantiation a GEMM-family trace record ran on; group = 2: the two-problem grouped form (",x2")."""
+    g = ",x2" if group == 2 else ""
     if tile == 37:
-        return "geglu_big_kernel<256,320,4x2>"
+        return f"geglu_big_kernel<256,320,4x2{g}>"
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv"}[tile]
-        return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}>"
+        return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}{g}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
             "128,128,2x2x2k"][t]
@@ -147,28 +150,39 @@ def save_tuning(path=None):
         _json.dump([[list(k), v] for k, v in _TUNE.items()], open(path, "w"))
 
 
-def _autotune(key, candidates, launch):
-    best = _TUNE.get(key)
-    if best is not None:
-        return best
-    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
-        return -1
+def _time_options(options, run):
+    """Time `run(option)` for every option (HIP events on the launch stream; min over three short rounds: one round of 5 launches
+    picked a 15 % slower tile now and then).  An option whose first launch returns an error code is dropped -- the C side refuses
+    shapes / alignments the Python predicates may not know about, and a refused launch would otherwise time at ~0 us and win.
+    Returns [(ms, option)] of the options that ran."""
     times = []
-    for t in candidates:
-        for _ in range(3):
-            launch(t)
+    for t in options:
+        if run(t) != 0:
+            continue
+        for _ in range(2):
+            run(t)
         best_t = None
-        for _ in range(3):          # min over three short rounds: one round of 5 launches picked a 15 % slower tile now and then
+        for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(6):
-                launch(t)
+                run(t)
             e1.record()
             e1.synchronize()
             dt = e0.elapsed_time(e1)
             best_t = dt if best_t is None or dt < best_t else best_t
         times.append((best_t, t))
-    best = min(times)[1]
+    return times
+
+
+def _autotune(key, candidates, launch):
+    best = _TUNE.get(key)
+    if best is not None:
+        return best
+    if not AUTOTUNE or _DEFER is not None or torch.cuda.is_current_stream_capturing():
+        return -1
+    times = _time_options(candidates, launch)
+    best = min(times)[1] if times else -1
     _TUNE[key] = best
     return best
 
@@ -204,7 +218,7 @@ class WeightPrefetch:
         self.stream.wait_stream(torch.cuda.current_stream())
         lib = _lib.load()
         for j in range(min(self.distance, len(self.plan))):      # prime the first `distance` weights
-            ptr, nb = self.plan[j]
+            ptr, nb = self.plan[j][0]
             lib.supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
 
     def end(self):
@@ -216,25 +230,39 @@ class WeightPrefetch:
                     lib.supir_set_next_prefetch(None, 0)
         self.mode = None
 
-    def touch(self, w):
+    def touch_group(self, ws):
+        """One launch consuming the weight matrices `ws` (one per problem of a grouped launch).  Recording: append the group to the
+        plan.  Replaying: return, per problem, the (pointer, bytes) of the weight the group `distance` launches later consumes
+        (problem k prefetches that group's k-th weight), or None."""
+        cur = tuple((w.data_ptr(), w.numel() * w.element_size()) for w in ws)
+        none = [None] * len(ws)
         if self.mode == "record":
-            self.plan.append((w.data_ptr(), w.numel() * w.element_size()))
-        elif self.mode == "replay":
-            i = self.idx
-            self.idx += 1
-            # wrap around: the last ops of a step prefetch the first weights of the next step (same graph replayed 50 times)
-            if i >= len(self.plan) or self.plan[i][0] != w.data_ptr():
-                return
-            ptr, nb = self.plan[(i + self.distance) % len(self.plan)]
-            if self.kind == "stream":
-                if i + self.distance >= len(self.plan):
-                    return
-                ev = torch.cuda.Event()
-                ev.record()                       # on the op's own stream: "op i is next"
-                self.stream.wait_event(ev)
-                _lib.load().supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
-            else:
-                _lib.load(w.dtype).supir_set_next_prefetch(ptr, nb)
+            self.plan.append(cur)
+            return none
+        if self.mode != "replay":
+            return none
+        i = self.idx
+        self.idx += 1
+        # wrap around: the last ops of a step prefetch the first weights of the next step (same graph replayed 50 times)
+        if i >= len(self.plan) or [q[0] for q in self.plan[i]] != [q[0] for q in cur]:
+            return none
+        if self.kind == "stream" and i + self.distance >= len(self.plan):
+            return none
+        nxt = self.plan[(i + self.distance) % len(self.plan)]
+        return [nxt[k] if k < len(nxt) else None for k in range(len(ws))]
+
+    def touch(self, w):
+        nxt = self.touch_group([w])[0]
+        if nxt is None:
+            return
+        ptr, nb = nxt
+        if self.kind == "stream":
+            ev = torch.cuda.Event()
+            ev.record()                       # on the op's own stream: "op i is next"
+            self.stream.wait_event(ev)
+            _lib.load().supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
+        else:
+            _lib.load(w.dtype).supir_set_next_prefetch(ptr, nb)
 
 
 _PF = None
@@ -250,6 +278,12 @@ def _pf(w):
         _PF.touch(w)
 
 
+def _pf_group(ws):
+    if _PF is not None and _PF.mode is not None:
+        return _PF.touch_group(ws)
+    return [None] * len(ws)
+
+
 # --------------------------------------------------------------------------------------------- GroupNorm statistics from producers
 class GnPart:
     """What a producer GEMM / conv epilogue left behind for a GroupNorm over its output (supir_set_next_gn_partials): fp32
@@ -263,17 +297,198 @@ class GnPart:
 USE_GN_PARTS = _os.environ.get("SUPIR_GN_PARTS", "1") != "0"   # producers emit GroupNorm statistics where the kernels support it
 
 
-def _gn_part_request(lib, tile, nbatch, rows_per_batch, N, device):
-    """Arm the one-shot request for the launch that follows, if the chosen tile can serve it; returns the GnPart or None."""
+def _gn_part_alloc(tile, nbatch, rows_per_batch, N, device):
+    """The buffer a launch on `tile` fills with GroupNorm partials of its output, if that tile can emit them; returns the GnPart
+    or None.  (The request itself travels with the launch: the one-shot supir_set_next_gn_partials for a single launch, the
+    problem's gn_partials_out field for a grouped one.)"""
     if not USE_GN_PARTS or tile not in _G16:
         return None
     bm = _G16[tile][0]
     if rows_per_batch <= 0 or rows_per_batch % bm or N % 10:
         return None
     nchunk = rows_per_batch // bm
-    buf = torch.empty(nbatch, nchunk, N // 10, 2, dtype=torch.float32, device=device)
-    lib.supir_set_next_gn_partials(buf.data_ptr())
+    # recorded launches (paired_run) may be re-timed on other tiles of the family before they are issued: room for the finest tile rows
+    alloc = max(nchunk, rows_per_batch // 128) if _DEFER is not None else nchunk
+    buf = torch.empty(nbatch, alloc, N // 10, 2, dtype=torch.float32, device=device)
     return GnPart(buf, nchunk, N)
+
+
+# --------------------------------------------------------------------------------------------- deferred issue / paired launches
+# GLVControl and the encoder half of LightGLVUNet are the same stack of layers on independent data (SUPIR/modules/SUPIR_v0.py:499-540
+# next to :600-625).  paired_run() executes the two Python call trees one after the other with every launch RECORDED instead of
+# issued (shapes, output allocation and tile choice happen as usual; control flow on this path never depends on tensor values), then
+# walks the two launch lists in lockstep and issues each pair of identical problems as ONE grouped launch (supir_gemm_grouped,
+# supir_flash_attn_d64_grouped, supir_groupnorm_grouped), anything else one by one in the recorded order.  Per-branch order is
+# preserved and the two branches share no tensor, so any interleaving is valid.  Every tensor a recorded launch touches is kept
+# alive until the lists have been issued: the caching allocator must not hand a buffer the first branch "freed" while recording to
+# the second branch.
+_DEFER = None
+PAIR = _os.environ.get("SUPIR_PAIR", "1") != "0"            # paired_run groups launches (0: records and issues them one by one)
+PAIR_TILES = (33, 34, 35, 37)                               # tiles with a two-problem form (csrc/gemm16.hip, csrc/gemm_big.hip)
+PAIR_KINDS = set(_os.environ.get("SUPIR_PAIR_KINDS", "gemm,conv,qkv,attn,gn").split(","))   # A/B runs: which kinds may group
+
+
+class _Launch:
+    """One kernel launch, ready to go: `call(tile, out_override)` issues it alone through its own entry point; `make(tile,
+    out_override)` returns its (shared shape, per-problem struct) for a grouped launch.  kind None = no grouped form."""
+    __slots__ = ("kind", "key", "tkey", "lib", "name", "tile", "single_tile", "cands", "call", "make", "w", "part", "trace",
+                 "keep", "out", "inplace")
+
+    def __init__(self, kind, lib, name, call, *, key=None, tkey=None, tile=-1, single_tile=-1, cands=(), make=None, w=None, part=None,
+                 trace=None, keep=(), out=None, inplace=False):
+        self.kind, self.lib, self.name, self.call = kind, lib, name, call
+        self.key, self.tkey, self.tile, self.single_tile, self.cands, self.make = key, tkey, tile, single_tile, cands, make
+        self.w, self.part, self.trace, self.keep, self.out, self.inplace = w, part, trace, keep, out, inplace
+
+
+def _run_single(L):
+    if L.w is not None:
+        _pf(L.w)
+    if L.part is not None:
+        L.lib.supir_set_next_gn_partials(L.part.buf.data_ptr())
+    ev = _ev()
+    rc = L.call(L.tile, None)
+    _lib.check(rc, L.name, L.lib)
+    if L.trace is not None:
+        _rec(L.trace[0], L.trace[1], L.trace[2], ev, **L.trace[3])
+
+
+def _issue(L):
+    if _DEFER is not None:
+        _DEFER.append(L)
+    else:
+        _run_single(L)
+
+
+def _no_defer(name):
+    if _DEFER is not None:
+        raise _lib.SupirHipError(f"ops.{name} inside paired_run: this op has no recorded form (it would run out of order)")
+
+
+def _pair_tile(tkey, tile, cands):
+    """Tile of a RECORDED launch: the winner of the pair autotune for this shape once there is one, else the single-launch tile."""
+    if _DEFER is None or not PAIR:
+        return tile
+    pt = _TUNE.get(("pair",) + tkey)
+    return pt if (pt is not None and pt >= 32 and pt in cands) else tile
+
+
+def _scratch_like(t):
+    return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+
+
+def _gemm_group_call(a, b, tile, oa=None, ob=None, prefetch=(None, None)):
+    sh, pa = a.make(tile, oa)
+    _, pb = b.make(tile, ob)
+    probs = (_lib.GemmProblem * 2)(pa, pb)
+    for q, pf in zip(probs, prefetch):
+        if pf is not None:
+            q.prefetch, q.prefetch_bytes = pf
+    return a.lib.supir_gemm_grouped(_ct.byref(sh), probs, 2, _stream())
+
+
+_PAIR_BM_BN = {33: (128, 160), 34: (256, 160), 35: (128, 80), 36: (256, 160), 37: (256, 320)}
+
+
+def _group_ok(L, tile):
+    """A two-problem grid gives each problem four XCDs: its tile count must divide over them (same check as the C side)."""
+    if tile not in _PAIR_BM_BN:
+        return False
+    bm, bn = _PAIR_BM_BN[tile]
+    M, N = L.trace[3]["M"], L.trace[3]["N"]
+    return M % bm == 0 and N % bn == 0 and ((M // bm) * (N // bn)) % 4 == 0
+
+
+def _pair_autotune(a, b, pkey):
+    """Grouped launch on each tile both problems can take vs the two single launches on their own tiles (-2), timed in place where
+    the pair sits in the issue order (operands are live; outputs of in-place accumulations go to scratch).  Everything a candidate
+    writes is rewritten by the real launch that follows."""
+    if a.kind == "qkv":
+        opts = ([36] if _group_ok(a, 36) else []) + [-2]
+    else:
+        opts = [t for t in PAIR_TILES if t in a.cands and t in b.cands and _group_ok(a, t)] + [-2]
+    oa = _scratch_like(a.out) if a.inplace else None
+    ob = _scratch_like(b.out) if b.inplace else None
+
+    def run(t):
+        if t == -2:
+            rc = a.call(a.single_tile, oa)
+            return rc if rc != 0 else b.call(b.single_tile, ob)
+        return _gemm_group_call(a, b, t, oa, ob)
+
+    times = _time_options(opts, run)
+    best = min(times)[1] if times else -2
+    _TUNE[pkey] = best
+    return best
+
+
+def _try_pair(a, b):
+    """Issue the recorded launches a, b (identical problems of the two branches) as one grouped launch if there is one for them."""
+    if not PAIR or a.kind not in PAIR_KINDS:
+        return False
+    capturing = torch.cuda.is_current_stream_capturing()
+    if a.kind in ("gemm", "conv", "qkv"):
+        if a.kind != "qkv" and not a.cands and not b.cands:
+            pt = a.tile if a.tile in PAIR_TILES else -2      # tiles forced by the caller: group on that tile, no timing
+        else:
+            pkey = ("pair",) + a.tkey
+            pt = _TUNE.get(pkey)
+            if pt is None and AUTOTUNE and not capturing:
+                pt = _pair_autotune(a, b, pkey)
+        if pt is None or pt == -2 or a.tile != b.tile or a.tile != pt or not _group_ok(a, pt):
+            return False   # (a winner found after this pass was recorded is used from the next pass on: tile-dependent buffers)
+        pfs = _pf_group([a.w, b.w])
+        ev = _ev()
+        rc = _gemm_group_call(a, b, a.tile, prefetch=pfs)
+        _lib.check(rc, "supir_gemm_grouped", a.lib)
+        if a.trace is not None:
+            k, fl, by, kw = a.trace
+            _rec(k, 2 * fl, 2 * by, ev, **dict(kw, group=2))
+        return True
+    ev = _ev()
+    if a.kind == "attn":
+        (B, H, Tq, scale), pa = a.make()
+        _, pb = b.make()
+        rc = a.lib.supir_flash_attn_d64_grouped((_lib.AttnProblem * 2)(pa, pb), 2, B, H, Tq, scale, _stream())
+        _lib.check(rc, "supir_flash_attn_d64_grouped", a.lib)
+    elif a.kind == "gn":
+        (B, HW, C, eps, act), pa = a.make()
+        _, pb = b.make()
+        rc = a.lib.supir_groupnorm_grouped((_lib.GnProblem * 2)(pa, pb), 2, B, HW, C, eps, act, _stream())
+        _lib.check(rc, "supir_groupnorm_grouped", a.lib)
+    else:
+        return False
+    if a.trace is not None:
+        k, fl, by, kw = a.trace
+        _rec(k, 2 * fl, 2 * by, ev, **dict(kw, group=2))
+    return True
+
+
+def paired_run(fn_a, fn_b):
+    """Run fn_a() and fn_b() -- two independent branches built from the ops of this module -- with their launches recorded, then
+    issue the two launch lists in lockstep on the current stream, identical problems as grouped launches.  Returns (fn_a(), fn_b())."""
+    global _DEFER
+    assert _DEFER is None, "paired_run does not nest"
+    lists = []
+    results = []
+    for fn in (fn_a, fn_b):
+        _DEFER = cur = []
+        try:
+            results.append(fn())
+        finally:
+            _DEFER = None
+        lists.append(cur)
+    la, lb = lists
+    for i in range(max(len(la), len(lb))):
+        a = la[i] if i < len(la) else None
+        b = lb[i] if i < len(lb) else None
+        if a is not None and b is not None and a.kind is not None and a.kind == b.kind and a.key == b.key and a.lib is b.lib \
+                and _try_pair(a, b):
+            continue
+        for L in (a, b):
+            if L is not None:
+                _run_single(L)
+    return results[0], results[1]
 
 
 # --------------------------------------------------------------------------------------------- GEMM family
@@ -303,36 +518,58 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         assert rowbias.dtype == DT and rowbias.stride(-1) == 1 and rowbias.shape[-1] == N
         ld_rb = rowbias.stride(0)
     om = 0 if out.dtype == DT else 1
+    if gn_part and rows_per_batch <= 0:
+        rows_per_batch = M   # one batch: the partials' row-chunk index is computed from it (never 0 in the kernel)
+
+    def wb(t):
+        return (alt16[0], alt16[1]) if (t in (34, 37) and act == 2 and alt16 is not None) else (w, bias)
 
     def launch(t, outp=None):
-        wq, bq = (alt16[0], alt16[1]) if (t in (34, 37) and act == 2 and alt16 is not None) else (w, bias)
+        wq, bq = wb(t)
         return lib.supir_gemm_bf16(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
                                    _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, act, om, alpha, t, _stream())
 
+    inplace = residual is not None and residual.data_ptr() == out.data_ptr()
+    key = ("gemm", M, N, K, act, om) + _k(DT)
+    cands = ()
+    single_tile = tile
     if tile == -1:
-        key = ("gemm", M, N, K, act, om) + _k(DT)
         ok = (lda % 8 == 0 and out.data_ptr() % 16 == 0 and (residual is None or ldr % 4 == 0)
               and (rowbias is None or ld_rb % 4 == 0))
-        cands = _gemm_candidates(M, N, K, act, om, ldc, epilogue_ok=ok, geglu16=alt16 is not None)
-        if residual is not None and residual.data_ptr() == out.data_ptr():
+        big_ok = alpha == 1.0 and a.data_ptr() % 16 == 0 and (alt16 is None or alt16[0].data_ptr() % 16 == 0)
+        cands = _gemm_candidates(M, N, K, act, om, ldc, epilogue_ok=ok, geglu16=alt16 is not None, big_ok=big_ok)
+        if inplace:
             # in-place accumulate (x += f(x)): re-launching would change the data, so the candidates are timed into a scratch
             # output of the same strides (reads `residual`, never writes it)
             tile = _TUNE.get(key)
             if tile is None:
-                scratch = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device)
-                tile = _autotune(key, cands, lambda t: launch(t, scratch))
+                if _DEFER is None:
+                    scratch = _scratch_like(out)
+                    tile = _autotune(key, cands, lambda t: launch(t, scratch))
+                else:
+                    tile = -1
         else:
             tile = _autotune(key, cands, launch)
         if tile >= 32 and tile not in cands:   # a winner cached for this shape under friendlier strides / layouts
             tile = -1
-    _pf(w)
+        single_tile = tile
+        tile = _pair_tile(key, tile, cands)
     part = None
     if gn_part and om == 0 and act != 2:
-        part = _gn_part_request(lib, tile, M // rows_per_batch if rows_per_batch else 1, rows_per_batch or M, N, a.device)
-    ev = _ev()
-    rc = launch(tile)
-    _lib.check(rc, "supir_gemm_bf16", lib)
-    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act, tile=tile)
+        part = _gn_part_alloc(tile, M // rows_per_batch, rows_per_batch, N, a.device)
+
+    def make(t, outp=None):
+        wq, bq = wb(t)
+        sh = _lib.GemmShape(kind=_lib.GROUP_GEMM, tile=t, M=M, N=N, K=K, rows_per_batch=rows_per_batch, act=act, out_mode=om, alpha=alpha)
+        pr = _lib.GemmProblem(A=a.data_ptr(), W=wq.data_ptr(), C=(out if outp is None else outp).data_ptr(), bias=_p(bq),
+                              rowbias=_p(rowbias), residual=_p(residual), gn_partials_out=None if part is None else part.buf.data_ptr(),
+                              lda=lda, ldc=ldc, ldr=ldr, ld_rowbias=ld_rb)
+        return sh, pr
+
+    _issue(_Launch("gemm", lib, "supir_gemm_bf16", launch, key=key + (alpha, rows_per_batch, part is not None), tkey=key, tile=tile,
+                   single_tile=single_tile, cands=cands, make=make, w=w, part=part, out=out, inplace=inplace,
+                   trace=("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), dict(M=M, N=N, K=K, act=act, tile=tile)),
+                   keep=(a, w, bias, rowbias, residual, out, alt16, part)))
     return (out, part) if gn_part else out
 
 
@@ -344,7 +581,7 @@ USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc
 USE_GEMM_BIG = _os.environ.get("SUPIR_GEMM_BIG", "1") != "0"   # tile 37 (csrc/gemm_big.hip) in the GEGLU autotune lists
 
 
-def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu16=False):
+def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu16=False, big_ok=True):
     """Tile candidates for the autotuner.  Tiles 32-35 (csrc/gemm16.hip: 16x16x32 MFMA, tile grids that are exact multiples of
     the 256 CUs) take exact shapes only -- the same predicate as supir_gemm16_supported.  act = 2 (GEGLU) can use tile 34 when the
     caller also supplied the 16-row-interleaved weight layout (`geglu16`)."""
@@ -362,8 +599,9 @@ def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu1
         if act == 2 and not (t == 34 and geglu16):
             continue
         extra.append(t)
-    # tile 37 (csrc/gemm_big.hip): 256 x 320, activation operand global -> VGPR, GEGLU only; same predicate as supir_gemm_big_supported
-    if act == 2 and geglu16 and USE_GEMM_BIG and om == 0 and M % 256 == 0 and N % 320 == 0 and K % 64 == 0 and K >= 128 and ln_slots <= 64:
+    # tile 37 (csrc/gemm_big.hip): 256 x 320, GEGLU only; same predicate as supir_gemm_big_supported (big_ok: alpha == 1 and 16-byte
+    # aligned A / W / C, checked by the caller)
+    if act == 2 and geglu16 and USE_GEMM_BIG and big_ok and om == 0 and M % 256 == 0 and N % 320 == 0 and K % 64 == 0 and K >= 128 and ln_slots <= 64:
         extra.append(37)
     return base + tuple(extra)
 
@@ -384,10 +622,12 @@ def rowstats_finalize(st, dim, eps):
     lib = _lib.load()
     M = st.buf.shape[0]
     out = torch.empty(M, 2, dtype=torch.float32, device=st.buf.device)
-    ev = _ev()
-    rc = lib.supir_rowstats_finalize(st.buf.data_ptr(), out.data_ptr(), M, st.ld, st.slots, dim, eps, _stream())
-    _lib.check(rc, "supir_rowstats_finalize")
-    _rec("rowstats_finalize", 0, 8.0 * M * (st.slots + 1), ev)
+
+    def launch(t, outp=None):
+        return lib.supir_rowstats_finalize(st.buf.data_ptr(), out.data_ptr(), M, st.ld, st.slots, dim, eps, _stream())
+
+    _issue(_Launch(None, lib, "supir_rowstats_finalize", launch, trace=("rowstats_finalize", 0, 8.0 * M * (st.slots + 1), {}),
+                   keep=(st.buf, out)))
     return RowStats(out, 0, 0)
 
 
@@ -407,6 +647,8 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
         B, T, Tpad = trans
         assert M == B * T
         if out is None:
+            if Tpad != T:
+                _no_defer("gemm_ln(trans with padding)")
             out = torch.zeros(B, N, Tpad, dtype=DT, device=a.device) if Tpad != T else \
                 torch.empty(B, N, Tpad, dtype=DT, device=a.device)
         ldc, om, rpb = Tpad, 2, T
@@ -429,32 +671,52 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
         ln_p, ln_ld, ln_slots = ln.buf.data_ptr(), ln.ld, ln.slots
         assert colsum is not None and colsum.numel() == N
 
+    def wcb(t):
+        return alt16 if (t in (34, 37) and act == 2 and alt16 is not None) else (w, colsum, bias)
+
     def launch(t, outp=None):
-        wq, cq, bq = alt16 if (t in (34, 37) and act == 2 and alt16 is not None) else (w, colsum, bias)
+        wq, cq, bq = wcb(t)
         return lib.supir_gemm_bf16_ln(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
                                       _p(bq), _p(residual), ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots,
                                       _p(cq), ln_eps, _stream())
 
+    inplace = residual is not None and residual.data_ptr() == out.data_ptr()
+    key = ("gemm", M, N, K, act, om) + _k(DT)
+    cands = ()
+    single_tile = tile
     if tile == -1:
-        key = ("gemm", M, N, K, act, om) + _k(DT)
         ok = (lda % 8 == 0 and out.data_ptr() % 16 == 0 and (residual is None or ldr % 4 == 0)
               and (trans is None or rpb % 4 == 0))
-        cands = _gemm_candidates(M, N, K, act, om, ldc, ln_slots=ln_slots, epilogue_ok=ok, geglu16=alt16 is not None)
-        if residual is not None and residual.data_ptr() == out.data_ptr():
+        big_ok = alpha == 1.0 and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (alt16 is None or alt16[0].data_ptr() % 16 == 0)
+        cands = _gemm_candidates(M, N, K, act, om, ldc, ln_slots=ln_slots, epilogue_ok=ok, geglu16=alt16 is not None, big_ok=big_ok)
+        if inplace:
             tile = _TUNE.get(key)
             if tile is None:   # in-place accumulate: time the candidates into a scratch output (see gemm())
-                scratch = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device)
-                tile = _autotune(key, cands, lambda t: launch(t, scratch))
+                if _DEFER is None:
+                    scratch = _scratch_like(out)
+                    tile = _autotune(key, cands, lambda t: launch(t, scratch))
+                else:
+                    tile = -1
         else:
             tile = _autotune(key, cands, launch)
         if tile >= 32 and tile not in cands:
             tile = -1
-    _pf(w)
-    ev = _ev()
-    rc = launch(tile)
-    _lib.check(rc, "supir_gemm_bf16_ln", lib)
-    _rec("gemm_t" if trans is not None else "gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out), ev, M=M, N=N, K=K, act=act,
-         tile=tile)
+        single_tile = tile
+        tile = _pair_tile(key, tile, cands)
+
+    def make(t, outp=None):
+        wq, cq, bq = wcb(t)
+        sh = _lib.GemmShape(kind=_lib.GROUP_GEMM, tile=t, M=M, N=N, K=K, rows_per_batch=rpb, act=act, out_mode=om, alpha=alpha, ln_eps=ln_eps)
+        pr = _lib.GemmProblem(A=a.data_ptr(), W=wq.data_ptr(), C=(out if outp is None else outp).data_ptr(), bias=_p(bq),
+                              residual=_p(residual), rowstats_out=_p(stats), ln_stats=ln_p, ln_colsum=_p(cq), lda=lda, ldc=ldc, ldr=ldr,
+                              rs_ld=rs_ld, ln_ld=ln_ld, ln_slots=ln_slots)
+        return sh, pr
+
+    _issue(_Launch("gemm", lib, "supir_gemm_bf16_ln", launch, key=key + (alpha, rpb, ln_eps, emit_stats, ln is not None), tkey=key,
+                   tile=tile, single_tile=single_tile, cands=cands, make=make, w=w, out=out, inplace=inplace,
+                   trace=("gemm_t" if trans is not None else "gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * n_out),
+                          dict(M=M, N=N, K=K, act=act, tile=tile)),
+                   keep=(a, w, bias, residual, out, stats, ln.buf if ln is not None else None, colsum, alt16)))
     if emit_stats:
         t_used = tile if tile >= 32 else (tile & 7) if tile >= 0 else lib.supir_gemm_tile_for(M, N, act)
         bn, _ = _TILE_BN_WN[t_used]
@@ -488,12 +750,22 @@ def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, ou
     if ln is not None:
         ln_p, ln_ld, ln_slots = ln.buf.data_ptr(), ln.ld, ln.slots
         assert colsum is not None and colsum.numel() == N
-    _pf(w)
-    ev = _ev()
-    rc = lib.supir_gemm_bf16_qkv(a.data_ptr(), w.data_ptr(), out_qk.data_ptr(), out_vt.data_ptr(), M, N, n_split, K, lda, n_split, T, T,
-                                 _p(bias), ln_p, ln_ld, ln_slots, _p(colsum), ln_eps, _stream())
-    _lib.check(rc, "supir_gemm_bf16_qkv", lib)
-    _rec("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev, M=M, N=N, K=K, act=0, tile=36)
+
+    def launch(t, outp=None):
+        return lib.supir_gemm_bf16_qkv(a.data_ptr(), w.data_ptr(), out_qk.data_ptr(), out_vt.data_ptr(), M, N, n_split, K, lda, n_split,
+                                       T, T, _p(bias), ln_p, ln_ld, ln_slots, _p(colsum), ln_eps, _stream())
+
+    def make(t, outp=None):
+        sh = _lib.GemmShape(kind=_lib.GROUP_QKV, tile=34, M=M, N=N, K=K, rows_per_batch=T, n_split=n_split, alpha=1.0, ln_eps=ln_eps)
+        pr = _lib.GemmProblem(A=a.data_ptr(), W=w.data_ptr(), C=out_qk.data_ptr(), C2=out_vt.data_ptr(), bias=_p(bias), ln_stats=ln_p,
+                              ln_colsum=_p(colsum), lda=lda, ldc=n_split, ldc2=T, ln_ld=ln_ld, ln_slots=ln_slots)
+        return sh, pr
+
+    tkey = ("qkv", M, N, K) + _k(DT)
+    _issue(_Launch("qkv", lib, "supir_gemm_bf16_qkv", launch, key=tkey + (n_split, T, ln_eps, ln is not None), tkey=tkey, tile=36,
+                   single_tile=36, make=make, w=w, out=out_qk,
+                   trace=("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), dict(M=M, N=N, K=K, act=0, tile=36)),
+                   keep=(a, w, bias, out_qk, out_vt, ln.buf if ln is not None else None, colsum)))
     return out_qk, out_vt
 
 
@@ -506,7 +778,7 @@ def choose(key, fns):
     c = _CHOICE.get(key)
     if c is not None:
         return c
-    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+    if not AUTOTUNE or _DEFER is not None or torch.cuda.is_current_stream_capturing():
         return 0
     times = []
     for i, fn in enumerate(fns):
@@ -533,24 +805,36 @@ def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
     assert M == B * T and DT in HALF_TYPES and w.dtype == DT
     N = w.shape[0]
     if out is None:
+        if Tpad != T:
+            _no_defer("gemm_t(with padding)")
         out = torch.zeros(B, N, Tpad, dtype=DT, device=a.device) if Tpad != T else \
             torch.empty(B, N, Tpad, dtype=DT, device=a.device)
     assert out.dtype == DT
 
-    def launch(t):
-        return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, lda, Tpad, _p(bias), 0, 0, T, 0, 0, 0, 2,
-                                   1.0, t, _stream())
+    def launch(t, outp=None):
+        return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, Tpad, _p(bias),
+                                   0, 0, T, 0, 0, 0, 2, 1.0, t, _stream())
 
+    key = ("gemm", M, N, K, 0, 2) + _k(DT)
+    cands = ()
+    single_tile = tile
     if tile == -1:
         cands = _gemm_candidates(M, N, K, 0, 2, Tpad, epilogue_ok=(lda % 8 == 0 and T % 4 == 0))
-        tile = _autotune(("gemm", M, N, K, 0, 2) + _k(DT), cands, launch)
+        tile = _autotune(key, cands, launch)
         if tile >= 32 and tile not in cands:
             tile = -1
-    _pf(w)
-    ev = _ev()
-    rc = launch(tile)
-    _lib.check(rc, "supir_gemm_bf16(T)", lib)
-    _rec("gemm_t", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev, M=M, N=N, K=K, act=0, tile=tile)
+        single_tile = tile
+        tile = _pair_tile(key, tile, cands)
+
+    def make(t, outp=None):
+        sh = _lib.GemmShape(kind=_lib.GROUP_GEMM, tile=t, M=M, N=N, K=K, rows_per_batch=T, act=0, out_mode=2, alpha=1.0)
+        pr = _lib.GemmProblem(A=a.data_ptr(), W=w.data_ptr(), C=(out if outp is None else outp).data_ptr(), bias=_p(bias), lda=lda, ldc=Tpad)
+        return sh, pr
+
+    _issue(_Launch("gemm", lib, "supir_gemm_bf16(T)", launch, key=key + (T, Tpad), tkey=key, tile=tile, single_tile=single_tile,
+                   cands=cands, make=make, w=w, out=out,
+                   trace=("gemm_t", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), dict(M=M, N=N, K=K, act=0, tile=tile)),
+                   keep=(a, w, bias, out)))
     return out
 
 
@@ -587,11 +871,15 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
         ld_rb = rowbias.stride(0)
     om = 0 if out.dtype == DT else 1
 
-    def launch(t):
-        return lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cin, ldx, Cout, ldy, OH, OW, stride,
-                                      pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb, _p(residual), ldr,
-                                      act, om, alpha, t, _stream())
+    def launch(t, outp=None):
+        return lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), (out if outp is None else outp).data_ptr(), B, H, W, Cin, ldx, Cout,
+                                      ldy, OH, OW, stride, pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb,
+                                      _p(residual), ldr, act, om, alpha, t, _stream())
 
+    inplace = residual is not None and residual.data_ptr() == out.data_ptr()
+    key = ("conv", B, H, W, Cin, Cout, stride, bool(upsample)) + _k(DT)
+    cands = ()
+    single_tile = tile
     if tile == -1:
         M_ = B * OH * OW
         cands = [0, 1, 2, 3, 4, 5, 6]
@@ -600,21 +888,31 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
             for t, (bm, bn, ks, s_) in _G16.items():   # same predicate as supir_gemm16_supported(conv)
                 if t in G16_TILES and M_ % bm == 0 and Cout % bn == 0 and Cin % (64 * ks) == 0 and (9 * Cin // 64) // ks >= s_ - 1:
                     cands.append(t)
-        key = ("conv", B, H, W, Cin, Cout, stride, bool(upsample)) + _k(DT)
-        if residual is not None and residual.data_ptr() == out.data_ptr():
+        cands = tuple(cands)
+        if inplace:
             tile = _TUNE.get(key, -1)
         else:
-            tile = _autotune(key, tuple(cands), launch)
+            tile = _autotune(key, cands, launch)
         if tile >= 32 and tile not in cands:
             tile = -1
-    _pf(w)
-    part = _gn_part_request(lib, tile, B, OH * OW, Cout, x.device) if (gn_part and om == 0) else None
-    ev = _ev()
-    rc = launch(tile)
-    _lib.check(rc, "supir_conv3x3_bf16", lib)
+        single_tile = tile
+        tile = _pair_tile(key, tile, cands)
+    part = _gn_part_alloc(tile, B, OH * OW, Cout, x.device) if (gn_part and om == 0) else None
+
+    def make(t, outp=None):
+        sh = _lib.GemmShape(kind=_lib.GROUP_CONV3X3, tile=t, act=act, out_mode=om, alpha=alpha, B=B, H=H, W=W, Cin=Cin, Cout=Cout, OH=OH,
+                            OW=OW, stride=stride, pad_t=pad[0], pad_l=pad[1], upsample=1 if upsample else 0)
+        pr = _lib.GemmProblem(A=x.data_ptr(), W=w.data_ptr(), C=(out if outp is None else outp).data_ptr(), bias=_p(bias),
+                              rowbias=_p(rowbias), residual=_p(residual), gn_partials_out=None if part is None else part.buf.data_ptr(),
+                              lda=ldx, ldc=ldy, ldr=ldr, ld_rowbias=ld_rb)
+        return sh, pr
+
     M = B * OH * OW
-    _rec("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout), ev, M=M, N=Cout, K=9 * Cin,
-         act=act, tile=tile)
+    _issue(_Launch("conv", lib, "supir_conv3x3_bf16", launch, key=key + (OH, OW, pad, act, om, alpha, part is not None), tkey=key, tile=tile,
+                   single_tile=single_tile, cands=cands, make=make, w=w, part=part, out=out, inplace=inplace,
+                   trace=("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout),
+                          dict(M=M, N=Cout, K=9 * Cin, act=act, tile=tile)),
+                   keep=(x, w, bias, rowbias, residual, out, part)))
     return (out, part) if gn_part else out
 
 
@@ -632,15 +930,22 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     if out is None:
         out = torch.empty(B, Tq, H * 64, dtype=DT, device=q.device)
     assert out.dtype == DT
-    ev = _ev()
-    if causal:
-        rc = lib.supir_flash_attn_d64_ex(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
-                                         out.stride(-2), 0.125, 1, _stream())
-    else:
-        rc = lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
-                                      out.stride(-2), 0.125, _stream())
-    _lib.check(rc, "supir_flash_attn_d64", lib)
-    _rec("attn", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * H * 64 * (2 * Tq + 2 * Tk), ev, B=B, H=H, Tq=Tq, Tk=Tk)
+    ldo = out.stride(-2)
+
+    def launch(t, outp=None):
+        if causal:
+            return lib.supir_flash_attn_d64_ex(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
+                                               ldo, 0.125, 1, _stream())
+        return lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
+                                        ldo, 0.125, _stream())
+
+    def make():
+        return (B, H, Tq, 0.125), _lib.AttnProblem(Q=q.data_ptr(), K=k.data_ptr(), Vt=vt.data_ptr(), O=out.data_ptr(), Tk=Tk, ldq=ldq,
+                                                   ldk=ldk, ldvt=ldvt, ldo=ldo, flags=1 if causal else 0)
+
+    _issue(_Launch("attn", lib, "supir_flash_attn_d64", launch, key=("attn", B, H, Tq) + _k(DT), make=make,
+                   trace=("attn", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * H * 64 * (2 * Tq + 2 * Tk), dict(B=B, H=H, Tq=Tq, Tk=Tk)),
+                   keep=(q, k, vt, out)))
     return out
 
 
@@ -673,6 +978,7 @@ def flash_attn_d512(q, k, vt, Tk, out=None):
     if out is None:
         out = torch.empty(B, Tq, 512, dtype=DT, device=q.device)
     assert out.dtype == DT and out.stride(-1) == 1 and out.stride(0) == Tq * out.stride(1)
+    _no_defer("flash_attn_d512")
     ev = _ev()
     rc = lib.supir_flash_attn_d512(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, Tq, Tk, q.stride(1), k.stride(1),
                                    vt.shape[-1], out.stride(1), 512 ** -0.5, _stream())
@@ -693,6 +999,7 @@ def softmax_rows(s, scale, out=None, valid=None, dtype=None):
     assert s.dtype == torch.float32 and s.stride(1) == 1 and DT in HALF_TYPES
     if out is None:
         out = torch.empty(rows, Tp, dtype=DT, device=s.device)
+    _no_defer("softmax_rows")
     ev = _ev()
     rc = lib.supir_softmax_rows(s.data_ptr(), out.data_ptr(), rows, T, Tp, s.stride(0), out.stride(0), scale, _stream())
     _lib.check(rc, "supir_softmax_rows", lib)
@@ -709,6 +1016,7 @@ def groupnorm_stats(x):
     B = x.shape[0]
     HW = int(math.prod(x.shape[1:-1]))
     _, C, ld = _rows_ld(x)
+    _no_defer("groupnorm_stats")
     ws = _gn_workspace(B, x.device)
     out = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
     rc = lib.supir_groupnorm_stats(x.data_ptr(), 0, B, HW, C, C, ld, 0, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
@@ -744,22 +1052,35 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
         assert Cm == C and Cm2 == C and ldm == ldm2
     use_parts = (part is not None and given is None and (x2 is None or part2 is not None) and (C // 32) % 10 == 0 and C1 % 10 == 0
                  and part.C == C1 and part.buf.shape[0] == B and (part2 is None or (part2.C == C - C1 and part2.buf.shape[0] == B)))
-    ev = _ev()
-    if use_parts:
-        rc = lib.supir_groupnorm_nhwc_parts(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
-                                            beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
-                                            out.data_ptr(), ldo, part.buf.data_ptr(), part.nchunk,
-                                            0 if part2 is None else part2.buf.data_ptr(), 0 if part2 is None else part2.nchunk,
-                                            _stream())
-        _lib.check(rc, "supir_groupnorm_nhwc_parts", lib)
-    else:
-        ws = _gn_workspace(B, x.device)
-        rc = lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
-                                      beta.data_ptr(), eps, 1 if silu else 0, _p(mod_g), _p(mod_b), ldm, control_scale,
-                                      out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _p(given), _stream())
-        _lib.check(rc, "supir_groupnorm_nhwc", lib)
+    act = 1 if silu else 0
+    # own statistics: partial-sum workspace.  Recorded launches may run two to a grid (paired_run): each gets its own.
+    ws = None if use_parts else (torch.empty(B * 1024 * 64, dtype=torch.float32, device=x.device) if _DEFER is not None
+                                 else _gn_workspace(B, x.device))
+
+    def launch(t, outp=None):
+        if use_parts:
+            return lib.supir_groupnorm_nhwc_parts(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
+                                                  beta.data_ptr(), eps, act, _p(mod_g), _p(mod_b), ldm, control_scale,
+                                                  out.data_ptr(), ldo, part.buf.data_ptr(), part.nchunk,
+                                                  0 if part2 is None else part2.buf.data_ptr(), 0 if part2 is None else part2.nchunk,
+                                                  _stream())
+        return lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
+                                        beta.data_ptr(), eps, act, _p(mod_g), _p(mod_b), ldm, control_scale,
+                                        out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _p(given), _stream())
+
+    def make():
+        pr = _lib.GnProblem(x1=x.data_ptr(), x2=_p(x2), x1raw=_p(x1raw), x2raw=_p(x2raw), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
+                            mod_g=_p(mod_g), mod_b=_p(mod_b), out=out.data_ptr(), part1=part.buf.data_ptr() if use_parts else None,
+                            part2=part2.buf.data_ptr() if (use_parts and part2 is not None) else None, workspace=_p(ws), C1=C1, ld1=ld1,
+                            ld2=ld2, ldm=ldm, ldo=ldo, nchunk1=part.nchunk if use_parts else 0,
+                            nchunk2=part2.nchunk if (use_parts and part2 is not None) else 0, control_scale=control_scale)
+        return (B, HW, C, eps, act), pr
+
     n = B * HW * C
-    _rec("groupnorm", 0, 2.0 * n * (2 + (2 if mod_g is not None else 0)), ev, B=B, HW=HW, C=C, parts=use_parts)
+    _issue(_Launch("gn" if given is None else None, lib, "supir_groupnorm_nhwc_parts" if use_parts else "supir_groupnorm_nhwc", launch,
+                   key=("gn", B, HW, C, eps, act, use_parts) + _k(DT), make=make,
+                   trace=("groupnorm", 0, 2.0 * n * (2 + (2 if mod_g is not None else 0)), dict(B=B, HW=HW, C=C, parts=use_parts)),
+                   keep=(x, x2, x1raw, x2raw, gamma, beta, mod_g, mod_b, out, ws, given, part, part2)))
     return out
 
 
@@ -772,11 +1093,12 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     if out is None:
         out = torch.empty(*x.shape, dtype=DT, device=x.device)
     _, _, ldy = _rows_ld(out)
-    ev = _ev()
-    rc = lib.supir_layernorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, ldx, ldy, eps,
-                             _stream())
-    _lib.check(rc, "supir_layernorm", lib)
-    _rec("layernorm", 0, 4.0 * rows * C, ev, rows=rows, C=C)
+
+    def launch(t, outp=None):
+        return lib.supir_layernorm(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, C, ldx, ldy, eps, _stream())
+
+    _issue(_Launch(None, lib, "supir_layernorm", launch, trace=("layernorm", 0, 4.0 * rows * C, dict(rows=rows, C=C)),
+                   keep=(x, out, gamma, beta)))
     return out
 
 
@@ -797,6 +1119,7 @@ def conv3x3_smallcin(x_nchw, w, bias, add=None, out=None, dtype=None):
     ld_add = 0
     if add is not None:
         _, _, ld_add = _rows_ld(add)
+    _no_defer("conv3x3_smallcin")
     ev = _ev()
     rc = lib.supir_conv3x3_smallcin(x_nchw.data_ptr(), w.data_ptr(), _p(bias), _p(add), out.data_ptr(), B, Cin, H, W, Cout,
                                     ld_add, ldo, _stream())
@@ -816,6 +1139,7 @@ def conv3x3_smallcout(x, w9, bias, out=None):
     assert DT in HALF_TYPES and w9.shape == (9, Cout, Cin) and w9.dtype == DT and w9.is_contiguous()
     if out is None:
         out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    _no_defer("conv3x3_smallcout")
     ev = _ev()
     rc = lib.supir_conv3x3_smallcout(x.data_ptr(), w9.data_ptr(), _p(bias), out.data_ptr(), B, Cin, H, W, Cout, ldx,
                                      _stream())
@@ -833,6 +1157,7 @@ def pointwise_nchw(x, w, bias, in_scale=1.0):
     Cout = w.shape[0]
     w2 = w.reshape(Cout, Cin).contiguous()
     out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    _no_defer("pointwise_nchw")
     rc = lib.supir_pointwise_nchw(x.data_ptr(), w2.data_ptr(), _p(bias), out.data_ptr(), B, Cin, Cout, H * W, in_scale,
                                   _stream())
     _lib.check(rc, "supir_pointwise_nchw")
@@ -850,6 +1175,7 @@ def edm_step_pre(x, eps, s_noise, noise_mul, c_in, reps):
     n = x.numel()
     x_hat = torch.empty_like(x) if eps is not None else x
     net_in = torch.empty((reps * x.shape[0],) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    _no_defer("edm_step_pre")
     rc = lib.supir_edm_step_pre(x.data_ptr(), _p(eps), float(s_noise), float(noise_mul), float(c_in),
                                 x_hat.data_ptr() if eps is not None else 0, net_in.data_ptr(), n, reps, _stream())
     _lib.check(rc, "supir_edm_step_pre", lib)
@@ -869,6 +1195,7 @@ def edm_step_post(net_out, x_hat, x_center, c_out, c_skip, cfg_scale, restore_mu
             x_center = x_center.float().contiguous()
         assert x_center.shape == x_hat.shape
     out = torch.empty_like(x_hat)
+    _no_defer("edm_step_post")
     rc = lib.supir_edm_step_post(net_out.data_ptr(), x_hat.data_ptr(), _p(x_center), float(c_out), float(c_skip), float(cfg_scale),
                                  float(restore_mul), float(sigma_hat), float(dt), out.data_ptr(), n, reps, _stream())
     _lib.check(rc, "supir_edm_step_post", lib)

@@ -1,0 +1,264 @@
+"""Grouped (two-problem) launches and the record / pair machinery behind them (ops.paired_run, supir_gemm_grouped,
+supir_flash_attn_d64_grouped, supir_groupnorm_grouped).
+
+A grouped launch runs the same kernel code on the same tile as the two single launches it replaces -- only the workgroup -> problem /
+XCD map differs -- so every output (C, V^T, LayerNorm row statistics, GroupNorm unit partials) must be BITWISE what the single
+launches produce.  The network-level tests then hold the paired ControlWrapper call to the unpaired one (different tiles may run,
+so that comparison is at the bf16 noise floor, not bitwise) and check that recording + issuing one by one changes nothing at all.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from supir_amd import ops  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _eq(x, y, name):
+    if isinstance(x, (tuple, list)):
+        assert len(x) == len(y)
+        for i, (p, q) in enumerate(zip(x, y)):
+            _eq(p, q, f"{name}[{i}]")
+    elif isinstance(x, ops.RowStats):
+        assert x.slots == y.slots and x.ld == y.ld
+        _eq(x.buf[:, :x.slots], y.buf[:, :y.slots], name + ".rowstats")
+    elif isinstance(x, ops.GnPart):
+        assert x.nchunk == y.nchunk and x.C == y.C
+        n = x.buf.shape[0] * x.nchunk * (x.C // 10) * 2
+        _eq(x.buf.reshape(-1)[:n], y.buf.reshape(-1)[:n], name + ".gn_partials")
+    elif x is None:
+        assert y is None
+    else:
+        assert x.shape == y.shape and torch.isfinite(x.float()).all(), name
+        assert torch.equal(x, y), f"{name}: grouped launch differs from the single launches (max |d| {(x.float() - y.float()).abs().max().item():.3e})"
+
+
+def _both(fa, fb):
+    """(fa(), fb()) issued one by one, then through paired_run; returns both result pairs and how many grouped launches were issued."""
+    single = (fa(), fb())
+    torch.cuda.synchronize()
+    tr = ops.start_trace()
+    paired = ops.paired_run(fa, fb)
+    torch.cuda.synchronize()
+    ops.stop_trace()
+    return single, paired, sum(1 for r in tr if r.get("group") == 2)
+
+
+@pytest.mark.parametrize("tile,M,N,K,groups", [(33, 2048, 1280, 1280, 5), (35, 2048, 1280, 1280, 5), (34, 2048, 1280, 1280, 5),
+                                               (33, 2048, 1280, 5120, 5), (33, 8192, 640, 2560, 5), (35, 256, 160, 256, 5),
+                                               (33, 128, 160, 128, 0)])   # one tile per problem: no grouped form, issued one by one
+def test_gemm_grouped_bitwise(tile, M, N, K, groups):
+    B = 2
+    ops_ = []
+    for s in (0, 100):
+        a = rnd(M, K, seed=s).to(BF)
+        w = rnd(N, K, scale=K ** -0.5, seed=s + 1).to(BF)
+        bias = rnd(N, seed=s + 2)
+        res = rnd(M, N, seed=s + 3).to(BF)
+        rb = rnd(B, N, seed=s + 4).to(BF)
+        ops_.append((a, w, bias, res, rb))
+
+    def run(i):
+        a, w, bias, res, rb = ops_[i]
+        o1 = ops.gemm(a, w, bias, tile=tile)
+        o2 = ops.gemm(a, w, bias, residual=res, alpha=0.5, rowbias=rb, rows_per_batch=M // B, act=1, tile=tile, gn_part=True)
+        o3 = ops.gemm_ln(a, w, bias, residual=res, emit_stats=True, tile=tile)
+        o4 = ops.gemm_ln(a, w, bias, ln=o3[1], colsum=bias, tile=tile)                  # consumer of the statistics just emitted
+        o5 = ops.gemm_t(a, w, bias, B, M // B, M // B, tile=tile)
+        return o1, o2, o3, o4, o5
+
+    single, paired, ngroup = _both(lambda: run(0), lambda: run(1))
+    assert ngroup == groups
+    _eq(single, paired, f"gemm tile {tile} {(M, N, K)}")
+    # and against fp32 math, so that "bitwise equal" is not two identical wrong answers
+    a, w, bias, _, _ = ops_[1]
+    ref = a.float() @ w.float().T + bias
+    err = ((paired[1][0].float() - ref).norm() / ref.norm()).item()
+    assert err <= 4e-3, err
+
+
+@pytest.mark.parametrize("tile,M,N,K", [(34, 2048, 2560, 1280), (37, 2048, 10240, 1280), (37, 512, 640, 128)])
+def test_geglu_grouped_bitwise(tile, M, N, K):
+    from supir_amd import weights as Wt
+    prob = []
+    for s in (0, 50):
+        a = rnd(M, K, seed=s).to(BF)
+        w = rnd(N, K, scale=K ** -0.5, seed=s + 1).to(BF)
+        bias = rnd(N, seed=s + 2)
+        w32, b32 = Wt.interleave_geglu(w, bias, 32)
+        w16, b16 = Wt.interleave_geglu(w, bias, 16)
+        prob.append((a, w32, b32, (w16, b16), w, bias))
+    single, paired, ngroup = _both(lambda: ops.gemm(prob[0][0], prob[0][1], prob[0][2], act=2, alt16=prob[0][3], tile=tile),
+                                   lambda: ops.gemm(prob[1][0], prob[1][1], prob[1][2], act=2, alt16=prob[1][3], tile=tile))
+    assert ngroup == 1
+    _eq(single, paired, f"geglu tile {tile}")
+    a, _, _, _, w, bias = prob[1]
+    y = a.float() @ w.float().T + bias
+    ref = y[:, :N // 2] * torch.nn.functional.gelu(y[:, N // 2:])
+    assert ((paired[1].float() - ref).norm() / ref.norm()).item() <= 4e-3
+
+
+@pytest.mark.parametrize("tile,B,H,W,Cin,Cout,stride,up", [(35, 2, 32, 32, 1280, 1280, 1, False), (33, 2, 32, 32, 1280, 1280, 1, False),
+                                                            (33, 2, 64, 64, 640, 640, 1, False), (34, 2, 128, 128, 320, 320, 1, False),
+                                                            (33, 2, 64, 64, 640, 640, 2, False), (33, 2, 32, 32, 1280, 1280, 1, True),
+                                                            (33, 2, 16, 16, 128, 160, 1, False)])
+def test_conv_grouped_bitwise(tile, B, H, W, Cin, Cout, stride, up):
+    prob = []
+    for s in (0, 7):
+        x = rnd(B, H, W, Cin, seed=s).to(BF)
+        w = rnd(Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5, seed=s + 1).to(BF)
+        bias = rnd(Cout, seed=s + 2)
+        rb = rnd(B, Cout, seed=s + 3).to(BF)
+        prob.append((x, w, bias, rb))
+
+    def run(i):
+        x, w, bias, rb = prob[i]
+        return ops.conv3x3(x, w, bias, stride=stride, pad=(1, 1), upsample=up, rowbias=rb, tile=tile, gn_part=True)
+
+    single, paired, ngroup = _both(lambda: run(0), lambda: run(1))
+    assert ngroup == 1
+    _eq(single, paired, f"conv tile {tile}")
+    x, w, bias, rb = prob[1]
+    xin = x.float().permute(0, 3, 1, 2)
+    if up:
+        xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(xin, w.float().permute(0, 3, 1, 2), bias, stride=stride, padding=1) + rb.float()[:, :, None, None]
+    got = paired[1][0].float().permute(0, 3, 1, 2)
+    assert ((got - ref).norm() / ref.norm()).item() <= 4e-3
+
+
+def test_qkv_grouped_bitwise():
+    B, T, C = 2, 1024, 1280
+    prob = []
+    for s in (0, 9):
+        a = rnd(B * T, C, seed=s).to(BF)
+        w = rnd(3 * C, C, scale=C ** -0.5, seed=s + 1).to(BF)
+        prob.append((a, w))
+    key = ("pair", "qkv", B * T, 3 * C, C)
+    ops._TUNE[key] = 36      # group without timing
+    try:
+        single, paired, ngroup = _both(lambda: ops.gemm_qkv(prob[0][0], prob[0][1], None, B, T, 2 * C),
+                                       lambda: ops.gemm_qkv(prob[1][0], prob[1][1], None, B, T, 2 * C))
+    finally:
+        del ops._TUNE[key]
+    assert ngroup == 1
+    _eq(single, paired, "qkv")
+    a, w = prob[1]
+    ref = a.float() @ w.float().T
+    qk, vt = paired[1]
+    assert ((qk.float().reshape(B * T, -1) - ref[:, :2 * C]).norm() / ref[:, :2 * C].norm()).item() <= 4e-3
+    v = vt.float().permute(0, 2, 1).reshape(B * T, C)
+    assert ((v - ref[:, 2 * C:]).norm() / ref[:, 2 * C:].norm()).item() <= 4e-3
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk", [(2, 20, 1024, 1024), (2, 10, 4096, 4096), (2, 20, 1024, 77), (1, 3, 200, 130)])
+def test_flash_attn_grouped_bitwise(B, H, Tq, Tk):
+    Tp = (Tk + 63) // 64 * 64
+    prob = []
+    for s in (0, 5):
+        q = rnd(B, Tq, H * 64, seed=s).to(BF)
+        k = rnd(B, Tk, H * 64, seed=s + 1).to(BF)
+        vt = torch.zeros(B, H * 64, Tp, dtype=BF, device=DEV)
+        vt[:, :, :Tk] = rnd(B, H * 64, Tk, seed=s + 2).to(BF)
+        prob.append((q, k, vt))
+    single, paired, ngroup = _both(lambda: ops.flash_attn(*prob[0], B, H, Tq, Tk), lambda: ops.flash_attn(*prob[1], B, H, Tq, Tk))
+    assert ngroup == 1
+    _eq(single, paired, "attn")
+    q, k, vt = prob[1]
+    qh = q.float().view(B, Tq, H, 64).transpose(1, 2)
+    kh = k.float().view(B, Tk, H, 64).transpose(1, 2)
+    vh = vt.float()[:, :, :Tk].reshape(B, H, 64, Tk).transpose(2, 3)
+    ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Tq, H * 64)
+    assert ((paired[1].float() - ref).norm() / ref.norm()).item() <= 6e-3
+
+
+def test_groupnorm_grouped_bitwise():
+    B, H, W, C = 2, 32, 32, 1280
+    prob = []
+    for s in (0, 3):
+        x = rnd(B, H, W, C, seed=s).to(BF)
+        w = rnd(C, C, scale=C ** -0.5, seed=s + 1).to(BF)
+        g, b = 1 + 0.1 * rnd(C, seed=s + 2), 0.1 * rnd(C, seed=s + 3)
+        prob.append((x, w, g, b))
+
+    def run(i):
+        x, w, g, b = prob[i]
+        n1 = ops.groupnorm(x, g, b, 1e-5, silu=True)                                         # own statistics: two launches
+        y, part = ops.gemm(n1.view(B * H * W, C), w, None, rows_per_batch=H * W, tile=33, gn_part=True)
+        assert part is not None
+        n2 = ops.groupnorm(y.view(B, H, W, C), g, b, 1e-5, part=part)                         # statistics from the producer
+        return n1, n2
+
+    single, paired, ngroup = _both(lambda: run(0), lambda: run(1))
+    assert ngroup == 3
+    _eq(single, paired, "groupnorm")
+    x, _, g, b = prob[1]
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(x.float().permute(0, 3, 1, 2), 32, g, b, 1e-5)).permute(0, 2, 3, 1)
+    assert ((paired[1][0].float() - ref).norm() / ref.norm()).item() <= 4e-3
+
+
+def test_paired_run_falls_back_when_the_branches_differ():
+    """Different shapes at the same position: issued one by one, in order, results unchanged."""
+    a1, a2 = rnd(256, 256).to(BF), rnd(512, 256, seed=1).to(BF)
+    w = rnd(160, 256, scale=1 / 16, seed=2).to(BF)
+    s1, s2 = ops.gemm(a1, w, tile=35), ops.gemm(a2, w, tile=35)
+    tr = ops.start_trace()
+    p1, p2 = ops.paired_run(lambda: ops.gemm(a1, w, tile=35), lambda: (ops.gemm(a2, w, tile=35), ops.layernorm(a2, torch.ones(256, device=DEV), torch.zeros(256, device=DEV)))[0])
+    ops.stop_trace()
+    assert all(r.get("group", 1) == 1 for r in tr) and len(tr) == 3
+    assert torch.equal(s1, p1) and torch.equal(s2, p2)
+
+
+# ------------------------------------------------------------------------------------------------------- network level
+def _net_inputs(latent):
+    from tests.helpers import synth_tensor
+    B = 2
+    x = synth_tensor("xt", (B, 4, latent, latent)).to(DEV)
+    cond = {"crossattn": synth_tensor("context", (B, 77, 2048)).to(DEV), "vector": synth_tensor("vector", (B, 2816)).to(DEV),
+            "control": synth_tensor("lq", (B, 4, latent, latent)).to(DEV)}
+    t = torch.tensor([500, 37], dtype=torch.int64, device=DEV)
+    return x, t, cond
+
+
+def test_paired_branches_network_call():
+    """One ControlWrapper call (reduced depth, real widths, latent 32): (a) record + issue one by one (ops.PAIR off) is bitwise the
+    two-stream path; (b) grouped launches stay at the bf16 noise floor of it; (c) hipGraph replay of the paired call is bitwise the
+    eager paired call, run to run."""
+    from tests.helpers import build_unet, rel_l2
+    wrap = build_unet(depth=(1, 1, 2), device=DEV)
+    x, t, cond = _net_inputs(32)
+    with torch.no_grad():
+        wrap.pair_branches = False
+        wrap(x, t, cond, 1.0)                       # cold call: serial, fills caches / autotune
+        base = wrap(x, t, cond, 1.0).clone()
+        wrap.pair_branches = True
+        old = ops.PAIR
+        ops.PAIR = False
+        try:
+            rec = wrap(x, t, cond, 1.0).clone()
+        finally:
+            ops.PAIR = old
+        assert torch.equal(base, rec), "recording the two branches and issuing their launches one by one must not change a bit"
+        wrap(x, t, cond, 1.0)                       # pair autotune pass
+        tr = ops.start_trace()
+        p1 = wrap(x, t, cond, 1.0).clone()
+        ops.stop_trace()
+        p2 = wrap(x, t, cond, 1.0).clone()
+        ngroup = sum(1 for r in tr if r.get("group") == 2)
+        assert ngroup >= 20, f"only {ngroup} grouped launches in a paired call"
+        assert torch.equal(p1, p2)
+        err = rel_l2(p1, base)
+        assert err <= 6e-3, err
+        wrap.enable_graph(True)
+        g1 = wrap(x, t, cond, 1.0).clone()
+        g2 = wrap(x, t, cond, 1.0).clone()
+        wrap.enable_graph(False)
+        assert torch.equal(g1, g2) and torch.equal(g1, p1), "hipGraph replay of the paired call != eager paired call"

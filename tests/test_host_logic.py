@@ -255,11 +255,12 @@ def test_weight_prefetch_plan_is_one_shot_per_op_and_wraps(monkeypatch):
         for w in ws:
             ops._pf(w)
         pf.end()
-        assert pf.plan == [(w.data_ptr(), w.numel() * 2) for w in ws] and calls == []
+        # one plan entry per LAUNCH: a tuple with the weight of each problem of that launch (one for a plain launch)
+        assert pf.plan == [((w.data_ptr(), w.numel() * 2),) for w in ws] and calls == []
         pf.begin_replay(torch.device("cpu"))
         for w in ws:
             ops._pf(w)
-        assert calls == [pf.plan[1], pf.plan[2], pf.plan[0]]
+        assert calls == [pf.plan[1][0], pf.plan[2][0], pf.plan[0][0]]
         calls.clear()
         pf.end()
         assert calls == [(None, 0)]                      # pending request cancelled
@@ -271,6 +272,21 @@ def test_weight_prefetch_plan_is_one_shot_per_op_and_wraps(monkeypatch):
         calls.clear()
         ops._pf(ws[0])                                   # no pass active
         assert calls == []
+        # grouped launches (ops.paired_run): a launch of two problems prefetches, per problem, the weight the SAME problem slot of
+        # the next launch consumes; at a pair -> single transition only problem 0 has something to fetch
+        pf.begin_record()
+        assert ops._pf_group([ws[0], ws[1]]) == [None, None]
+        assert ops._pf_group([ws[2], ws[0]]) == [None, None]
+        ops._pf(ws[1])
+        pf.end()
+        assert [len(g) for g in pf.plan] == [2, 2, 1]
+        pf.begin_replay(torch.device("cpu"))
+        assert ops._pf_group([ws[0], ws[1]]) == [pf.plan[1][0], pf.plan[1][1]]
+        assert ops._pf_group([ws[2], ws[0]]) == [pf.plan[2][0], None]
+        calls.clear()
+        ops._pf(ws[1])                                   # wraps to the first launch: its problem-0 weight
+        assert calls == [pf.plan[0][0]]
+        pf.end()
     finally:
         ops.set_prefetch(None)
 
