@@ -91,7 +91,7 @@ class ControlWrapper(nn.Module):
                 cm, dm = self.control_model, self.diffusion_model
                 emb_c, h_c = cm.prologue(ckw["x"], t, x, vec)
                 emb_u, h_u = dm.encode_prologue(x, t, vec)
-                control, enc = ops.paired_run(lambda: cm.body(h_c, emb_c, ctx), lambda: dm.encode_body(h_u, emb_u, ctx))
+                control, enc = ops.paired_run(lambda: cm.body(h_c, emb_c, ctx), lambda: dm.encode_body(h_u, emb_u, ctx), side=side)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 if enc is None:

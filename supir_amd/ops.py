@@ -150,23 +150,26 @@ def save_tuning(path=None):
         _json.dump([[list(k), v] for k, v in _TUNE.items()], open(path, "w"))
 
 
-def _time_options(options, run):
+def _time_options(options, run, repeat=None):
     """Time `run(option)` for every option (HIP events on the launch stream; min over three short rounds: one round of 5 launches
     picked a 15 % slower tile now and then).  An option whose first launch returns an error code is dropped -- the C side refuses
     shapes / alignments the Python predicates may not know about, and a refused launch would otherwise time at ~0 us and win.
-    Returns [(ms, option)] of the options that ran."""
+    repeat(option, n), when given, issues the option n times back to back (options that span two streams fork / join once per
+    round, not once per launch).  Returns [(ms, option)] of the options that ran."""
+    if repeat is None:
+        def repeat(t, n):
+            for _ in range(n):
+                run(t)
     times = []
     for t in options:
         if run(t) != 0:
             continue
-        for _ in range(2):
-            run(t)
+        repeat(t, 2)
         best_t = None
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(6):
-                run(t)
+            repeat(t, 6)
             e1.record()
             e1.synchronize()
             dt = e0.elapsed_time(e1)
@@ -325,6 +328,7 @@ def _gn_part_alloc(tile, nbatch, rows_per_batch, N, device):
 _DEFER = None
 PAIR = _os.environ.get("SUPIR_PAIR", "1") != "0"            # paired_run groups launches (0: records and issues them one by one)
 PAIR_TILES = (33, 34, 35, 37)                               # tiles with a two-problem form (csrc/gemm16.hip, csrc/gemm_big.hip)
+PAIR_FORCE = False                                          # tools/pair_ab.py: drop the "two single launches" option from the timing
 PAIR_KINDS = set(_os.environ.get("SUPIR_PAIR_KINDS", "gemm,conv,qkv,attn,gn").split(","))   # A/B runs: which kinds may group
 
 
@@ -399,74 +403,93 @@ def _group_ok(L, tile):
     return M % bm == 0 and N % bn == 0 and ((M // bm) * (N // bn)) % 4 == 0
 
 
-def _pair_autotune(a, b, pkey):
-    """Grouped launch on each tile both problems can take vs the two single launches on their own tiles (-2), timed in place where
-    the pair sits in the issue order (operands are live; outputs of in-place accumulations go to scratch).  Everything a candidate
-    writes is rewritten by the real launch that follows."""
+def _group_call(a, b, tile, oa=None, ob=None, prefetch=(None, None)):
+    """One grouped launch of the recorded launches a, b (same kind, same key)."""
+    if a.kind in ("gemm", "conv", "qkv"):
+        return _gemm_group_call(a, b, tile, oa, ob, prefetch)
+    if a.kind == "attn":
+        (B, H, Tq, scale), pa = a.make()
+        _, pb = b.make()
+        return a.lib.supir_flash_attn_d64_grouped((_lib.AttnProblem * 2)(pa, pb), 2, B, H, Tq, scale, _stream())
+    (B, HW, C, eps, act), pa = a.make()
+    _, pb = b.make()
+    return a.lib.supir_groupnorm_grouped((_lib.GnProblem * 2)(pa, pb), 2, B, HW, C, eps, act, _stream())
+
+
+def _pair_autotune(a, b, pkey, side):
+    """Grouped launch (on each tile both problems can take) vs the two single launches on their own tiles (-2) -- the latter on two
+    streams when the caller runs the branches that way --, timed in place where the pair sits in the issue order (operands are live;
+    outputs of in-place accumulations go to scratch).  Everything a candidate writes is rewritten by the real launch that follows."""
     if a.kind == "qkv":
         opts = ([36] if _group_ok(a, 36) else []) + [-2]
-    else:
+    elif a.kind in ("gemm", "conv"):
         opts = [t for t in PAIR_TILES if t in a.cands and t in b.cands and _group_ok(a, t)] + [-2]
+    else:
+        opts = [0, -2]
     oa = _scratch_like(a.out) if a.inplace else None
     ob = _scratch_like(b.out) if b.inplace else None
+    main = torch.cuda.current_stream()
 
     def run(t):
         if t == -2:
             rc = a.call(a.single_tile, oa)
             return rc if rc != 0 else b.call(b.single_tile, ob)
-        return _gemm_group_call(a, b, t, oa, ob)
+        return _group_call(a, b, t, oa, ob)
 
-    times = _time_options(opts, run)
+    def repeat(t, n):
+        if t != -2 or side is None:
+            for _ in range(n):
+                run(t)
+            return
+        side.wait_stream(main)
+        for _ in range(n):
+            a.call(a.single_tile, oa)
+        with torch.cuda.stream(side):
+            for _ in range(n):
+                b.call(b.single_tile, ob)
+        main.wait_stream(side)
+
+    if PAIR_FORCE and len(opts) > 1:
+        opts = opts[:-1]
+    times = _time_options(opts, run, repeat)
     best = min(times)[1] if times else -2
     _TUNE[pkey] = best
     return best
 
 
-def _try_pair(a, b):
-    """Issue the recorded launches a, b (identical problems of the two branches) as one grouped launch if there is one for them."""
+def _try_pair(a, b, side=None):
+    """Issue the recorded launches a, b (identical problems of the two branches) as one grouped launch if there is one for them and
+    it is the faster way to run them (timed once per shape)."""
     if not PAIR or a.kind not in PAIR_KINDS:
         return False
-    capturing = torch.cuda.is_current_stream_capturing()
-    if a.kind in ("gemm", "conv", "qkv"):
-        if a.kind != "qkv" and not a.cands and not b.cands:
-            pt = a.tile if a.tile in PAIR_TILES else -2      # tiles forced by the caller: group on that tile, no timing
-        else:
-            pkey = ("pair",) + a.tkey
-            pt = _TUNE.get(pkey)
-            if pt is None and AUTOTUNE and not capturing:
-                pt = _pair_autotune(a, b, pkey)
-        if pt is None or pt == -2 or a.tile != b.tile or a.tile != pt or not _group_ok(a, pt):
-            return False   # (a winner found after this pass was recorded is used from the next pass on: tile-dependent buffers)
-        pfs = _pf_group([a.w, b.w])
-        ev = _ev()
-        rc = _gemm_group_call(a, b, a.tile, prefetch=pfs)
-        _lib.check(rc, "supir_gemm_grouped", a.lib)
-        if a.trace is not None:
-            k, fl, by, kw = a.trace
-            _rec(k, 2 * fl, 2 * by, ev, **dict(kw, group=2))
-        return True
-    ev = _ev()
-    if a.kind == "attn":
-        (B, H, Tq, scale), pa = a.make()
-        _, pb = b.make()
-        rc = a.lib.supir_flash_attn_d64_grouped((_lib.AttnProblem * 2)(pa, pb), 2, B, H, Tq, scale, _stream())
-        _lib.check(rc, "supir_flash_attn_d64_grouped", a.lib)
-    elif a.kind == "gn":
-        (B, HW, C, eps, act), pa = a.make()
-        _, pb = b.make()
-        rc = a.lib.supir_groupnorm_grouped((_lib.GnProblem * 2)(pa, pb), 2, B, HW, C, eps, act, _stream())
-        _lib.check(rc, "supir_groupnorm_grouped", a.lib)
+    gemm_like = a.kind in ("gemm", "conv", "qkv")
+    if gemm_like and a.kind != "qkv" and not a.cands and not b.cands:
+        pt = a.tile if a.tile in PAIR_TILES else -2      # tiles forced by the caller: group on that tile, no timing
     else:
+        pkey = ("pair",) + (a.tkey if gemm_like else a.key)
+        pt = _TUNE.get(pkey)
+        if pt is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+            pt = _pair_autotune(a, b, pkey, side)
+    if pt is None or pt == -2:
         return False
+    if gemm_like and (a.tile != b.tile or a.tile != pt or not _group_ok(a, pt)):
+        return False   # (a winner found after this pass was recorded is used from the next pass on: tile-dependent buffers)
+    pfs = _pf_group([a.w, b.w]) if gemm_like else (None, None)
+    ev = _ev()
+    rc = _group_call(a, b, a.tile, prefetch=pfs)
+    _lib.check(rc, {"attn": "supir_flash_attn_d64_grouped", "gn": "supir_groupnorm_grouped"}.get(a.kind, "supir_gemm_grouped"), a.lib)
     if a.trace is not None:
         k, fl, by, kw = a.trace
         _rec(k, 2 * fl, 2 * by, ev, **dict(kw, group=2))
     return True
 
 
-def paired_run(fn_a, fn_b):
+def paired_run(fn_a, fn_b, side=None):
     """Run fn_a() and fn_b() -- two independent branches built from the ops of this module -- with their launches recorded, then
-    issue the two launch lists in lockstep on the current stream, identical problems as grouped launches.  Returns (fn_a(), fn_b())."""
+    issue the two launch lists in lockstep: identical problems as ONE grouped launch on the current stream where that is the faster
+    way to run them, everything else one by one -- branch A on the current stream and, when a `side` stream is given, branch B on
+    that one (two half-machine launches overlap; a grouped launch is a join point of the two chains: in a captured hipGraph these
+    are just edges).  On return the current stream is ordered after everything issued.  Returns (fn_a(), fn_b())."""
     global _DEFER
     assert _DEFER is None, "paired_run does not nest"
     lists = []
@@ -479,15 +502,30 @@ def paired_run(fn_a, fn_b):
             _DEFER = None
         lists.append(cur)
     la, lb = lists
+    main = torch.cuda.current_stream()
+    b_on_side = False   # which stream the tail of branch B's chain is on
     for i in range(max(len(la), len(lb))):
         a = la[i] if i < len(la) else None
         b = lb[i] if i < len(lb) else None
-        if a is not None and b is not None and a.kind is not None and a.kind == b.kind and a.key == b.key and a.lib is b.lib \
-                and _try_pair(a, b):
-            continue
-        for L in (a, b):
-            if L is not None:
-                _run_single(L)
+        if a is not None and b is not None and a.kind is not None and a.kind == b.kind and a.key == b.key and a.lib is b.lib:
+            if b_on_side:
+                main.wait_stream(side)   # (needed by the grouped launch, and by the timing passes of a first visit)
+                b_on_side = False
+            if _try_pair(a, b, side):
+                continue
+        if b is not None and side is not None and not b_on_side:
+            side.wait_stream(main)       # B's next launch follows B's previous one (on main so far); taken BEFORE a is issued
+            b_on_side = True
+        if a is not None:
+            _run_single(a)
+        if b is not None:
+            if b_on_side:
+                with torch.cuda.stream(side):
+                    _run_single(b)
+            else:
+                _run_single(b)
+    if b_on_side:
+        main.wait_stream(side)
     return results[0], results[1]
 
 

@@ -29,7 +29,19 @@ t = torch.full((B,), 500, dtype=torch.int64, device=dev)
 
 
 def configure(v):
-    kinds = VARIANTS[v]
+    if v.startswith("force_"):      # every pair that has a grouped form is grouped, whatever the timing says
+        kinds = VARIANTS[v[6:]]
+        for k in list(ops._TUNE):
+            if k[0] == "pair":
+                del ops._TUNE[k]
+        ops.PAIR_FORCE = True
+    else:
+        kinds = VARIANTS[v]
+        if getattr(ops, "PAIR_FORCE", False):
+            for k in list(ops._TUNE):
+                if k[0] == "pair":
+                    del ops._TUNE[k]
+        ops.PAIR_FORCE = False
     wrap.pair_branches = kinds is not None
     ops.PAIR_KINDS = kinds or set()
 
@@ -62,28 +74,30 @@ with torch.no_grad():
     ref = outs[variants[0]]
     for v in variants[1:]:
         print(f"{v} vs {variants[0]}: rel-L2 {((outs[v] - ref).norm() / ref.norm()).item():.3e}")
-    # per-kernel breakdown of the last variant, eager, every launch event-timed (serial sum; pessimistic vs the overlapped replay)
-    configure(variants[-1])
-    wrap(x, t, cond, 1.0)
-    torch.cuda.synchronize()
-    tr = ops.start_trace(timed=True)
-    wrap(x, t, cond, 1.0)
-    torch.cuda.synchronize()
-    tr = ops.finish_timing(ops.stop_trace())
-    agg = collections.OrderedDict()
-    for r in tr:
-        k = r["kernel"]
-        if k in ("gemm", "gemm_t", "conv3x3"):
-            k = ops.gemm_tile_name(r["M"], r["N"], r.get("act", 0), conv=(k == "conv3x3"), trans=(k == "gemm_t"), tile=r.get("tile", -1),
-                                   group=r.get("group", 1)) + f" M{r['M']} N{r['N']} K{r['K']}"
-        elif r.get("group") == 2:
-            k += " x2"
-        a = agg.setdefault(k, [0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += r["us"]
-        a[2] += r["flops"]
-    tot = sum(a[1] for a in agg.values())
-    print(f"eager serial sum {tot / 1e3:.2f} ms over {len(tr)} launches ({variants[-1]})")
-    for k, (n, us, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-        print(f"  {k:78s} x{n:4d} {us / 1e3:7.3f} ms  {us / n:7.1f} us/launch  {fl / us / 1e6 if us else 0:7.1f} TF/s")
+    # per-kernel breakdown, eager, every launch event-timed (serial sum; pessimistic vs the overlapped replay)
+    for v in variants:
+        configure(v)
+        wrap(x, t, cond, 1.0)
+        torch.cuda.synchronize()
+        tr = ops.start_trace(timed=True)
+        wrap(x, t, cond, 1.0)
+        torch.cuda.synchronize()
+        tr = ops.finish_timing(ops.stop_trace())
+        agg = collections.OrderedDict()
+        for r in tr:
+            k = r["kernel"]
+            if k in ("gemm", "gemm_t", "conv3x3"):
+                k = ops.gemm_tile_name(r["M"], r["N"], r.get("act", 0), conv=(k == "conv3x3"), trans=(k == "gemm_t"), tile=r.get("tile", -1),
+                                       group=r.get("group", 1)) + f" M{r['M']} N{r['N']} K{r['K']}"
+            elif r.get("group") == 2:
+                k += " x2"
+            a = agg.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += r["us"]
+            a[2] += r["flops"]
+        tot = sum(a[1] for a in agg.values())
+        print(f"[{v}] eager serial sum {tot / 1e3:.2f} ms over {len(tr)} launches, {sum(1 for r in tr if r.get('group') == 2)} grouped")
+        if v == variants[-1]:
+            for k, (n, us, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+                print(f"  {k:78s} x{n:4d} {us / 1e3:7.3f} ms  {us / n:7.1f} us/launch  {fl / us / 1e6 if us else 0:7.1f} TF/s")
 print(json.dumps(res))
