@@ -48,11 +48,15 @@ class ControlWrapper(nn.Module):
         # per (context shape, vector shape): every graph of that shape and the eager path write the same buffers in place
         self._resident = {}
         self.overlap_branches = True   # GLVControl || UNet encoder on two HIP streams
-        # GLVControl and the UNet encoder are the same stack of layers on independent data: record both and issue every layer
-        # pair as ONE grouped launch (ops.paired_run) instead of two half-machine launches on two streams whose kernels barely
-        # overlap (profiles/r02/step_trace_summary_gemm16.txt: 1.2 ms of concurrency in a 38 ms step).  The adapters' control
-        # sides still run on the second stream beside the decoder.  Needs overlap_branches.
-        self.pair_branches = os.environ.get("SUPIR_PAIR_BRANCHES", "1") != "0"
+        # GLVControl and the UNet encoder are the same stack of layers on independent data: ops.paired_run records both and can
+        # issue a layer pair as ONE grouped launch (two problems, 128 x 160 / 256 x 160 tiles, problem q on XCDs [4q, 4q+4)).
+        # Measured (profiles/r03/pair_ab_*.log, dual_bench_*.log): the grouped kernels are faster per FLOP where they unlock the
+        # 256 x 160 tile ((2048, 2560, 1280): 18.9 -> 14.0 us per problem, (8192, 640, 2560): 32.2 -> 24.0, K = 5120: 31.5 -> 28.8,
+        # attention at 1024 tokens: 2 x 29.3 -> 36.8 us) and equal at (2048, 1280, 1280) (12.4 vs 12.2-12.8: fixed-cost bound) --
+        # but every grouped launch is a JOIN of the two chains, and two free-running chains of full-machine kernels hide each
+        # other's launch gaps and cold starts: the step is 29.9 ms on two streams, 31.2 ms with every pair grouped on one stream,
+        # 30.3-31.3 ms with the pairs chosen by timing (+20-27 us per join).  Off by default; SUPIR_PAIR_BRANCHES=1 enables it.
+        self.pair_branches = os.environ.get("SUPIR_PAIR_BRANCHES", "0") == "1"
         # Weight prefetch inside captured graphs: op i's GEMM kernel touches the weight of op i+distance on its way out
         # (ops.WeightPrefetch, supir_set_next_prefetch).  The cold-weight penalty is +25..40 % per GEMM (tools/cold_probe.py).
         # The earlier form -- a prefetch launch per op on a third stream -- cost more in graph nodes than it saved

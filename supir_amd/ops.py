@@ -328,6 +328,7 @@ def _gn_part_alloc(tile, nbatch, rows_per_batch, N, device):
 _DEFER = None
 PAIR = _os.environ.get("SUPIR_PAIR", "1") != "0"            # paired_run groups launches (0: records and issues them one by one)
 PAIR_TILES = (33, 34, 35, 37)                               # tiles with a two-problem form (csrc/gemm16.hip, csrc/gemm_big.hip)
+PAIR_MIN_GAIN = float(_os.environ.get("SUPIR_PAIR_MIN_GAIN", "0.0"))   # grouped must beat the two overlapped singles by this fraction
 PAIR_FORCE = False                                          # tools/pair_ab.py: drop the "two single launches" option from the timing
 PAIR_KINDS = set(_os.environ.get("SUPIR_PAIR_KINDS", "gemm,conv,qkv,attn,gn").split(","))   # A/B runs: which kinds may group
 
@@ -453,15 +454,21 @@ def _pair_autotune(a, b, pkey, side):
         opts = opts[:-1]
     times = _time_options(opts, run, repeat)
     best = min(times)[1] if times else -2
+    if best != -2 and PAIR_MIN_GAIN > 0.0:
+        # a grouped launch is a join point of the two chains (cross-queue edges in the captured graph): it has to win by a margin
+        sep = [ms for ms, t in times if t == -2]
+        if sep and min(times)[0] > (1.0 - PAIR_MIN_GAIN) * sep[0]:
+            best = -2
     _TUNE[pkey] = best
     return best
 
 
-def _try_pair(a, b, side=None):
-    """Issue the recorded launches a, b (identical problems of the two branches) as one grouped launch if there is one for them and
-    it is the faster way to run them (timed once per shape)."""
+def _pair_choice(a, b, side, join):
+    """How to run the recorded launches a, b (identical problems of the two branches): the tile of a grouped launch (0 for kinds
+    without tiles), or None = one by one.  Timed once per shape (pair autotune; `join()` first: the candidates run on the current
+    stream and both branches' operands must be there)."""
     if not PAIR or a.kind not in PAIR_KINDS:
-        return False
+        return None
     gemm_like = a.kind in ("gemm", "conv", "qkv")
     if gemm_like and a.kind != "qkv" and not a.cands and not b.cands:
         pt = a.tile if a.tile in PAIR_TILES else -2      # tiles forced by the caller: group on that tile, no timing
@@ -469,19 +476,24 @@ def _try_pair(a, b, side=None):
         pkey = ("pair",) + (a.tkey if gemm_like else a.key)
         pt = _TUNE.get(pkey)
         if pt is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+            join()
             pt = _pair_autotune(a, b, pkey, side)
     if pt is None or pt == -2:
-        return False
+        return None
     if gemm_like and (a.tile != b.tile or a.tile != pt or not _group_ok(a, pt)):
-        return False   # (a winner found after this pass was recorded is used from the next pass on: tile-dependent buffers)
+        return None   # (a winner found after this pass was recorded is used from the next pass on: tile-dependent buffers)
+    return pt
+
+
+def _run_pair(a, b, tile):
+    gemm_like = a.kind in ("gemm", "conv", "qkv")
     pfs = _pf_group([a.w, b.w]) if gemm_like else (None, None)
     ev = _ev()
-    rc = _group_call(a, b, a.tile, prefetch=pfs)
+    rc = _group_call(a, b, tile, prefetch=pfs)
     _lib.check(rc, {"attn": "supir_flash_attn_d64_grouped", "gn": "supir_groupnorm_grouped"}.get(a.kind, "supir_gemm_grouped"), a.lib)
     if a.trace is not None:
         k, fl, by, kw = a.trace
         _rec(k, 2 * fl, 2 * by, ev, **dict(kw, group=2))
-    return True
 
 
 def paired_run(fn_a, fn_b, side=None):
@@ -503,29 +515,34 @@ def paired_run(fn_a, fn_b, side=None):
         lists.append(cur)
     la, lb = lists
     main = torch.cuda.current_stream()
-    b_on_side = False   # which stream the tail of branch B's chain is on
+    state = {"b_on_side": False}   # which stream the tail of branch B's chain is on
+
+    def join():
+        if state["b_on_side"]:
+            main.wait_stream(side)
+            state["b_on_side"] = False
+
     for i in range(max(len(la), len(lb))):
         a = la[i] if i < len(la) else None
         b = lb[i] if i < len(lb) else None
         if a is not None and b is not None and a.kind is not None and a.kind == b.kind and a.key == b.key and a.lib is b.lib:
-            if b_on_side:
-                main.wait_stream(side)   # (needed by the grouped launch, and by the timing passes of a first visit)
-                b_on_side = False
-            if _try_pair(a, b, side):
+            tile = _pair_choice(a, b, side, join)
+            if tile is not None:
+                join()
+                _run_pair(a, b, tile)
                 continue
-        if b is not None and side is not None and not b_on_side:
+        if b is not None and side is not None and not state["b_on_side"]:
             side.wait_stream(main)       # B's next launch follows B's previous one (on main so far); taken BEFORE a is issued
-            b_on_side = True
+            state["b_on_side"] = True
         if a is not None:
             _run_single(a)
         if b is not None:
-            if b_on_side:
+            if state["b_on_side"]:
                 with torch.cuda.stream(side):
                     _run_single(b)
             else:
                 _run_single(b)
-    if b_on_side:
-        main.wait_stream(side)
+    join()
     return results[0], results[1]
 
 

@@ -16,7 +16,7 @@ from supir_amd import ops
 from tests.helpers import build_unet, synth_tensor
 
 dev = "cuda"
-VARIANTS = {"off": None, "all": {"gemm", "conv", "qkv", "attn", "gn"}, "gemm": {"gemm"}, "gemm_conv": {"gemm", "conv"},
+VARIANTS = {"qkv": {"qkv"}, "attn": {"attn"}, "off": None, "all": {"gemm", "conv", "qkv", "attn", "gn"}, "gemm": {"gemm"}, "gemm_conv": {"gemm", "conv"},
             "gemm_conv_qkv": {"gemm", "conv", "qkv"}, "gemm_attn": {"gemm", "conv", "qkv", "attn"}, "nogn": {"gemm", "conv", "qkv", "attn"},
             "noqkv": {"gemm", "conv", "attn", "gn"}, "noattn": {"gemm", "conv", "qkv", "gn"}, "record_only": set()}
 variants = sys.argv[1:] or ["off", "all"]
@@ -29,6 +29,14 @@ t = torch.full((B,), 500, dtype=torch.int64, device=dev)
 
 
 def configure(v):
+    ops.PAIR_MIN_GAIN = 0.0
+    if v.startswith("gain"):        # gain20_all: group only where the grouped launch beats the overlapped singles by 20 %
+        pct, v = v[4:].split("_", 1)
+        ops.PAIR_MIN_GAIN = int(pct) / 100.0
+        v = "force_" + v if False else v
+        for k in list(ops._TUNE):
+            if k[0] == "pair":
+                del ops._TUNE[k]
     if v.startswith("force_"):      # every pair that has a grouped form is grouped, whatever the timing says
         kinds = VARIANTS[v[6:]]
         for k in list(ops._TUNE):
@@ -37,7 +45,7 @@ def configure(v):
         ops.PAIR_FORCE = True
     else:
         kinds = VARIANTS[v]
-        if getattr(ops, "PAIR_FORCE", False):
+        if getattr(ops, "PAIR_FORCE", False) or True:
             for k in list(ops._TUNE):
                 if k[0] == "pair":
                     del ops._TUNE[k]
@@ -68,7 +76,7 @@ with torch.no_grad():
             ms = (time.time() - t0) / n * 1e3
             res.setdefault(v, []).append(round(ms, 2))
             outs[v] = o.clone()
-            print(f"rep{rep} {v}: {ms:.2f} ms/step", flush=True)
+            print(f"rep{rep} {v}: {ms:.2f} ms/step   picks " + json.dumps({str(k[1:]): tl for k, tl in ops._TUNE.items() if k[0] == "pair"}), flush=True)
     wrap.enable_graph(False)
     print("pair picks:", json.dumps({str(k[1:]): v for k, v in ops._TUNE.items() if k[0] == "pair"}))
     ref = outs[variants[0]]
