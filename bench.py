@@ -55,7 +55,7 @@ def build_model(device, rank, world):
         # ONE weight broadcast rank0 -> all over RCCL/xGMI, coalesced into 2^28-element buckets; nothing else is communicated
         from supir_amd.parallel import broadcast_module_
         t0 = time.time()
-        broadcast_module_(model, src=0, payload_dtype=torch.bfloat16)   # 7.9 GB of bf16 instead of 15.9 GB of fp32 masters
+        broadcast_module_(model, src=0)   # fp32 masters as they are (15.9 GB, once): every rank computes what a 1-GPU run computes
         torch.cuda.synchronize()
         t_bcast = time.time() - t0
     return model, t_fill, t_bcast

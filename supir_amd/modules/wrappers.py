@@ -66,6 +66,7 @@ class ControlWrapper(nn.Module):
         self._side = None
         self._warm = False
         self._dtype_noted = False
+        self._last_cdt = None
 
     @property
     def effective_dtype(self):
@@ -218,6 +219,14 @@ class ControlWrapper(nn.Module):
 
     def forward(self, x, t, c, control_scale=1, **kwargs):
         self._note_dtype()
+        if self.effective_dtype != self._last_cdt:
+            # The derived weight layouts (base.Prep) exist in ONE element type at a time: a call in the other type rebuilds them
+            # and frees the buffers the kernels of an earlier capture point at.  Graphs (and the record of what the shared text
+            # K / V^T buffers hold) therefore do not survive a change of compute dtype; they are re-captured on demand.
+            self._graphs.clear()
+            self._cs_miss.clear()
+            self._resident.clear()
+            self._last_cdt = self.effective_dtype
         with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
             if self._graph_on and not kwargs and x.is_cuda:
                 return self._forward_graph(x, t, c, control_scale)

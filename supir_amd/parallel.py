@@ -7,14 +7,19 @@ import torch
 import torch.distributed as dist
 
 
-def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), payload_dtype=None):
+def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), payload_dtype=None, round_min_elems=1 << 16):
     """Broadcast every floating parameter/buffer of `module` from rank `src`, coalesced into buckets (few large
     collectives: xGMI rings are per-link bound, so size matters more than count). Returns the number of buckets sent.
 
-    payload_dtype=torch.bfloat16: the fp32 masters travel as bf16 (7.9 GB instead of 15.9 GB for SDXL + control + VAE,
-    SURVEY.md 8(e)).  The kernels only ever read bf16 copies of the weights, so nothing the compute path sees changes; to keep
-    every rank's masters IDENTICAL (derived layouts such as LayerNorm-folded matrices are computed from the masters), rank
-    `src` rounds its own masters to the payload precision as well."""
+    payload_dtype=None (default): the masters travel in their own precision (15.9 GB of fp32 for SDXL + control + VAE, once,
+    ~0.1 s per GB-link): every rank computes exactly what a single-GPU run computes.
+
+    payload_dtype=torch.bfloat16 halves the bytes for links where that matters, at a price that must be known: only the big
+    matrices (ndim >= 2 and >= 2^16 elements: Linear / 3x3-conv weights, which the kernels consume as 16-bit copies) travel
+    rounded; biases, norm affine parameters and the <= 8-channel edge convolutions (read as fp32 by the kernels) stay fp32.  Rank
+    `src` rounds its own copies too, so all ranks hold IDENTICAL masters -- but layouts DERIVED from them in fp32 (LayerNorm-folded
+    W' = gamma (.) W, its column sums) then start from bf16-rounded W and differ from a single-GPU run at the bf16 noise floor,
+    and an fp16 compute scope loses the three mantissa bits it would have kept.  Not used by bench.py."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     tensors = [t for k, t in module.state_dict().items() if t.is_floating_point() and not any(k.endswith(s) for s in skip)]
@@ -22,8 +27,12 @@ def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), pay
     for t in tensors:
         groups.setdefault((t.dtype, t.device), []).append(t)
     sent = 0
-    for (dt, _), ts in groups.items():
-        wire = payload_dtype if (payload_dtype is not None and dt == torch.float32) else dt
+    split = {}
+    for (dt, dev), ts in groups.items():
+        for t in ts:
+            rounded = payload_dtype is not None and dt == torch.float32 and t.dim() >= 2 and t.numel() >= round_min_elems
+            split.setdefault((dt, dev, payload_dtype if rounded else dt), []).append(t)
+    for (dt, _, wire), ts in split.items():
         bucket, size = [], 0
         for t in ts + [None]:
             if t is None or (bucket and size + t.numel() > bucket_elems):

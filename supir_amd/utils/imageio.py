@@ -130,10 +130,30 @@ def resize_bicubic_u8(img_u8, out_w, out_h, want_u8=False):
     return (out_f, out_u) if want_u8 else out_f
 
 
+def unpremultiply_u8(u8):
+    """uint8 [H, W, C + 1] with premultiplied colour bands ("RGBa" / "La") -> straight alpha, Pillow's rgba2rgbA / la2lA
+    (src/libImaging/Convert.c): c' = min(255, 255 * c // alpha), colour passed through where alpha is 0 or 255."""
+    c, a = u8[..., :-1].to(torch.int32), u8[..., -1:].to(torch.int32)
+    un = torch.where((a == 0) | (a == 255), c, ((255 * c) // a.clamp(min=1)).clamp(max=255))
+    return torch.cat([un, a], dim=-1).to(torch.uint8)
+
+
 def PIL2Tensor(img, upsacle=1, min_size=1024, fix_resize=None, device="cuda"):
     """PIL.Image -> (Tensor[C, H, W] RGB in [-1, 1] on `device`, h0, w0): SUPIR/util.py:60-83 (argument names as there)."""
     w, h = img.size
     w, h, w0, h0 = target_size(w, h, upsacle, min_size, fix_resize)
+    if img.mode in ("RGBA", "LA"):
+        # Pillow resamples images with an alpha band in PREMULTIPLIED form (Image.resize: convert to "RGBa" / "La", resample every
+        # band, convert back), so the colour bands the reference gets differ from a per-band resample wherever alpha < 255.  The
+        # two conversions are 8-bit per-pixel arithmetic: the premultiply is Pillow's own convert() on the decoded image, the
+        # un-premultiply (Convert.c rgba2rgbA: CLIP8(255 * c / alpha), pass-through for alpha 0 / 255) is integer torch ops.
+        pre = np.asarray(img.convert("RGBa" if img.mode == "RGBA" else "La"))
+        _, u8 = resize_bicubic_u8(torch.from_numpy(np.ascontiguousarray(pre)).to(device), w, h, want_u8=True)
+        u8 = unpremultiply_u8(u8)
+        return _lut(u8.device)[u8.long()].permute(2, 0, 1).contiguous(), h0, w0
+    if img.mode not in ("L", "RGB"):
+        raise ValueError(f"PIL2Tensor: image mode {img.mode!r} is not supported (convert to RGB / RGBA / L / LA first): Pillow "
+                         "resamples palette, 16-bit and float modes through other code paths than the 8-bit kernel reproduces")
     arr = np.asarray(img)
     if arr.ndim == 2:
         arr = arr[:, :, None]

@@ -262,6 +262,35 @@ def test_network_call_fp16_vs_fp32_oracle(mini, monkeypatch):
     assert e_bf_after == e_bf_before                                   # the bf16 path is untouched by the excursion
 
 
+def test_captured_graphs_do_not_survive_a_change_of_compute_dtype(mini, monkeypatch):
+    """bf16 graph captured, one fp16 call (rebuilds every derived weight layout in fp16: the buffers the bf16 graph's kernels point
+    at are freed), back to bf16 WITH graphs still enabled: the wrapper must re-capture, not replay the stale graph."""
+    from supir_amd.modules import wrappers
+    monkeypatch.setattr(wrappers, "FP16_NATIVE", True)
+    B, L = 2, 32
+    x = synth_tensor("xt32", (B, 4, L, L)).to(DEV)
+    cond = {"crossattn": synth_tensor("context", (B, 77, 2048)).to(DEV), "vector": synth_tensor("vector", (B, 2816)).to(DEV),
+            "control": synth_tensor("lq32", (B, 4, L, L)).to(DEV)}
+    t = torch.tensor([500, 37], dtype=torch.int64, device=DEV)
+    with torch.no_grad():
+        eager = mini(x, t, cond, 1.0).clone()
+        mini.enable_graph(True)
+        try:
+            g0 = mini(x, t, cond, 1.0).clone()
+            assert len(mini._graphs) == 1
+            mini.dtype = HF
+            mini(x, t, cond, 1.0)
+            junk = [torch.full((1 << 22,), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(8)]   # reuse freed blocks
+            mini.dtype = torch.bfloat16
+            g1 = mini(x, t, cond, 1.0).clone()
+            g2 = mini(x, t, cond, 1.0).clone()
+            del junk
+        finally:
+            mini.enable_graph(False)
+            mini.dtype = torch.bfloat16
+    assert torch.equal(g0, eager) and torch.equal(g1, eager) and torch.equal(g2, eager)
+
+
 def test_dpmpp2m_config5_sampler_fp16(mini, monkeypatch):
     """BASELINE config 5's sampler (RestoreDPMPP2MSampler, sampling.py:422-515) driving the fp16 network vs the same sampler
     driving the fp32 oracle network, scripted noise, 4 and 8 steps: tighter than the bf16 run of the same test (3e-2)."""

@@ -82,6 +82,44 @@ def test_pil2tensor_end_to_end_vs_reference_formula():
     assert torch.equal(x.cpu(), ref)
 
 
+def test_unpremultiply_matches_pillow_convert():
+    """The un-premultiply step of the alpha path (host-checkable: no kernel involved) against Pillow's own RGBa -> RGBA / La -> LA."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, (64, 48, 1), dtype=np.uint8)
+    a[:8] = 0
+    a[8:16] = 255
+    c = (rng.integers(0, 256, (64, 48, 3)) * (a.astype(np.int64) + 3) // 258).astype(np.uint8)    # mostly <= alpha, some above
+    for mode_pre, mode, arr in (("RGBa", "RGBA", np.concatenate([c, a], -1)), ("La", "LA", np.concatenate([c[..., :1], a], -1))):
+        ref = np.asarray(Image.fromarray(np.ascontiguousarray(arr), mode_pre).convert(mode))
+        got = IO.unpremultiply_u8(torch.from_numpy(np.ascontiguousarray(arr))).numpy()
+        assert np.array_equal(got, ref), mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["RGBA", "LA"])
+def test_pil2tensor_alpha_modes_vs_reference_formula(mode):
+    """Images with an alpha band: Pillow resamples them premultiplied; PIL2Tensor must reproduce that (SUPIR/util.py:79-82)."""
+    from PIL import Image
+    rng = np.random.default_rng(21)
+    nb = 4 if mode == "RGBA" else 2
+    arr = rng.integers(0, 256, (70, 90, nb), dtype=np.uint8)
+    arr[:20, :, -1] = 255
+    arr[20:30, :, -1] = 0
+    img = Image.fromarray(arr, mode)
+    x, h0, w0 = IO.PIL2Tensor(img, upsacle=1, min_size=128)
+    w, h, _, _ = IO.target_size(90, 70, 1, 128)
+    ref = np.array(img.resize((w, h), Image.BICUBIC)).round().clip(0, 255).astype(np.uint8)
+    ref = torch.tensor(ref / 255 * 2 - 1, dtype=torch.float32).permute(2, 0, 1)
+    assert tuple(x.shape) == (nb, h, w) and torch.equal(x.cpu(), ref)
+
+
+def test_pil2tensor_refuses_modes_it_cannot_reproduce():
+    from PIL import Image
+    with pytest.raises(ValueError):
+        IO.PIL2Tensor(Image.new("P", (64, 64)), device="cpu")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("H,W,h0,w0", [(128, 192, 96, 130), (64, 64, 200, 150), (256, 320, 256, 320), (100, 60, 37, 211)])
 def test_tensor2pil_vs_torch_interpolate(H, W, h0, w0):
