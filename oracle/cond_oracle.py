@@ -8,7 +8,11 @@ fp32 PyTorch restatement of the text conditioner that feeds the hot path (SURVEY
 on a flat {reference state-dict key: tensor} dict, tokens given (the BPE tokenisers need vocabulary files that are not in this
 image).
 
-Pinning.  The arithmetic of both towers lives in third-party packages:
+Pinning.  tests/golden/golden_cond.pt holds outputs of the REFERENCE'S OWN GeneralConditionerWithControl / FrozenCLIPEmbedder /
+FrozenOpenCLIPEmbedder2 / ConcatTimestepEmbedderND (instantiated from the embedder list of options/SUPIR_v0.yaml and run on CPU by
+oracle/gen_golden_cond.py: c, uc, uc with force_uc_zero_embeddings, the legacy branch); tests/test_conditioner.py holds this file to
+them (<= 2e-5).  That pins the reference's routing, concatenation order, pooling at the argmax token, layer selection, permutes,
+force-zero and legacy handling.  The arithmetic of both towers lives in third-party packages:
   * transformers (CLIPTextModel; reference pin `transformers==4.28.1`, requirements.txt): INSTALLED here -- tests/test_conditioner.py
     checks `clip_l_hidden` against a real CLIPTextModel built from the ViT-L/14 text config with the same weights: pinned.
   * open_clip_torch (`open-clip-torch==2.17.1`, requirements.txt): NOT installed.  Its text tower is restated from the published
@@ -85,6 +89,19 @@ def openclip_g_penultimate_pooled(sd, tokens, p="model.", heads=20):
     return pen, pooled
 
 
+def openclip_g_legacy(sd, tokens, layer, p="model.", heads=20):
+    """FrozenOpenCLIPEmbedder2(legacy=True) (modules.py:565-568, 592-601): ln_final applied to the chosen layer's residual stream
+    ('last' = after all blocks, 'penultimate' = entering the last block); no pooled output."""
+    x = sd[p + "token_embedding.weight"][tokens] + sd[p + "positional_embedding"]
+    pre = p + "transformer.resblocks."
+    n_layers = 1 + max(int(k[len(pre):].split(".")[0]) for k in sd if k.startswith(pre))
+    for i in range(n_layers):
+        if i == n_layers - 1 and layer == "penultimate":
+            break
+        x = openclip_block(sd, f"{p}transformer.resblocks.{i}.", x, heads)
+    return F.layer_norm(x, x.shape[-1:], sd[p + "ln_final.weight"], sd[p + "ln_final.bias"], 1e-5)
+
+
 def timestep_embedding(t, dim, max_period=10000):
     half = dim // 2
     freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
@@ -100,11 +117,16 @@ def concat_timestep_embedder_nd(x, outdim=256):
     return timestep_embedding(x.reshape(-1), outdim).reshape(b, dims * outdim)
 
 
-def general_conditioner_with_control(sd, batch, tokens_l, tokens_g):
+def general_conditioner_with_control(sd, batch, tokens_l, tokens_g, force_zero_embeddings=(), heads_l=12, heads_g=20):
     """GeneralConditionerWithControl.forward for options/SUPIR_v0.yaml:66-106 (embedders 0..4): crossattn = CLIP-L hidden[11] ||
-    bigG penultimate (dim 2), vector = bigG pooled || 3 x ND(2 x 256) (dim 1), control passed through (:242)."""
-    z_l = clip_l_hidden(sd, tokens_l, p="embedders.0.transformer.text_model.")
-    pen, pooled = openclip_g_penultimate_pooled(sd, tokens_g, p="embedders.1.model.")
-    vec = [pooled] + [concat_timestep_embedder_nd(batch[k]) for k in ("original_size_as_tuple", "crop_coords_top_left",
-                                                                     "target_size_as_tuple")]
+    bigG penultimate (dim 2), vector = bigG pooled || 3 x ND(2 x 256) (dim 1), control passed through (:242).  An input key listed in
+    force_zero_embeddings has EVERY output of EVERY embedder reading that key zeroed before concatenation (:229-233): 'txt' zeroes
+    both text towers (crossattn entirely, the pooled part of vector) and leaves the size embeddings."""
+    z_l = clip_l_hidden(sd, tokens_l, p="embedders.0.transformer.text_model.", heads=heads_l)
+    pen, pooled = openclip_g_penultimate_pooled(sd, tokens_g, p="embedders.1.model.", heads=heads_g)
+    if "txt" in force_zero_embeddings:
+        z_l, pen, pooled = torch.zeros_like(z_l), torch.zeros_like(pen), torch.zeros_like(pooled)
+    nd_keys = ("original_size_as_tuple", "crop_coords_top_left", "target_size_as_tuple")
+    vec = [pooled] + [torch.zeros_like(e) if k in force_zero_embeddings else e for k, e in
+                      ((k, concat_timestep_embedder_nd(batch[k])) for k in nd_keys)]
     return {"crossattn": torch.cat([z_l, pen], 2), "vector": torch.cat(vec, 1), "control": batch["control"]}

@@ -1,9 +1,10 @@
 """SUPIRModel: the unit of work of the metric (`batchify_sample`), same constructor kwargs / methods / attribute protocol
 as SUPIR/models/SUPIR_model.py:12-179 (+ the DiffusionEngine constructor subset it relies on, sgm/models/diffusion.py:23-83).
 
-Out of scope by the survey (section 2): the text conditioner (CLIP-L + OpenCLIP-bigG, runs once per image, needs weights that
-are not available).  `conditioner_config` may therefore be None; `batchify_sample(..., cond=(c, uc))` takes the
-prepared `crossattn [N,77,2048]` / `vector [N,2816]` tensors directly, or a `conditioner` object with the reference's
+The text conditioner (CLIP-L + OpenCLIP-bigG, once per image) is built from `conditioner_config` like the
+reference does (supir_amd/modules/conditioner.py: both towers on the HIP kernels).  `conditioner_config` may also be None:
+`batchify_sample(..., cond=(c, uc))` takes prepared `crossattn [N,77,2048]` / `vector [N,2816]` tensors directly (what bench.py
+does: synthetic conditioning, no tokeniser vocabulary files in this image), or a `conditioner` object with the reference's
 `get_unconditional_conditioning(batch, batch_uc)` method can be attached.
 """
 import copy

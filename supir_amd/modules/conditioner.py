@@ -324,6 +324,10 @@ class GeneralConditioner(nn.Module):
         output = {}
         force_zero_embeddings = force_zero_embeddings or []
         for e in self.embedders:
+            if e.ucg_rate > 0.0 or e.legacy_ucg_val is not None:
+                # training-time conditioning dropout (modules.py:217-228): never active on the inference path, where
+                # get_unconditional_conditioning sets every rate to 0 (:177-186); refuse rather than silently ignore
+                raise NotImplementedError("ucg_rate > 0 / legacy_ucg_value are training-time options of the reference")
             out = e(batch[e.input_key])
             for emb in (out if isinstance(out, (list, tuple)) else [out]):
                 key = self._key_of(e, emb)

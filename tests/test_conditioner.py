@@ -67,6 +67,68 @@ def test_openclip_block_restatement_vs_torch_multihead_attention():
     assert ((got - ref).norm() / ref.norm()).item() <= 2e-5
 
 
+def _cond_golden():
+    import os
+    return torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_cond.pt"), map_location="cpu")
+
+
+def test_oracle_vs_the_references_own_conditioner_classes():
+    """oracle/cond_oracle.py against outputs of the reference's GeneralConditionerWithControl + FrozenCLIPEmbedder +
+    FrozenOpenCLIPEmbedder2 + ConcatTimestepEmbedderND (tests/golden/golden_cond.pt, written by oracle/gen_golden_cond.py from
+    /root/reference: c and uc of get_unconditional_conditioning as SUPIR_model.py:166 calls it, force_uc_zero_embeddings, and the
+    legacy branch of the OpenCLIP embedder).  Pins dim-keyed concatenation order, penultimate-layer selection, argmax-EOT pooling,
+    the hidden_states[11] choice, force-zero by input key and control passthrough."""
+    from oracle import gen_golden_cond as G
+    gold = _cond_golden()
+    # the synthetic state dict the generator loaded into the reference classes, rebuilt from key names + shapes alone
+    shapes = {}
+    with torch.device("meta"):
+        from transformers import CLIPTextConfig, CLIPTextModel
+        hf = CLIPTextModel(CLIPTextConfig(vocab_size=G.VOCAB, hidden_size=G.L_WIDTH, intermediate_size=4 * G.L_WIDTH, num_hidden_layers=G.L_LAYERS,
+                                          num_attention_heads=G.L_HEADS, max_position_embeddings=77, hidden_act="quick_gelu"))
+        oc = G._FakeOpenClipModel()
+    for k, v in hf.state_dict().items():
+        shapes[G.canonical_key("embedders.0.transformer." + k)] = tuple(v.shape)
+    for k, v in oc.state_dict().items():
+        shapes["embedders.1.model." + k] = tuple(v.shape)
+    sd = {k: synth_param("conditioner." + k, shp) for k, shp in shapes.items() if "position_ids" not in k}
+    c_b, uc_b = G.batches()
+    tok = lambda texts: torch.stack([gold["texts"][t] for t in texts])  # noqa: E731
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-20)).item()  # noqa: E731
+    with torch.no_grad():
+        c = CO.general_conditioner_with_control(sd, c_b, tok(c_b["txt"]), tok(c_b["txt"]), heads_l=G.L_HEADS, heads_g=G.G_HEADS)
+        uc = CO.general_conditioner_with_control(sd, uc_b, tok(uc_b["txt"]), tok(uc_b["txt"]), heads_l=G.L_HEADS, heads_g=G.G_HEADS)
+        uc0 = CO.general_conditioner_with_control(sd, uc_b, tok(uc_b["txt"]), tok(uc_b["txt"]), force_zero_embeddings=["txt"],
+                                                  heads_l=G.L_HEADS, heads_g=G.G_HEADS)
+        gsd = {k[len("embedders.1."):]: v for k, v in sd.items() if k.startswith("embedders.1.")}
+        leg = {layer: CO.openclip_g_legacy(gsd, tok(c_b["txt"]), layer, heads=G.G_HEADS) for layer in ("last", "penultimate")}
+    for name, got in (("c", c), ("uc", uc)):
+        assert got["crossattn"].shape == gold[f"{name}.crossattn"].shape == (2, 77, G.L_WIDTH + G.G_WIDTH)
+        assert rel(got["crossattn"], gold[f"{name}.crossattn"]) <= 2e-5, name
+        assert rel(got["vector"], gold[f"{name}.vector"]) <= 2e-5, name
+        assert torch.equal(got["control"], gold[f"{name}.control"])
+    assert torch.equal(uc0["crossattn"], gold["uc_force_zero_txt.crossattn"]) and uc0["crossattn"].abs().sum() == 0
+    assert rel(uc0["vector"], gold["uc_force_zero_txt.vector"]) <= 2e-5 and uc0["vector"][:, :G.G_PROJ].abs().sum() == 0
+    for layer in ("last", "penultimate"):
+        assert rel(leg[layer], gold[f"g_legacy_{layer}"]) <= 2e-5, layer
+    # c and uc differ (different prompts), the size embeddings are prompt independent
+    assert rel(c["crossattn"], uc["crossattn"]) > 0.1 and torch.equal(c["vector"][:, G.G_PROJ:], uc["vector"][:, G.G_PROJ:])
+
+
+def test_conditioner_fixture_reproduces_from_the_live_reference():
+    """With /root/reference mounted (the build container): re-run the generator and require the committed fixture bit for bit."""
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("reference checkout not mounted")
+    from oracle import gen_golden_cond as G
+    live, _ = G.run_reference()
+    gold = _cond_golden()
+    assert set(live) == set(gold)
+    for k, v in gold.items():
+        if torch.is_tensor(v):
+            assert torch.equal(live[k], v), k
+
+
 def test_product_state_dict_keys_follow_transformers_and_open_clip():
     from transformers import CLIPTextConfig, CLIPTextModel
     from supir_amd.modules import conditioner as C
