@@ -144,7 +144,7 @@ def _embed(sd, p, t, y):
 
 
 # ----------------------------------------------------------------------------------------------- SUPIR control / adapters
-def glv_control(sd, x, timesteps, xt, context, y, p="control_model."):
+def glv_control(sd, x, timesteps, xt, context, y, p="control_model.", taps=None):
     """GLVControl.forward (SUPIR/modules/SUPIR_v0.py:499-540): SDXL encoder + middle on xt, the LQ latent enters through
     input_hint_block (added after input block 0); returns the 10 feature maps."""
     emb = _embed(sd, p, timesteps, y)
@@ -188,9 +188,13 @@ def zero_cross_attn(sd, p, context, x, control_scale=1.0):
     return x + o.reshape(b, h, w, c).permute(0, 3, 1, 2) * control_scale
 
 
-def light_glv_unet(sd, x, timesteps, context, y, control, control_scale=1.0, p="diffusion_model."):
+def light_glv_unet(sd, x, timesteps, context, y, control, control_scale=1.0, p="diffusion_model.", taps=None):
     """LightGLVUNet.forward (SUPIR_v0.py:600-666): encoder, middle, then for every output block the skip concat is
-    replaced by project_modules[adapter_idx] (ZeroSFT), with a ZeroCrossAttn before the Upsample of 3-child blocks."""
+    replaced by project_modules[adapter_idx] (ZeroSFT), with a ZeroCrossAttn before the Upsample of 3-child blocks.
+    taps (a dict, tests only): filled with every module boundary tensor -- 'enc{i}' (input block outputs), 'mid', 'adapter{k}'
+    (project_modules[k] outputs), 'res{i}' / 'st{i}' / 'out{i}' (children / result of output block i) -- for teacher-forced
+    per-block checks of the product modules."""
+    tp = taps if taps is not None else {}
     emb = _embed(sd, p, timesteps, y)
     hs = []
     h = x
@@ -199,13 +203,16 @@ def light_glv_unet(sd, x, timesteps, context, y, control, control_scale=1.0, p="
             f"{p}input_blocks.{i}.0.op.weight" in sd:
         h = timestep_embed_sequential(sd, f"{p}input_blocks.{i}", h, emb, context)
         hs.append(h)
+        tp[f"enc{i}"] = h
         i += 1
     n_proj = 0
     while f"{p}project_modules.{n_proj}.zero_conv.weight" in sd or f"{p}project_modules.{n_proj}.norm1.weight" in sd:
         n_proj += 1
     adapter_idx, control_idx = n_proj - 1, len(control) - 1
     h = timestep_embed_sequential(sd, p + "middle_block", h, emb, context)
+    tp["mid"] = h
     h = zero_sft(sd, f"{p}project_modules.{adapter_idx}", control[control_idx], h, control_scale=control_scale)
+    tp[f"adapter{adapter_idx}"] = h
     adapter_idx -= 1
     control_idx -= 1
     i = 0
@@ -213,15 +220,20 @@ def light_glv_unet(sd, x, timesteps, context, y, control, control_scale=1.0, p="
         q = f"{p}output_blocks.{i}"
         _h = hs.pop()
         h = zero_sft(sd, f"{p}project_modules.{adapter_idx}", control[control_idx], _h, h, control_scale=control_scale)
+        tp[f"adapter{adapter_idx}"] = h
         adapter_idx -= 1
         if (q + ".2.conv.weight") in sd:  # [Res, ST, Upsample]
             h = res_block(sd, q + ".0", h, emb)
+            tp[f"res{i}"] = h
             h = spatial_transformer(sd, q + ".1", h, context)
+            tp[f"st{i}"] = h
             h = zero_cross_attn(sd, f"{p}project_modules.{adapter_idx}", control[control_idx], h, control_scale)
+            tp[f"adapter{adapter_idx}"] = h
             adapter_idx -= 1
             h = _conv(sd, q + ".2.conv", F.interpolate(h, scale_factor=2, mode="nearest"))
         else:
             h = timestep_embed_sequential(sd, q, h, emb, context)
+        tp[f"out{i}"] = h
         control_idx -= 1
         i += 1
     # self.out = [GN, SiLU, conv3x3]  (openaimodel.py:947-953)

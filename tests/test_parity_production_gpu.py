@@ -5,7 +5,7 @@ ATen-bf16 autocast, and the tiled / DPM++ samplers with the real network on the 
 The oracle (oracle/supir_oracle.py, pinned to the real reference by tests/test_oracle_golden.py) runs in fp32 ON THE DEVICE
 as the checker only; the product path is what is being measured.  Every bar has an ABSOLUTE cap next to the floor-relative
 one (a floor-relative bar alone scales with whatever ATen does).  Measured errors are appended to
-gpurun_out/parity_r02.json (copied to profiles/r02/parity.json and committed).
+gpurun_out/parity_r03.json (copied to profiles/r03/parity.json and committed).
 
 Tolerances: one bf16 network call vs the fp32 oracle: rel-L2 <= 2e-2 (absolute cap 2.5e-2), and within
 1.5x of what ATen-autocast bf16 (the reference's own arithmetic, wrappers.py:87) lands from fp32 on the same inputs; HIP vs
@@ -27,12 +27,12 @@ _OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 
 def record(name, **vals):
-    """Append measured parity numbers to gpurun_out/parity_r02.json (best effort: the directory only exists on a gpurun box
+    """Append measured parity numbers to gpurun_out/parity_r03.json (best effort: the directory only exists on a gpurun box
     or a developer checkout)."""
     print(f"[parity] {name}: " + ", ".join(f"{k}={v:.4g}" if isinstance(v, float) else f"{k}={v}" for k, v in vals.items()))
     try:
         os.makedirs(_OUT, exist_ok=True)
-        path = os.path.join(_OUT, "parity_r02.json")
+        path = os.path.join(_OUT, "parity_r03.json")
         data = json.load(open(path)) if os.path.exists(path) else {}
         data[name] = vals
         json.dump(data, open(path, "w"), indent=1, sort_keys=True)
@@ -174,9 +174,9 @@ def test_batchify_sample_config1_vs_oracle(model, restoration_scale):
     # Every stage is held to 1.5x the ATen-bf16 floor of the same quantity AND to an absolute cap.  The VAE stages compound:
     # x_stage1 = decode(z) and z_stage1 = encode(x_stage1) each see an input that already carries the previous stage's bf16
     # error, through random-init conv stacks that do not contract it (measured r02: z 8.7e-3, x_stage1 2.6e-2, z_stage1 3.0e-2).
-    caps = dict(z=2e-2, x_stage1=4e-2, z_stage1=5e-2, latent=3e-2, image=4e-2)
+    caps = dict(z=1.1e-2, x_stage1=3.2e-2, z_stage1=3.6e-2, latent=5e-3, image=1.5e-2)   # 1.2x the measured values (profiles/r02/parity.json)
     for k, cap in caps.items():
-        assert errs[k] <= cap and errs[k] <= max(1.5 * floor[k], 0.5 * cap), (k, errs[k], floor[k])
+        assert errs[k] <= cap and errs[k] <= max(1.5 * floor[k], 0.8 * cap), (k, errs[k], floor[k])
     assert errs["image_psnr_db"] >= 40.0
 
 
@@ -229,6 +229,228 @@ def test_batchify_sample_config2_50_steps_vs_oracle_bf16(model):
     assert torch.isfinite(out).all()
     # two bf16 evaluations of the same 50-step trajectory (measured r02: latent 8.7e-4, PSNR 51.7 dB)
     assert errs["latent_hip_vs_aten_bf16"] <= 5e-3 and errs["psnr_hip_vs_aten_bf16_db"] >= 40.0
+
+
+def test_batchify_sample_config2_10_steps_vs_fp32_oracle(model):
+    """The bench workload's arithmetic against the FP32 oracle in the default run (the 50-step fp32 comparison
+    is opt-in because it costs two minutes): 1024^2, 10 EDM steps through the hipGraph path, every noise injected.  Ten steps
+    already feed each step's error through the sampler nine times; the bar is the ATen-bf16 floor on the same inputs."""
+    from oracle import supir_oracle as O
+    P, lat, steps = 1024, 128, 10
+    x = T("cfg2.img", (1, 3, P, P), scale=0.5).clamp(-1, 1)
+    c, uc = _cond()
+    noises = {"posterior": T("cfg2.post", (1, 4, lat, lat)), "init": T("cfg2.init", (1, 4, lat, lat)),
+              "steps": [T(f"cfg2.eps{i}", (1, 4, lat, lat)) for i in range(steps)]}
+
+    def clone(n):
+        return {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in n.items()}
+
+    model.model.enable_graph(True)
+    try:
+        with torch.no_grad():
+            out, mid = model.batchify_sample(x, cond=(c, uc), num_steps=steps, restoration_scale=-1, s_churn=5, s_noise=1.01,
+                                             cfg_scale=4.0, control_scale=1.0, seed=1234, color_fix_type="Wavelet",
+                                             use_linear_CFG=True, cfg_scale_start=1.0, noises=clone(noises),
+                                             return_intermediates=True)
+    finally:
+        model.model.enable_graph(False)
+    sd = _model_sd(model)
+    kw = dict(num_steps=steps, s_churn=5, s_noise=1.01, restoration_scale=-1.0, cfg_scale=4.0, cfg_scale_start=1.0,
+              table=model.denoiser.sigmas.to(DEV))
+    with torch.no_grad():
+        ref32, m32 = O.batchify_sample(sd, x, c, uc, clone(noises), **kw)
+        ref32 = O.wavelet_reconstruction(ref32, m32["x_stage1"])
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ref16, m16 = O.batchify_sample(sd, x, c, uc, clone(noises), **kw)
+        ref16 = O.wavelet_reconstruction(ref16.float(), m16["x_stage1"].float())
+    errs = dict(latent_hip_vs_fp32=rel_l2(mid["samples"], m32["samples"]), latent_aten_bf16_vs_fp32=rel_l2(m16["samples"].float(), m32["samples"]),
+                image_hip_vs_fp32=rel_l2(out, ref32), image_aten_bf16_vs_fp32=rel_l2(ref16, ref32),
+                psnr_hip_vs_fp32_db=psnr(out, ref32), psnr_aten_bf16_vs_fp32_db=psnr(ref16, ref32))
+    record("batchify_sample_config2_1024px_10steps_vs_fp32", **errs)
+    assert torch.isfinite(out).all()
+    assert errs["latent_hip_vs_fp32"] <= max(1.5 * errs["latent_aten_bf16_vs_fp32"], 2e-3) and errs["latent_hip_vs_fp32"] <= 1e-2
+    assert errs["image_hip_vs_fp32"] <= max(1.5 * errs["image_aten_bf16_vs_fp32"], 1e-2) and errs["psnr_hip_vs_fp32_db"] >= 40.0
+
+
+def test_per_block_teacher_forced_at_full_depth(full):
+    """Every module of the full-depth UNet + control fed the FP32 ORACLE'S activations at its input and compared with the oracle at
+    its output: an end-to-end comparison attenuates what a deep block does wrong by the 0.4 gains of the
+    synthetic residual branches that follow it; here each ResBlock / SpatialTransformer stack / adapter is on its own.
+    Latent 64^2 (config-1 shapes), B = 2."""
+    from oracle import supir_oracle as O
+    from supir_amd import weights as Wt
+    B, lat = 2, 64
+    x, lq = T("xt64", (B, 4, lat, lat)), T("lq64", (B, 4, lat, lat))
+    ctx, y = T("context", (B, 77, 2048)), T("vector", (B, 2816))
+    t = torch.tensor([999, 3], dtype=torch.int64, device=DEV)
+    sd = _sd_of(full)
+    cm, dm = full.control_model, full.diffusion_model
+    taps = {}
+    with torch.no_grad():
+        control = O.glv_control(sd, lq, t, x, ctx, y, p="model.control_model.")
+        O.light_glv_unet(sd, x, t, ctx, y, control, 1.0, p="model.diffusion_model.", taps=taps)
+
+    def nhwc(v):   # what a product module receives from its predecessor: the compute dtype, channels-last memory
+        return v.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    errs = {}
+    with torch.no_grad(), Wt.compute_dtype(torch.bfloat16):
+        emb_c, emb_u = cm._embed(t, y), dm._embed(t, y)
+        # control branch: input blocks 1.. and the middle block, each from the oracle's previous feature map
+        blocks = list(cm.input_blocks)[1:] + [cm.middle_block]
+        for i, blk in enumerate(blocks):
+            errs[f"control.block{i + 1}"] = rel_l2(blk(nhwc(control[i]), emb_c, ctx), control[i + 1])
+        # UNet encoder
+        ublocks = list(dm.input_blocks)[1:]
+        for i, blk in enumerate(ublocks):
+            errs[f"unet.enc{i + 1}"] = rel_l2(blk(nhwc(taps[f"enc{i}"]), emb_u, ctx), taps[f"enc{i + 1}"])
+        errs["unet.mid"] = rel_l2(dm.middle_block(nhwc(taps[f"enc{len(ublocks)}"]), emb_u, ctx), taps["mid"])
+        # decoder: adapters and output blocks in the order LightGLVUNet.forward walks them
+        a_idx, c_idx = len(dm.project_modules) - 1, len(control) - 1
+        errs[f"adapter{a_idx}"] = rel_l2(dm.project_modules[a_idx](nhwc(control[c_idx]), nhwc(taps["mid"]), control_scale=1.0),
+                                         taps[f"adapter{a_idx}"])
+        h_prev = taps[f"adapter{a_idx}"]
+        a_idx -= 1
+        c_idx -= 1
+        n_enc = len(ublocks)
+        for i, module in enumerate(dm.output_blocks):
+            skip = taps[f"enc{n_enc - i}"]
+            out = dm.project_modules[a_idx](nhwc(control[c_idx]), nhwc(skip), nhwc(h_prev), control_scale=1.0)
+            errs[f"adapter{a_idx}"] = rel_l2(out, taps[f"adapter{a_idx}"])
+            h_in = taps[f"adapter{a_idx}"]
+            a_idx -= 1
+            if len(module) == 3:
+                errs[f"dec{i}.res"] = rel_l2(module[0](nhwc(h_in), emb_u), taps[f"res{i}"])
+                errs[f"dec{i}.st"] = rel_l2(module[1](nhwc(taps[f"res{i}"]), ctx), taps[f"st{i}"])
+                xa = dm.project_modules[a_idx](nhwc(control[c_idx]), nhwc(taps[f"st{i}"]), control_scale=1.0)
+                errs[f"adapter{a_idx}"] = rel_l2(xa, taps[f"adapter{a_idx}"])
+                errs[f"dec{i}.up"] = rel_l2(module[2](nhwc(taps[f"adapter{a_idx}"])), taps[f"out{i}"])
+                a_idx -= 1
+            else:
+                errs[f"dec{i}"] = rel_l2(module(nhwc(h_in), emb_u, ctx), taps[f"out{i}"])
+            h_prev = taps[f"out{i}"]
+            c_idx -= 1
+        errs["unet.out"] = rel_l2(dm._out(nhwc(h_prev)), O._conv(sd, "model.diffusion_model.out.2", torch.nn.functional.silu(
+            O._gn(sd, "model.diffusion_model.out.0", h_prev, 1e-5))))
+    record("per_block_teacher_forced_full_depth_latent64", **errs)
+    worst = max(errs, key=errs.get)
+    # a single bf16 module (GroupNorm + conv / a 10-block transformer stack with bf16 token stream): the measured values sit at
+    # 2e-3 .. 9e-3; anything structurally wrong in one block is >= 5e-2 on that block
+    assert errs[worst] <= 1.5e-2, (worst, errs[worst])
+
+
+def test_tiled_sampler_config3_production_scale(full):
+    """BASELINE config 3's sampler at its own scale: latent 512^2 (a 4096^2 image), tiles of 128 / stride 64 =
+    49 tiles, tile_batch 4 (twelve groups of four and a remainder of ONE), full depth, 2 steps.  Checker: the oracle's tiled sampler
+    driving the oracle network under ATen-bf16 autocast -- the reference's own arithmetic (wrappers.py:87); the fp32 oracle network
+    (49 x 2 calls of ~2.4 s) is opt-in (SUPIR_TEST_LONG=1)."""
+    from oracle import supir_oracle as O
+    from supir_amd.modules.sampling import DiscreteDenoiserWithControl, LinearCFG, TiledRestoreEDMSampler
+    h = w = 512
+    steps = 2
+    ctx, y = T("context", (2, 77, 2048)), T("vector", (2, 2816))
+    lq = T("cfg3.lq", (1, 4, h, w))
+    c = {"crossattn": ctx[:1], "vector": y[:1], "control": lq}
+    uc = {"crossattn": ctx[1:], "vector": y[1:], "control": lq}
+    den = DiscreteDenoiserWithControl().to(DEV)
+    noises = [T(f"cfg3.eps{i}", (1, 4, h, w)) for i in range(steps)]
+    x0, xc = T("cfg3.x0", (1, 4, h, w)), T("cfg3.xc", (1, 4, h, w))
+    from supir_amd.modules import sampling as S
+    assert len(S._sliding_windows(h, w, 128, 64)) == 49
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda t_, **kw: next(it).to(t_)
+    try:
+        smp = TiledRestoreEDMSampler(tile_size=128, tile_stride=64, num_steps=steps, s_churn=5, s_noise=1.01, restore_cfg=4.0,
+                                     guider_config=LinearCFG(1.0, 4.0), device=DEV, tile_batch=4)
+        with torch.no_grad():
+            out = smp(lambda i, s, cc, cs: den(full, i, s, cc, cs), x0.clone(), cond=dict(c), uc=dict(uc), x_center=xc,
+                      control_scale=1.0).float()
+    finally:
+        torch.randn_like = orig
+    sd = _sd_of(full)
+    table = den.sigmas.to(DEV)
+
+    def denoise_fn(xin, sigma, cond, cs):
+        return O.discrete_denoiser_with_control(lambda a, b_, cc, s: O.control_wrapper(sd, a, b_, cc, s), table, xin, sigma, cond, cs)
+
+    kw = dict(tile_size=128, tile_stride=64, num_steps=steps, s_churn=5, s_noise=1.01, restore_cfg=4.0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ref16 = O.tiled_restore_edm_sample(denoise_fn, x0.clone(), c, uc, xc, noises, **kw).float()
+    errs = dict(hip_vs_aten_bf16=rel_l2(out, ref16), out_std=out.std().item())
+    if os.environ.get("SUPIR_TEST_LONG") == "1":
+        with torch.no_grad():
+            ref32 = O.tiled_restore_edm_sample(denoise_fn, x0.clone(), c, uc, xc, noises, **kw).float()
+        errs.update(hip_vs_fp32=rel_l2(out, ref32), aten_bf16_vs_fp32=rel_l2(ref16, ref32))
+        assert errs["hip_vs_fp32"] <= max(1.5 * errs["aten_bf16_vs_fp32"], 5e-3)
+    record("tiled_sampler_config3_latent512_49tiles_tb4_2steps_full_depth", **errs)
+    assert out.shape == (1, 4, h, w) and torch.isfinite(out).all()
+    assert errs["hip_vs_aten_bf16"] <= 1e-2      # two bf16 evaluations of the same 2-step tiled trajectory
+
+
+def test_tiled_vae_at_2048px_vs_oracle(model):
+    """The tiled VAE at a size where the tile grid is real: decoder on a 256^2 latent with 64-latent tiles
+    (4 x 4 tiles of 86^2 incl. padding -> 2048^2 px), encoder on a 1536 x 2048 image with 512 px tiles (3 x 4), against the
+    oracle's layer-major tiled forward (pinned to the reference's VAEHook by tests/test_oracle_golden.py) in fp32."""
+    from oracle import supir_oracle as O
+    from supir_amd.utils.tilevae import VAEHook
+    fs = model.first_stage_model
+    sd = {k[len("first_stage_model."):]: v for k, v in model.state_dict().items() if k.startswith("first_stage_model.")}
+    z = T("cfg3.vae.z", (1, 4, 256, 256))
+    img = T("cfg3.vae.img", (1, 3, 1536, 2048), scale=0.5).clamp(-1, 1)
+    with torch.no_grad():
+        dec = VAEHook(fs.decoder, 64, is_decoder=True)(z).float()
+        ref_dec = O.vae_tiled_forward(sd, z, "decoder.", 64, True)
+        e_dec = rel_l2(dec, ref_dec)
+        del ref_dec
+        enc = VAEHook(fs.denoise_encoder, 512, is_decoder=False)(img).float()
+        ref_enc = O.vae_tiled_forward(sd, img, "denoise_encoder.", 512, False)
+        e_enc = rel_l2(enc, ref_enc)
+    record("tiled_vae_2048px", decoder_16_tiles=e_dec, encoder_12_tiles=e_enc)
+    assert tuple(dec.shape) == (1, 3, 2048, 2048) and tuple(enc.shape) == (1, 8, 192, 256)
+    assert e_dec <= 2.5e-2 and e_enc <= 2.5e-2
+
+
+def test_dpmpp2m_config5_at_1024px_full_depth_fp16(full):
+    """BASELINE config 5 at the metric's size: RestoreDPMPP2MSampler (sampling.py:422-515), 4 steps, latent
+    128^2, full depth, diff_dtype fp16 (the fp16 build of the kernels), scripted noise, against the same sampler class driving the
+    fp32 oracle network."""
+    from oracle import supir_oracle as O
+    from supir_amd.modules.sampling import DiscreteDenoiserWithControl, LinearCFG, RestoreDPMPP2MSampler
+    h = w = 128
+    ctx, y = T("context", (2, 77, 2048)), T("vector", (2, 2816))
+    lq = T("cfg5.lq", (1, 4, h, w))
+    c = {"crossattn": ctx[:1], "vector": y[:1], "control": lq}
+    uc = {"crossattn": ctx[1:], "vector": y[1:], "control": lq}
+    den = DiscreteDenoiserWithControl().to(DEV)
+    sd = _sd_of(full)
+    x0 = T("cfg5.x0", (1, 4, h, w))
+
+    class Scripted:
+        def __init__(self, x, *a, **k):
+            self.i = 0
+
+        def __call__(self, s, sn):
+            self.i += 1
+            return T(f"cfg5.eps{self.i}", (1, 4, h, w))
+
+    outs = {}
+    for name, net, dt in (("fp16", full, torch.float16), ("bf16", full, torch.bfloat16),
+                          ("oracle", lambda a, b_, cc, s: O.control_wrapper(sd, a, b_, cc, s), None)):
+        if dt is not None:
+            full.dtype = dt
+        try:
+            smp = RestoreDPMPP2MSampler(num_steps=4, s_noise=1.0, eta=1.0, restore_cfg=4.0, guider_config=LinearCFG(2.0, 2.0),
+                                        device=DEV, noise_sampler_cls=Scripted)
+            with torch.no_grad():
+                outs[name] = smp(lambda i, s, cc, cs, n=net: den(n, i, s, cc, cs), x0.clone(), cond=dict(c), uc=dict(uc),
+                                 control_scale=1.0).float()
+        finally:
+            full.dtype = torch.bfloat16
+    errs = dict(fp16_vs_fp32_oracle=rel_l2(outs["fp16"], outs["oracle"]), bf16_vs_fp32_oracle=rel_l2(outs["bf16"], outs["oracle"]))
+    record("dpmpp2m_config5_latent128_full_depth_4steps", **errs)
+    assert torch.isfinite(outs["fp16"]).all()
+    assert errs["fp16_vs_fp32_oracle"] <= 3e-3 and errs["bf16_vs_fp32_oracle"] <= 1.5e-2
 
 
 # ------------------------------------------------------------------------------------------ tiled / DPM++ samplers, real network
