@@ -188,9 +188,10 @@ def run_reference():
 
 
 def main():
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
     gold, _ = run_reference()
-    torch.save(gold, OUT)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes;", {k: tuple(v.shape) for k, v in gold.items() if torch.is_tensor(v)})
+    torch.save(gold, out)
+    print("wrote", out, os.path.getsize(out), "bytes;", {k: tuple(v.shape) for k, v in gold.items() if torch.is_tensor(v)})
 
 
 if __name__ == "__main__":

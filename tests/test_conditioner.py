@@ -120,8 +120,17 @@ def test_conditioner_fixture_reproduces_from_the_live_reference():
     from oracle import ref_import
     if not ref_import.available():
         pytest.skip("reference checkout not mounted")
-    from oracle import gen_golden_cond as G
-    live, _ = G.run_reference()
+    # in a fresh interpreter: other tests of this session call plugin.install(), which re-points the reference's module attributes
+    # at this package's classes -- the generator must see the genuine reference
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "cond.pt")
+        subprocess.run([sys.executable, "-m", "oracle.gen_golden_cond", "--out", path], cwd=root, check=True, capture_output=True, timeout=600)
+        live = torch.load(path, map_location="cpu")
     gold = _cond_golden()
     assert set(live) == set(gold)
     for k, v in gold.items():
