@@ -53,9 +53,9 @@ class AttnBlock(nn.Module):
 
     def attend(self, n):
         """n: normalised tokens [B, T, C] bf16 -> proj_out-less attention output [B, T, C].  Any T.
-        C == 512 (every SDXL / SUPIR VAE) and ops.use_flash_d512(T) (forced, or the score matrix would be too large to be worth
-        materialising): q, k and v^T projections + ONE flash-attention launch (csrc/attention_d512.hip), no score matrix.
-        Otherwise the materialised form, which is the faster one at the sizes of BASELINE configs 1 / 2: the key axis is padded to a multiple of 64
+        C == 512 (every SDXL / SUPIR VAE) and ops.use_flash_d512(T) (T >= 16 384 tokens = a 1024^2 px image and larger, where it
+        measures faster): q, k and v^T projections + ONE flash-attention launch (csrc/attention_d512.hip), no score matrix.
+        Otherwise (512^2 px images, tiled-VAE tiles) the materialised form: the key axis is padded to a multiple of 64
         with zero K rows / zero V^T columns, a GEMM writes fp32 scores [T, Tp], softmax_rows masks the padding, a GEMM applies P."""
         B, T, C = n.shape
         Tp = (T + 63) // 64 * 64

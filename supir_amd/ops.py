@@ -1023,12 +1023,14 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
 
 
 # VAE mid-block attention (one head, dim 512): supir_flash_attn_d512 never forms the score matrix; the materialised form (GEMM -> fp32
-# scores [T, T] -> softmax_rows -> GEMM) moves ~3 GB per call at T = 16 384 but runs on the tuned GEMM tiles.  The flash kernel takes
-# over from FLASH_D512_MIN_TOKENS tokens per batch element upwards (env SUPIR_FLASH_D512_MIN_TOKENS; the default is where one
-# element's fp32 score matrix reaches 8 GiB -- an untiled image beyond ~1720^2 px -- unless a measurement moved it);
-# SUPIR_FLASH_D512 = 1 / 0 forces it on / off for every size.
+# scores [T, T] -> softmax_rows -> GEMM) moves ~3 GB per call at T = 16 384 but runs on the tuned GEMM tiles.  Measured on one box
+# (profiles/r02/attn_d512_timing.json): T = 4096: 391 us flash vs 93 us materialised (32 workgroups of one wave per SIMD cannot
+# fill 256 CUs); T = 16 384 (a 1024^2 image, the bench): 1.49 ms vs 1.69 ms.  The materialised form grows as T^2 from a small
+# constant, the flash kernel linearly in its workgroup count until the chip is full, so the flash kernel takes over from
+# FLASH_D512_MIN_TOKENS = 16 384 tokens per batch element upwards (env SUPIR_FLASH_D512_MIN_TOKENS); SUPIR_FLASH_D512 = 1 / 0 forces
+# it on / off for every size.
 USE_FLASH_D512 = {"1": True, "0": False}.get(_os.environ.get("SUPIR_FLASH_D512", "auto"), "auto")
-FLASH_D512_MIN_TOKENS = int(_os.environ.get("SUPIR_FLASH_D512_MIN_TOKENS", "46341"))
+FLASH_D512_MIN_TOKENS = int(_os.environ.get("SUPIR_FLASH_D512_MIN_TOKENS", "16384"))
 
 
 def use_flash_d512(T):

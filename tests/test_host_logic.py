@@ -547,11 +547,10 @@ def test_flash_d512_policy(monkeypatch):
     SUPIR_FLASH_D512 = 1 / 0 force it for every size."""
     from supir_amd import ops
     monkeypatch.setattr(ops, "USE_FLASH_D512", "auto")
-    monkeypatch.setattr(ops, "FLASH_D512_MIN_TOKENS", 46341)                   # the 8 GiB-of-scores default
-    assert not ops.use_flash_d512(16384) and not ops.use_flash_d512(4096)      # 1024^2 / 512^2 px: 1 GiB / 64 MiB of scores
-    assert not ops.use_flash_d512(46340) and ops.use_flash_d512(46341) and ops.use_flash_d512(65536)
-    monkeypatch.setattr(ops, "FLASH_D512_MIN_TOKENS", 8192)
-    assert ops.use_flash_d512(16384) and not ops.use_flash_d512(4096)
+    assert ops.FLASH_D512_MIN_TOKENS == 16384          # the default: where the flash kernel measured faster (1024^2 px images)
+    assert ops.use_flash_d512(16384) and ops.use_flash_d512(65536) and not ops.use_flash_d512(16383) and not ops.use_flash_d512(4096)
+    monkeypatch.setattr(ops, "FLASH_D512_MIN_TOKENS", 46341)                   # e.g. only where the score matrix would reach 8 GiB
+    assert not ops.use_flash_d512(16384) and not ops.use_flash_d512(46340) and ops.use_flash_d512(46341)
     monkeypatch.setattr(ops, "USE_FLASH_D512", True)
     assert ops.use_flash_d512(64)
     monkeypatch.setattr(ops, "USE_FLASH_D512", False)

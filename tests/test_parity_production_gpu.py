@@ -334,9 +334,9 @@ def test_per_block_teacher_forced_at_full_depth(full):
             O._gn(sd, "model.diffusion_model.out.0", h_prev, 1e-5))))
     record("per_block_teacher_forced_full_depth_latent64", **errs)
     worst = max(errs, key=errs.get)
-    # a single bf16 module (GroupNorm + conv / a 10-block transformer stack with bf16 token stream): the measured values sit at
-    # 2e-3 .. 9e-3; anything structurally wrong in one block is >= 5e-2 on that block
-    assert errs[worst] <= 1.5e-2, (worst, errs[worst])
+    # a single bf16 module (GroupNorm + conv / a 10-block transformer stack with bf16 token stream): measured 2.4e-3 .. 4.7e-3
+    # (profiles/r03/parity.json); anything structurally wrong in one block is >= 5e-2 on that block
+    assert errs[worst] <= 8e-3, (worst, errs[worst])
 
 
 def test_tiled_sampler_config3_production_scale(full):
