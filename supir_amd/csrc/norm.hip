@@ -79,37 +79,74 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgsN<NP> pp) {
     }
 }
 
+// Apply pass.  Thread layout: lane column v = tid % cv owns the 8 channels [8 v, 8 v + 8) of every row it touches (cv = C / 8
+// <= 512), row slot ty = tid / cv of TY; a workgroup of cv x TY threads walks its row chunk TY rows at a time.  Because a thread's
+// channels never change, the per-channel scale / shift live in 16 REGISTERS (the first version kept a [C] x 2 table in LDS and read
+// it at a stride of 8 floats per lane: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.82, profiles/r02/pmc_summary_final_build.json),
+// and the loads of the first row batch -- x, gamma / beta, the ZeroSFT maps -- are issued BEFORE the statistics are reduced: the
+// launch is a chain of dependent round trips (partials -> statistics -> rows -> store, ~8.7 us whatever the row loop does,
+// profiles/r02/groupnorm_more_loads_in_flight_experiment.log) and this overlaps the two longest of them.
 template <int NP>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgsN<NP> pp, int nchunk_apply, int rows_per_chunk_apply) {
+__global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int nchunk_apply, int rows_per_chunk_apply, int TY) {
     const GnArgs& p = pp.p[NP == 1 ? 0 : blockIdx.z];
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sA = (float*)smem_raw;  // [C] scale
-    float* sB = sA + p.C;          // [C] shift
     __shared__ float s_mean[32], s_rstd[32];
     __shared__ double s_part[4][64];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cv = p.C >> 3, cpg = p.C >> 5;
-    if (p.part_u1) {
-        // statistics left behind by the producer GEMM / conv epilogues (GemmArgs::gn_part_out): (sum, sum of squares) per tile row
-        // and 10-channel unit of each source tensor.  Group g = units [g * upg, (g + 1) * upg) of the concatenation; every group
-        // width on the path is a multiple of 10 (dispatcher).  Same fixed order on every workgroup -> reproducible.
-        const int v = tid & 63, sub = tid >> 6, g = v >> 1, st = v & 1;
-        const int upg = cpg / 10, U1 = p.C1 / 10, U2 = (p.C - p.C1) / 10;
-        double a = 0.0;
-        for (int uu = g * upg; uu < (g + 1) * upg; ++uu) {
-            const bool first = uu < U1;
-            const float* src = first ? p.part_u1 : p.part_u2;
-            const int nch = first ? p.nch1 : p.nch2, U = first ? U1 : U2, u = first ? uu : uu - U1;
-            for (int k = sub; k < nch; k += 4) a += (double)src[(((size_t)b * nch + k) * U + u) * 2 + st];
+    const int v = tid % cv, ty = tid / cv, c = v * 8;
+    const int row0 = chunk * rows_per_chunk_apply;
+    const int row1 = min(p.HW, row0 + rows_per_chunk_apply);
+    const bool lerp = p.cscale != 1.0f && p.mod_g;
+    constexpr int U = 4;   // rows in flight per thread
+    // ---- loads that do not depend on the statistics: this thread's affine parameters and its first U rows
+    const f32x4 g0 = *(const f32x4*)(p.gamma + c), g1 = *(const f32x4*)(p.gamma + c + 4);
+    const f32x4 be0 = *(const f32x4*)(p.beta + c), be1 = *(const f32x4*)(p.beta + c + 4);
+    u16x8 xv[U], gv[U], bv[U], rv[U];
+    auto load_rows = [&](int row) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = row + u * TY;
+            if (r < row1) {
+                xv[u] = *(const u16x8*)gn_src(p, b, r, c);
+                if (p.mod_g) {
+                    const size_t mo = ((size_t)b * p.HW + r) * p.ldm + c;
+                    gv[u] = *(const u16x8*)(p.mod_g + mo);
+                    bv[u] = *(const u16x8*)(p.mod_b + mo);
+                    if (lerp) {   // h_raw = cat[h_ori, h] (h BEFORE the zero_conv projection)
+                        rv[u] = xv[u];
+                        if (c < p.C1) {
+                            if (p.x1raw) rv[u] = *(const u16x8*)(p.x1raw + ((size_t)b * p.HW + r) * p.ld1 + c);
+                        } else if (p.x2raw) {
+                            rv[u] = *(const u16x8*)(p.x2raw + ((size_t)b * p.HW + r) * p.ld2 + (c - p.C1));
+                        }
+                    }
+                }
+            }
         }
-        s_part[sub][v] = a;
-    } else if (!p.given) {
-        // all 256 threads reduce the per-chunk partials (fixed order -> reproducible): value v = tid&63, chunks sub, sub+4, ...
-        const int v = tid & 63, sub = tid >> 6;
-        double a = 0.0;
-        for (int k = sub; k < p.nchunk; k += 4) a += (double)p.partial[((size_t)b * p.nchunk + k) * 64 + v];
-        s_part[sub][v] = a;
+    };
+    load_rows(row0 + ty);
+    // ---- statistics of this batch element: (sum, sum of squares) per group, reduced in a fixed order (reproducible)
+    if (tid < 256) {
+        const int sv = tid & 63, sub = tid >> 6;
+        if (p.part_u1) {
+            // left behind by the producer GEMM / conv epilogues (GemmArgs::gn_part_out): per tile row and 10-channel unit of each source
+            // tensor.  Group g = units [g * upg, (g + 1) * upg) of the concatenation; every group width on the path is a multiple of 10
+            const int g = sv >> 1, st = sv & 1;
+            const int upg = cpg / 10, U1 = p.C1 / 10, U2 = (p.C - p.C1) / 10;
+            double a = 0.0;
+            for (int uu = g * upg; uu < (g + 1) * upg; ++uu) {
+                const bool first = uu < U1;
+                const float* src = first ? p.part_u1 : p.part_u2;
+                const int nch = first ? p.nch1 : p.nch2, Un = first ? U1 : U2, u = first ? uu : uu - U1;
+                for (int k = sub; k < nch; k += 4) a += (double)src[(((size_t)b * nch + k) * Un + u) * 2 + st];
+            }
+            s_part[sub][sv] = a;
+        } else if (!p.given) {
+            double a = 0.0;
+            for (int k = sub; k < p.nchunk; k += 4) a += (double)p.partial[((size_t)b * p.nchunk + k) * 64 + sv];
+            s_part[sub][sv] = a;
+        }
     }
     __syncthreads();
     if (p.given) {
@@ -129,49 +166,45 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgsN<NP> pp, int
         s_rstd[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 256) {
-        const int g = c / cpg;
-        const float a = s_rstd[g] * p.gamma[c];
-        sA[c] = a;
-        sB[c] = p.beta[c] - s_mean[g] * a;
+    float sa[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cpg;
+        const float a = s_rstd[g] * (e < 4 ? g0[e] : g1[e - 4]);
+        sa[e] = a;
+        sb[e] = (e < 4 ? be0[e] : be1[e - 4]) - s_mean[g] * a;
     }
-    __syncthreads();
-    const int row0 = chunk * rows_per_chunk_apply;
-    const int row1 = min(p.HW, row0 + rows_per_chunk_apply);
-    const int items = (row1 - row0) * cv;
-    const bool lerp = p.cscale != 1.0f;
-    for (int idx = tid; idx < items; idx += 256) {
-        const int r = idx / cv, v = idx - r * cv;
-        const int row = row0 + r, c = v * 8;
-        const u16x8 xv = *(const u16x8*)gn_src(p, b, row, c);
-        float y[8];
+    if (ty >= TY) return;   // (never: the block is exactly cv x TY threads)
+    for (int row = row0 + ty; row < row1; row += U * TY) {
+        u16x8 ov[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = bf2f(xv[e]) * sA[c + e] + sB[c + e];
-        if (p.act == 1) {
+        for (int u = 0; u < U; ++u) {
+            float y[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
-        }
-        if (p.mod_g) {
-            const size_t mo = ((size_t)b * p.HW + row) * p.ldm + c;
-            const u16x8 gv = *(const u16x8*)(p.mod_g + mo);
-            const u16x8 bv = *(const u16x8*)(p.mod_b + mo);
+            for (int e = 0; e < 8; ++e) y[e] = bf2f(xv[u][e]) * sa[e] + sb[e];
+            if (p.act == 1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = y[e] * (bf2f(gv[e]) + 1.0f) + bf2f(bv[e]);
-            if (lerp) {
-                u16x8 rv = xv;  // h_raw = cat[h_ori, h] (h BEFORE the zero_conv projection)
-                if (c < p.C1) {
-                    if (p.x1raw) rv = *(const u16x8*)(p.x1raw + ((size_t)b * p.HW + row) * p.ld1 + c);
-                } else if (p.x2raw) {
-                    rv = *(const u16x8*)(p.x2raw + ((size_t)b * p.HW + row) * p.ld2 + (c - p.C1));
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = y[e] * p.cscale + bf2f(rv[e]) * (1.0f - p.cscale);
+                for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
             }
-        }
-        u16x8 ov;
+            if (p.mod_g) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = f2bf(y[e]);
-        *(u16x8*)(p.out + ((size_t)b * p.HW + row) * p.ldo + c) = ov;
+                for (int e = 0; e < 8; ++e) y[e] = y[e] * (bf2f(gv[u][e]) + 1.0f) + bf2f(bv[u][e]);
+                if (lerp) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = y[e] * p.cscale + bf2f(rv[u][e]) * (1.0f - p.cscale);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[u][e] = f2bf(y[e]);
+        }
+        const int next = row + U * TY;
+        const int here = row;
+        if (next < row1) load_rows(next);   // the next batch is in flight while this one is stored
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = here + u * TY;
+            if (r < row1) *(u16x8*)(p.out + ((size_t)b * p.HW + r) * p.ldo + c) = ov[u];
+        }
     }
 }
 
@@ -222,8 +255,13 @@ static int gn_launch(const GnArgs* a_in, hipStream_t st) {
     if (nca > 2048) nca = 2048;
     const int rpc = (a.HW + nca - 1) / nca;
     nca = (a.HW + rpc - 1) / rpc;
-    const size_t smem = (size_t)a.C * 2 * sizeof(float);
-    SUPIR_LAUNCH(gn_apply_kernel<NP>, dim3(nca, a.B, NP), dim3(256), smem, st, pp, nca, rpc);
+    // cv x TY threads: every thread owns one 8-channel column; TY row slots so that the block has >= 256 threads where cv allows
+    const int cv = a.C / 8;
+    if (cv > 512) return SUPIR_ERR_SHAPE;
+    int ty = (256 + cv - 1) / cv;
+    if (ty > 512 / cv) ty = 512 / cv;
+    if (ty < 1) ty = 1;
+    SUPIR_LAUNCH(gn_apply_kernel<NP>, dim3(nca, a.B, NP), dim3(cv * ty), 0, st, pp, nca, rpc, ty);
     return SUPIR_LAUNCH_STATUS();
 }
 

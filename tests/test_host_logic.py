@@ -555,3 +555,37 @@ def test_flash_d512_policy(monkeypatch):
     assert ops.use_flash_d512(64)
     monkeypatch.setattr(ops, "USE_FLASH_D512", False)
     assert not ops.use_flash_d512(1 << 20)
+
+
+def test_tiled_vae_host_logic_vs_oracle_with_torch_backend():
+    """supir_amd/utils/tilevae.py (tile split, shape-group stacking, pooled GroupNorm statistics with pixel weights at the current
+    resolution, crop + paste) run on CPU with tests/fake_ops.py standing in for the kernels, against oracle.vae_tiled_forward (pinned
+    to the reference's VAEHook by tests/test_oracle_golden.py::test_tiled_vae): ragged tile grids, batch of 2."""
+    import copy
+    from oracle import supir_oracle as O
+    from supir_amd.modules.vae import AutoencoderKLInferenceWrapper
+    from supir_amd.utils.tilevae import VAEHook, assign_tiles
+    from tests import fake_ops
+    from tests.helpers import fill_module
+    vae = AutoencoderKLInferenceWrapper(embed_dim=4, ddconfig=dict(VAE_DD, ch=32), lossconfig={"target": "torch.nn.Identity"})
+    vae.denoise_encoder = copy.deepcopy(vae.encoder)
+    fill_module(vae, "first_stage_model.", "cpu")
+    with torch.no_grad():    # the product derives 16-bit weight layouts: make the masters bf16-representable so both sides see the same numbers
+        for prm in vae.parameters():
+            if prm.dim() >= 2:
+                prm.copy_(prm.bfloat16().float())
+    sd = {k: v for k, v in vae.state_dict().items()}
+    img, z = synth_tensor("img_tiled", (2, 3, 200, 168), scale=0.5), synth_tensor("z_tiled", (2, 4, 40, 32))
+    undo = fake_ops.install()
+    try:
+        with torch.no_grad():
+            enc = VAEHook(vae.denoise_encoder, 64, is_decoder=False)(img)
+            dec = VAEHook(vae.decoder, 8, is_decoder=True)(z)
+    finally:
+        undo()
+    with torch.no_grad():
+        ref_enc = O.vae_tiled_forward(sd, img, "denoise_encoder.", 64, False)
+        ref_dec = O.vae_tiled_forward(sd, z, "decoder.", 8, True)
+    assert enc.shape == ref_enc.shape and dec.shape == ref_dec.shape == (2, 3, 320, 256)
+    assert rel_l2(enc, ref_enc) <= 2e-5 and rel_l2(dec, ref_dec) <= 2e-5
+    assert assign_tiles(7, 1, 3) == [1, 4] and assign_tiles(2, 0, 1) == [0, 1]

@@ -143,3 +143,53 @@ def test_tile_parallel_sampler_matches_single_process():
     for tile_batch in (1, 2):
         for rank, err, finite in _run_tile_parallel(tile_batch):
             assert finite and err <= 2e-6, (tile_batch, rank, err)
+
+
+# ------------------------------------------------------------------------------------------------ tile-parallel tiled VAE
+def _tiny_vae():
+    """A narrow VAE (32 base channels, the reference's 4-level layout) with synthetic weights, on CPU."""
+    from supir_amd.modules.vae import AutoencoderKLInferenceWrapper
+    from tests.helpers import VAE_DD, fill_module
+    import copy
+    vae = AutoencoderKLInferenceWrapper(embed_dim=4, ddconfig=dict(VAE_DD, ch=32), lossconfig={"target": "torch.nn.Identity"})
+    vae.denoise_encoder = copy.deepcopy(vae.encoder)
+    return fill_module(vae, "first_stage_model.", "cpu")
+
+
+def _vae_tile_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from supir_amd.utils.tilevae import VAEHook
+    from tests import fake_ops
+    from tests.helpers import synth_tensor
+    fake_ops.install()
+    vae = _tiny_vae()
+    img, z = synth_tensor("img_tiled", (2, 3, 192, 160), scale=0.5), synth_tensor("z_tiled", (2, 4, 40, 32))
+    res = {}
+    with torch.no_grad():
+        for name, net, size, dec, x in (("enc", vae.denoise_encoder, 64, False, img), ("dec", vae.decoder, 8, True, z)):
+            serial = VAEHook(net, size, is_decoder=dec)(x)
+            par = VAEHook(net, size, is_decoder=dec, tile_parallel=True)(x)
+            res[name] = ((par - serial).norm() / serial.norm()).item()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_parallel_tiled_vae_matches_single_process():
+    """VAEHook(tile_parallel=True) on two ranks (tiles dealt round robin; one all-reduce of the pooled GroupNorm statistics per
+    norm layer, one of the assembled result) == the single-process tiled forward, batch of 2 images, encoder and decoder.  The
+    kernels are replaced by tests/fake_ops.py (plain torch): this checks the host logic -- SURVEY.md 8(e), row "Tiles"."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_vae_tile_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, errs in res:
+        assert errs["enc"] <= 2e-6 and errs["dec"] <= 2e-6, (rank, errs)
