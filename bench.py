@@ -281,6 +281,14 @@ def main():
     ap.add_argument("--diff-dtype", choices=["bf16", "fp16"], default="bf16",
                     help="element type of the UNet + control kernels: bf16 = BASELINE configs[1] (the metric); fp16 = the reference's "
                          "default diff_dtype, on the fp16 build of the kernels (reported in `dtype`, never the headline line)")
+    ap.add_argument("--tune", choices=["box", "file"], default="box",
+                    help="box (default): forget the shipped picks and time every kernel choice on THIS box during the warm-up image (a "
+                         "pick made on another box costs up to 3 %% here: profiles/r03/step_variants_*.log); file: run the picks of "
+                         "--tune-file / supir_amd/tune_gfx950.json as they are (what the test suite does: same kernels in every process)")
+    ap.add_argument("--tune-file", default=None, help="picks to load with --tune file (e.g. the file a previous run saved)")
+    ap.add_argument("--save-tune", default=None,
+                    help="where rank 0 writes the picks the timed region ran with (default: gpurun_out/tune_used.json when that directory "
+                         "exists), so that a profiler run of the same command can replay exactly these kernels (--tune file --tune-file ...)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -300,7 +308,16 @@ def main():
 
     from supir_amd import _lib
     _lib.load()  # fail loudly if the HIP extension is missing
+    from supir_amd import ops
     from supir_amd.synth import synth_tensor
+    shipped = (dict(ops._TUNE), dict(ops._CHOICE))
+    if args.tune == "box":
+        ops._TUNE.clear()
+        ops._CHOICE.clear()
+    elif args.tune_file:
+        ops._TUNE.clear()
+        ops._CHOICE.clear()
+        ops.load_tuning(args.tune_file)
 
     model, t_fill, t_bcast = build_model(device, rank, world)
     if args.diff_dtype == "fp16":
@@ -340,6 +357,13 @@ def main():
         if int(ch.item()) > 0:   # all ranks run the extra image (keeps them in step; the unchanged ones just replay)
             out = one_image(model, x, (c, uc), 1234 + rank, args.edm_steps)
         autotune_resynced = int(ch.item())
+    picks = {"mode": args.tune, "tile_picks": len(ops._TUNE), "choices": len(ops._CHOICE),
+             "differ_from_shipped_file": sum(1 for k, v in ops._TUNE.items() if k in shipped[0] and shipped[0][k] != v)
+             + sum(1 for k, v in ops._CHOICE.items() if k in shipped[1] and shipped[1][k] != v)}
+    save_to = args.save_tune or (os.path.join(ROOT, "gpurun_out", "tune_used.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+    if rank == 0 and save_to and args.warmup > 0:
+        ops.save_tuning(save_to)
+        picks["saved_to"] = os.path.relpath(save_to, ROOT)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -485,11 +509,12 @@ def main():
                        "images_per_gpu_per_step": ipg, "parallelism": f"dp{world} (replicated weights, no collective inside a sample)",
                        "hip_graph": not args.no_graph,
                        "two_stream_overlap": bool(model.model.overlap_branches),
+                       "paired_branch_launches": bool(model.model.pair_branches),
                        "fused_sampler_step": _fused_step_on()},
             "roofline": roofline, "cpu_baseline": cpu, "autotune_entries_resynced_max_over_ranks": autotune_resynced,
             "output_finite": finite, "weight_fill_s": round(t_fill, 2), "weight_broadcast_s": round(t_bcast, 2),
             "end_to_end_tflops_per_gpu": IMAGE_TFLOP_1024 * args.steps * ipg / dt if P == 1024 and args.edm_steps == 50 else None,
-            "kernel_breakdown_unet_step": breakdown,
+            "kernel_breakdown_unet_step": breakdown, "kernel_picks": picks,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)

@@ -8,6 +8,7 @@
 // These are HBM-bound kernels: 16-byte loads/stores, fp32 statistics, two launches per GroupNorm
 // (partial sums per row-chunk, then normalise+activate); the second read is served by L2 / Infinity Cache.
 #include "kernels.h"
+#include <stdlib.h>
 
 
 __device__ __forceinline__ const bf16_t* gn_src(const GnArgs& p, int b, int row, int c) {
@@ -86,7 +87,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgsN<NP> pp) {
 // and the loads of the first row batch -- x, gamma / beta, the ZeroSFT maps -- are issued BEFORE the statistics are reduced: the
 // launch is a chain of dependent round trips (partials -> statistics -> rows -> store, ~8.7 us whatever the row loop does,
 // profiles/r02/groupnorm_more_loads_in_flight_experiment.log) and this overlaps the two longest of them.
-template <int NP>
+// MOD = the ZeroSFT form (modulation maps, optional lerp): its extra row operands live in registers only in that instantiation -- the
+// plain form must stay small (<= 64 VGPRs: eight waves per SIMD), a streaming kernel lives on the loads the resident waves keep in
+// flight (a first version with one 150-register body ran the 16384 x 320 map in 46.8 us instead of 31).
+template <int NP, bool MOD>
 __global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int nchunk_apply, int rows_per_chunk_apply, int TY) {
     const GnArgs& p = pp.p[NP == 1 ? 0 : blockIdx.z];
     __shared__ float s_mean[32], s_rstd[32];
@@ -97,19 +101,20 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int
     const int v = tid % cv, ty = tid / cv, c = v * 8;
     const int row0 = chunk * rows_per_chunk_apply;
     const int row1 = min(p.HW, row0 + rows_per_chunk_apply);
-    const bool lerp = p.cscale != 1.0f && p.mod_g;
-    constexpr int U = 4;   // rows in flight per thread
+    const bool lerp = MOD && p.cscale != 1.0f;
+    constexpr int U = 2;   // rows in flight per thread (4 cost 83 VGPRs = 5 waves per SIMD instead of 8)
     // ---- loads that do not depend on the statistics: this thread's affine parameters and its first U rows
     const f32x4 g0 = *(const f32x4*)(p.gamma + c), g1 = *(const f32x4*)(p.gamma + c + 4);
     const f32x4 be0 = *(const f32x4*)(p.beta + c), be1 = *(const f32x4*)(p.beta + c + 4);
-    u16x8 xv[U], gv[U], bv[U], rv[U];
+    constexpr int UM = MOD ? U : 1;
+    u16x8 xv[U], gv[UM], bv[UM], rv[UM];
     auto load_rows = [&](int row) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int r = row + u * TY;
             if (r < row1) {
                 xv[u] = *(const u16x8*)gn_src(p, b, r, c);
-                if (p.mod_g) {
+                if constexpr (MOD) {
                     const size_t mo = ((size_t)b * p.HW + r) * p.ldm + c;
                     gv[u] = *(const u16x8*)(p.mod_g + mo);
                     bv[u] = *(const u16x8*)(p.mod_b + mo);
@@ -175,27 +180,21 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int
         sb[e] = (e < 4 ? be0[e] : be1[e - 4]) - s_mean[g] * a;
     }
     if (ty >= TY) return;   // (never: the block is exactly cv x TY threads)
+    const bool silu = p.act == 1;
     for (int row = row0 + ty; row < row1; row += U * TY) {
         u16x8 ov[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float y[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = bf2f(xv[u][e]) * sa[e] + sb[e];
-            if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
-            }
-            if (p.mod_g) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = y[e] * (bf2f(gv[u][e]) + 1.0f) + bf2f(bv[u][e]);
-                if (lerp) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = y[e] * p.cscale + bf2f(rv[u][e]) * (1.0f - p.cscale);
+            for (int e = 0; e < 8; ++e) {
+                float y = bf2f(xv[u][e]) * sa[e] + sb[e];
+                if (silu) y = silu_f(y);
+                if constexpr (MOD) {
+                    y = y * (bf2f(gv[u][e]) + 1.0f) + bf2f(bv[u][e]);
+                    if (lerp) y = y * p.cscale + bf2f(rv[u][e]) * (1.0f - p.cscale);
                 }
+                ov[u][e] = f2bf(y);
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[u][e] = f2bf(y[e]);
         }
         const int next = row + U * TY;
         const int here = row;
@@ -205,6 +204,103 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int
             const int r = here + u * TY;
             if (r < row1) *(u16x8*)(p.out + ((size_t)b * p.HW + r) * p.ldo + c) = ov[u];
         }
+    }
+}
+
+// v1 of the apply pass (round 1-2: [C] x 2 scale / shift table in LDS, flat item loop), kept selectable (SUPIR_GN_APPLY=v1) for in-process A/B
+template <int NP>
+__global__ __launch_bounds__(256) void gn_apply_kernel_v1(const GnArgsN<NP> pp, int nchunk_apply, int rows_per_chunk_apply) {
+    const GnArgs& p = pp.p[NP == 1 ? 0 : blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sA = (float*)smem_raw;  // [C] scale
+    float* sB = sA + p.C;          // [C] shift
+    __shared__ float s_mean[32], s_rstd[32];
+    __shared__ double s_part[4][64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int cv = p.C >> 3, cpg = p.C >> 5;
+    if (p.part_u1) {
+        // statistics left behind by the producer GEMM / conv epilogues (GemmArgs::gn_part_out): (sum, sum of squares) per tile row
+        // and 10-channel unit of each source tensor.  Group g = units [g * upg, (g + 1) * upg) of the concatenation; every group
+        // width on the path is a multiple of 10 (dispatcher).  Same fixed order on every workgroup -> reproducible.
+        const int v = tid & 63, sub = tid >> 6, g = v >> 1, st = v & 1;
+        const int upg = cpg / 10, U1 = p.C1 / 10, U2 = (p.C - p.C1) / 10;
+        double a = 0.0;
+        for (int uu = g * upg; uu < (g + 1) * upg; ++uu) {
+            const bool first = uu < U1;
+            const float* src = first ? p.part_u1 : p.part_u2;
+            const int nch = first ? p.nch1 : p.nch2, U = first ? U1 : U2, u = first ? uu : uu - U1;
+            for (int k = sub; k < nch; k += 4) a += (double)src[(((size_t)b * nch + k) * U + u) * 2 + st];
+        }
+        s_part[sub][v] = a;
+    } else if (!p.given) {
+        // all 256 threads reduce the per-chunk partials (fixed order -> reproducible): value v = tid&63, chunks sub, sub+4, ...
+        const int v = tid & 63, sub = tid >> 6;
+        double a = 0.0;
+        for (int k = sub; k < p.nchunk; k += 4) a += (double)p.partial[((size_t)b * p.nchunk + k) * 64 + v];
+        s_part[sub][v] = a;
+    }
+    __syncthreads();
+    if (p.given) {
+        // externally pooled statistics (tiled VAE: SUPIR/utils/tilevae.py:524-553 custom_group_norm)
+        if (tid < 32) {
+            s_mean[tid] = p.given[((size_t)b * 32 + tid) * 2];
+            s_rstd[tid] = rsqrtf(p.given[((size_t)b * 32 + tid) * 2 + 1] + p.eps);
+        }
+    } else if (tid < 32) {
+        const double s = s_part[0][2 * tid] + s_part[1][2 * tid] + s_part[2][2 * tid] + s_part[3][2 * tid];
+        const double q = s_part[0][2 * tid + 1] + s_part[1][2 * tid + 1] + s_part[2][2 * tid + 1] + s_part[3][2 * tid + 1];
+        const double n = (double)p.HW * (double)cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        const int g = c / cpg;
+        const float a = s_rstd[g] * p.gamma[c];
+        sA[c] = a;
+        sB[c] = p.beta[c] - s_mean[g] * a;
+    }
+    __syncthreads();
+    const int row0 = chunk * rows_per_chunk_apply;
+    const int row1 = min(p.HW, row0 + rows_per_chunk_apply);
+    const int items = (row1 - row0) * cv;
+    const bool lerp = p.cscale != 1.0f;
+    for (int idx = tid; idx < items; idx += 256) {
+        const int r = idx / cv, v = idx - r * cv;
+        const int row = row0 + r, c = v * 8;
+        const u16x8 xv = *(const u16x8*)gn_src(p, b, row, c);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = bf2f(xv[e]) * sA[c + e] + sB[c + e];
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = silu_f(y[e]);
+        }
+        if (p.mod_g) {
+            const size_t mo = ((size_t)b * p.HW + row) * p.ldm + c;
+            const u16x8 gv = *(const u16x8*)(p.mod_g + mo);
+            const u16x8 bv = *(const u16x8*)(p.mod_b + mo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = y[e] * (bf2f(gv[e]) + 1.0f) + bf2f(bv[e]);
+            if (lerp) {
+                u16x8 rv = xv;  // h_raw = cat[h_ori, h] (h BEFORE the zero_conv projection)
+                if (c < p.C1) {
+                    if (p.x1raw) rv = *(const u16x8*)(p.x1raw + ((size_t)b * p.HW + row) * p.ld1 + c);
+                } else if (p.x2raw) {
+                    rv = *(const u16x8*)(p.x2raw + ((size_t)b * p.HW + row) * p.ld2 + (c - p.C1));
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = y[e] * p.cscale + bf2f(rv[e]) * (1.0f - p.cscale);
+            }
+        }
+        u16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = f2bf(y[e]);
+        *(u16x8*)(p.out + ((size_t)b * p.HW + row) * p.ldo + c) = ov;
     }
 }
 
@@ -261,7 +357,15 @@ static int gn_launch(const GnArgs* a_in, hipStream_t st) {
     int ty = (256 + cv - 1) / cv;
     if (ty > 512 / cv) ty = 512 / cv;
     if (ty < 1) ty = 1;
-    SUPIR_LAUNCH(gn_apply_kernel<NP>, dim3(nca, a.B, NP), dim3(cv * ty), 0, st, pp, nca, rpc, ty);
+    for (int q = 1; q < NP; ++q)
+        if ((pp.p[q].mod_g == nullptr) != (a.mod_g == nullptr)) return SUPIR_ERR_SHAPE;
+    const char* gn_env = getenv("SUPIR_GN_APPLY");   // read per launch: tools flip it between the variants of an in-process A/B
+    if (gn_env && gn_env[0] == 'v' && gn_env[1] == '1') {
+        SUPIR_LAUNCH(gn_apply_kernel_v1<NP>, dim3(nca, a.B, NP), dim3(256), (size_t)a.C * 2 * sizeof(float), st, pp, nca, rpc);
+        return SUPIR_LAUNCH_STATUS();
+    }
+    if (a.mod_g) SUPIR_LAUNCH((gn_apply_kernel<NP, true>), dim3(nca, a.B, NP), dim3(cv * ty), 0, st, pp, nca, rpc, ty);
+    else SUPIR_LAUNCH((gn_apply_kernel<NP, false>), dim3(nca, a.B, NP), dim3(cv * ty), 0, st, pp, nca, rpc, ty);
     return SUPIR_LAUNCH_STATUS();
 }
 

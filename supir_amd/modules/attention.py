@@ -191,7 +191,7 @@ class BasicTransformerBlock(nn.Module):
 
         if T % 64 == 0 and ops.gemm_qkv_supported(B * T, 3 * inner, 2 * inner, C, T):
             # one launch for q | k | v^T instead of two when it is faster for this shape (timed once, outside graph capture)
-            which = ops.choose(("qkv", B * T, 3 * inner, C) + ops._k(x.dtype), (qkv_separate, qkv_fused))
+            which = ops.choose(("qkv", B * T, 3 * inner, C) + ops._k(x.dtype), (qkv_separate, qkv_fused), prefer=1)
             qk, vt = qkv_fused() if which == 1 else qkv_separate()
         else:
             qk, vt = qkv_separate()

@@ -845,9 +845,13 @@ def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, ou
     return out_qk, out_vt
 
 
-def choose(key, fns):
+def choose(key, fns, prefer=None, margin=0.1):
     """Time alternative implementations of the same step once (outside graph capture) and remember the faster one:
-    returns the index into `fns`.  Used where two launch sequences compute the same tensors (fused q|k|v vs two projections)."""
+    returns the index into `fns`.  Used where two launch sequences compute the same tensors (fused q|k|v vs two projections).
+    prefer = index of the alternative with FEWER launches: it is kept unless another one is faster by more than `margin` -- the
+    timing here is back-to-back and hot, where a launch costs ~2 us; inside a step every launch also meets its weights cold
+    (+4..6 us), so near-ties go to the shorter sequence (fused q|k|v at (2048, 3840, 1280): a tie here, -0.7 ms per step there,
+    profiles/r02/step_ab_fused_qkv.log, profiles/r03/step_variants_*.log)."""
     c = _CHOICE.get(key)
     if c is not None:
         return c
@@ -865,6 +869,8 @@ def choose(key, fns):
         e1.synchronize()
         times.append((e0.elapsed_time(e1), i))
     c = min(times)[1]
+    if prefer is not None and c != prefer and min(times)[0] > (1.0 - margin) * dict((i, t_) for t_, i in times)[prefer]:
+        c = prefer
     _CHOICE[key] = c
     return c
 

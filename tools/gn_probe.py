@@ -13,7 +13,9 @@ from supir_amd import ops
 
 BF = torch.bfloat16
 torch.manual_seed(0)
-for (B, HW, C, C2) in [(2, 16384, 320, 0), (2, 16384, 640, 320), (2, 4096, 640, 0), (2, 4096, 1280, 640), (2, 1024, 1280, 0), (2, 1024, 1280, 1280)]:
+SHAPES = [(2, 16384, 320, 0), (2, 16384, 640, 320), (2, 4096, 640, 0), (2, 4096, 1280, 640), (2, 1024, 1280, 0), (2, 1024, 1280, 1280),
+          (1, 1 << 20, 128, 0), (1, 1 << 18, 256, 0), (1, 1 << 16, 512, 0)]     # + the VAE's 1024^2 / 512^2 / 256^2 maps
+for (B, HW, C, C2) in SHAPES:
     x = torch.randn(B, HW, C, device="cuda").to(BF)
     x2 = torch.randn(B, HW, C2, device="cuda").to(BF) if C2 else None
     g, b = torch.rand(C + C2, device="cuda") + 0.5, torch.randn(C + C2, device="cuda")
