@@ -1,0 +1,67 @@
+"""Merge a pmc_summary.json (tools/pmc_summarize.py) into profiles/pmc_traffic.json: per bench kernel name and shape the
+counter-measured fetch / write bytes per launch, their ratio to the algorithmic bytes, and (when the SQ pass is present) MFMA busy
+over SQ busy and the LDS bank-conflict ratio.  Cases (tools/pmc_probe.py's cases.json) are matched to counter rows by kernel family and
+grid size (work-items = workgroups x threads).
+Usage: python tools/pmc_to_traffic.py cases.json pmc_summary.json profiles/pmc_traffic.json "note text" """
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from supir_amd.ops import gemm_tile_name  # noqa: E402
+
+cases, summ, out_path, note = json.load(open(sys.argv[1])), json.load(open(sys.argv[2])), sys.argv[3], sys.argv[4]
+G16 = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320)}
+out = json.load(open(out_path)) if os.path.exists(out_path) else {}
+out["note"] = note
+
+
+def find(prefix, grid):
+    for k, e in summ.items():
+        if k.startswith(prefix) and k.endswith(f"grid={grid}"):
+            return e
+    return None
+
+
+for c in cases:
+    kind, shape, tile = c["kind"], c["shape"], c["tile"]
+    if kind in ("gemm", "gemm_geglu", "conv3x3"):
+        if kind == "conv3x3":
+            b, hw, ch = shape.split()
+            B, (H, W), (Cin, Cout) = int(b[1:]), map(int, hw.split("x")), map(int, ch.split("->"))
+            M, N = B * H * W, Cout
+        else:
+            M, N = (int(t[1:]) for t in shape.split()[:2])
+        bm, bn = G16[tile]
+        grid = (M // bm) * (N // bn) * 512
+        e = find("geglu_big_kernel" if tile == 37 else "gemm16_kernel", grid)
+        name = gemm_tile_name(M, N, 2 if kind == "gemm_geglu" else 0, conv=(kind == "conv3x3"), tile=tile)
+    elif kind == "attn":
+        B, H, Tq = (int(t.lstrip("BHTq")) for t in shape.split()[:3])
+        e = find("attn_d64_pipe_kernel", ((Tq + 127) // 128) * H * B * 256)
+        name = "attn"
+    else:
+        continue
+    if e is None:
+        print("no counter row for", kind, shape, tile)
+        continue
+    rec = {"shape": shape + (" geglu" if kind == "gemm_geglu" else ""), "algorithmic_bytes": c["algorithmic_bytes"]}
+    if "fetch_bytes" in e:
+        rec["fetch_bytes"] = e["fetch_bytes"]
+    if "write_bytes" in e:
+        rec["write_bytes"] = e["write_bytes"]
+    if "fetch_bytes" in e and "write_bytes" in e:
+        rec["fetch_plus_write_over_algorithmic"] = round((e["fetch_bytes"] + e["write_bytes"]) / c["algorithmic_bytes"], 2)
+    if "mfma_busy_over_sq_busy" in e:
+        rec["mfma_busy_over_sq_busy"] = round(e["mfma_busy_over_sq_busy"], 3)
+    if e.get("SQ_LDS_IDX_ACTIVE"):
+        rec["lds_bank_conflict_over_idx_active"] = round(e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"], 3)
+    lst = [x for x in out.get(name, []) if isinstance(x, dict) and x.get("shape") != rec["shape"]] if isinstance(out.get(name), list) else []
+    out[name] = lst + [rec]
+# GroupNorm apply kernel: conflict ratio per grid (no traffic model needed: read + write once)
+gn = {k: {"lds_bank_conflict_over_idx_active": round(e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"], 3)}
+      for k, e in summ.items() if k.startswith("gn_apply_kernel") and e.get("SQ_LDS_IDX_ACTIVE")}
+if gn:
+    out["groupnorm_apply_lds"] = gn
+json.dump(out, open(out_path, "w"), indent=1)
+print("updated", out_path, "kernels:", [k for k in out if k != "note"])
