@@ -16,11 +16,17 @@ out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 out["note"] = note
 
 
+seen = {}
+
+
 def find(prefix, grid):
-    for k, e in summ.items():
-        if k.startswith(prefix) and k.endswith(f"grid={grid}"):
-            return e
-    return None
+    """The counter row of the next case on this (kernel, grid): cases that share both come in dispatch order ("#0", "#1", ...)."""
+    keys = sorted(k for k in summ if k.startswith(prefix) and (k.endswith(f"grid={grid}") or f"grid={grid} #" in k))
+    if not keys:
+        return None
+    i = seen.get((prefix, grid), 0)
+    seen[(prefix, grid)] = i + 1
+    return summ[keys[min(i, len(keys) - 1)]]
 
 
 for c in cases:
@@ -34,7 +40,9 @@ for c in cases:
             M, N = (int(t[1:]) for t in shape.split()[:2])
         bm, bn = G16[tile]
         grid = (M // bm) * (N // bn) * 512
-        e = find("geglu_big_kernel" if tile == 37 else "gemm16_kernel", grid)
+        targs = {32: "128, 80, 4, 1, 2, 2", 33: "128, 160, 2, 2, 2, 2", 34: "256, 160, 8, 1, 1, 3", 35: "128, 80, 4, 1, 2, 3"}
+        e = find("geglu_big_kernel", grid) if tile == 37 else \
+            find(f"gemm16_kernel<{targs[tile]}, false, {'true' if kind == 'conv3x3' else 'false'}, false, 1>", grid)
         name = gemm_tile_name(M, N, 2 if kind == "gemm_geglu" else 0, conv=(kind == "conv3x3"), tile=tile)
     elif kind == "attn":
         B, H, Tq = (int(t.lstrip("BHTq")) for t in shape.split()[:3])
@@ -53,7 +61,10 @@ for c in cases:
     if "fetch_bytes" in e and "write_bytes" in e:
         rec["fetch_plus_write_over_algorithmic"] = round((e["fetch_bytes"] + e["write_bytes"]) / c["algorithmic_bytes"], 2)
     if "mfma_busy_over_sq_busy" in e:
+        # SQ_VALU_MFMA_BUSY_CYCLES accumulates over the 32 SIMD-slots an SQ_BUSY_CYCLES tick spans (profiles/r02: 8.8 "of 32"):
+        # / 32 = the share of cycles the matrix pipes were busy while the kernel was resident
         rec["mfma_busy_over_sq_busy"] = round(e["mfma_busy_over_sq_busy"], 3)
+        rec["mfma_busy_frac"] = round(e["mfma_busy_over_sq_busy"] / 32.0, 3)
     if e.get("SQ_LDS_IDX_ACTIVE"):
         rec["lds_bank_conflict_over_idx_active"] = round(e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"], 3)
     lst = [x for x in out.get(name, []) if isinstance(x, dict) and x.get("shape") != rec["shape"]] if isinstance(out.get(name), list) else []
