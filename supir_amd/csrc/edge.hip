@@ -16,6 +16,10 @@
 
 // ---------------------------------------------------------------------------------------------------------
 // weights: fp32 [Cout][Cin][3][3] (the reference's nn.Conv2d layout, untouched)
+// A thread computes 8 output channels of TWO horizontally adjacent pixels: the 9 x Cin weight vectors (2 x 16 B from LDS per tap) are
+// read once for both and the 3 x 4 input window is shared (12 instead of 18 loads per input channel).  The grid is capped at two
+// workgroups per CU: every workgroup first stages the whole [Cin*9][Cout] fp32 table into LDS (46 KB for 4 -> 320), and with the
+// earlier cap of 2048 workgroups that prologue was most of the launch (119 us for a 0.75 GFLOP, 21 MB-output convolution).
 __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias,
                                                                const bf16_t* __restrict__ add, bf16_t* __restrict__ out,
@@ -25,53 +29,66 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __re
     float* sw = (float*)smem_raw;  // [Cin*9][Cout]
     const int tid = threadIdx.x;
     const int K = Cin * 9;
-    for (int i = tid; i < K * Cout; i += 256) {
-        const int co = i / K, k = i - co * K;
-        sw[k * Cout + co] = w[i];
+    for (int i = tid; i < K * Cout; i += 256) {   // i = k * Cout + co: consecutive lanes write consecutive LDS words
+        const int k = i / Cout, co = i - k * Cout;
+        sw[i] = w[(size_t)co * K + k];
     }
     __syncthreads();
     const int cvo = Cout >> 3;
-    const long total = (long)B * H * W * cvo;
+    const int W2 = (W + 1) >> 1;                   // pixel pairs per row (the last pair of an odd row has one pixel)
+    const long total = (long)B * H * W2 * cvo;
     for (long idx = (long)blockIdx.x * 256 + tid; idx < total; idx += (long)gridDim.x * 256) {
         const int v = (int)(idx % cvo);
-        const long pix = idx / cvo;
-        const int xw = (int)(pix % W);
-        const int yh = (int)((pix / W) % H);
-        const int b = (int)(pix / ((long)W * H));
+        const long pp = idx / cvo;
+        const int xw = (int)(pp % W2) * 2;
+        const int yh = (int)((pp / W2) % H);
+        const int b = (int)(pp / ((long)W2 * H));
+        const bool two = xw + 1 < W;
         const int co = v * 8;
-        float acc[8];
+        float acc[2][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[co + e] : 0.f;
+        for (int e = 0; e < 8; ++e) acc[0][e] = acc[1][e] = bias ? bias[co + e] : 0.f;
         for (int ci = 0; ci < Cin; ++ci) {
             const float* xp = x + ((size_t)b * Cin + ci) * H * W;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = yh + ky - 1;
                 if ((unsigned)iy >= (unsigned)H) continue;
+                float xin[4];   // columns xw - 1 .. xw + 2 of this input row (zero outside the image)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ix = xw - 1 + j;
+                    xin[j] = (unsigned)ix < (unsigned)W ? xp[(size_t)iy * W + ix] : 0.f;
+                }
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = xw + kx - 1;
-                    if ((unsigned)ix >= (unsigned)W) continue;
-                    const float xv = xp[(size_t)iy * W + ix];
                     const float* wp = sw + ((ci * 3 + ky) * 3 + kx) * Cout + co;
                     const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+                    const float x0 = xin[kx], x1 = xin[kx + 1];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        acc[e] += xv * w0[e];
-                        acc[4 + e] += xv * w1[e];
+                        acc[0][e] += x0 * w0[e];
+                        acc[0][4 + e] += x0 * w1[e];
+                        acc[1][e] += x1 * w0[e];
+                        acc[1][4 + e] += x1 * w1[e];
                     }
                 }
             }
         }
-        if (add) {
-            const u16x8 av = *(const u16x8*)(add + (size_t)pix * ld_add + co);
+        const long pix = ((long)b * H + yh) * W + xw;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += bf2f(av[e]);
+        for (int q = 0; q < 2; ++q) {
+            if (q == 1 && !two) break;
+            if (add) {
+                const u16x8 av = *(const u16x8*)(add + (size_t)(pix + q) * ld_add + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[q][e] += bf2f(av[e]);
+            }
+            u16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[q][e]);
+            *(u16x8*)(out + (size_t)(pix + q) * ldo + co) = ov;
         }
-        u16x8 ov;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[e]);
-        *(u16x8*)(out + (size_t)pix * ldo + co) = ov;
     }
 }
 
@@ -86,9 +103,9 @@ int supir_conv3x3_smallcin_launch(const float* x, const float* w, const float* b
                                 160 * 1024)) != SUPIR_OK) return SUPIR_ERR_HIP;
         attr = true;
     }
-    const long total = (long)B * H * W * (Cout / 8);
+    const long total = (long)B * H * ((W + 1) / 2) * (Cout / 8);
     long blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;      // two workgroups per CU: the weight-table prologue is paid 512 times, not 2048
     SUPIR_LAUNCH(conv3x3_smallcin_kernel, dim3((unsigned)blocks), dim3(256), smem, st, x, w, bias, add, out, B, Cin,
                        H, W, Cout, ld_add, ldo);
     return SUPIR_LAUNCH_STATUS();

@@ -98,3 +98,47 @@ def test_round2_entry_points_validate_arguments_without_a_gpu():
     # tile 32 (128 x 80) on an inexact shape is refused, not silently run on another tile
     assert lib.supir_gemm_bf16(fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 32, None) == -2
     assert lib.supir_gemm_bf16(fake, fake, fake, 128, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 36, None) == -1   # no such tile
+
+
+def test_grouped_launch_structs_match_the_header_layout(tmp_path):
+    """The host-side structs of the grouped-launch entry points (supir_gemm_problem / supir_gemm_shape / supir_attn_problem /
+    supir_gn_problem): the ctypes mirrors in supir_amd/_lib.py against what a C compiler makes of include/supir_hip.h (size and the
+    offset of every field), and argument validation without a GPU."""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no C compiler")
+    pairs = {"supir_gemm_problem": _lib.GemmProblem, "supir_gemm_shape": _lib.GemmShape, "supir_attn_problem": _lib.AttnProblem,
+             "supir_gn_problem": _lib.GnProblem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "supir_hip.h")}"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)   # also: the header is plain C
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+    lib = _lib.load()
+    sh = _lib.GemmShape(kind=0, tile=35, M=2048, N=1280, K=1280, alpha=1.0)
+    pr = (_lib.GemmProblem * 2)()
+    assert lib.supir_gemm_grouped(None, pr, 2, None) == -1
+    assert lib.supir_gemm_grouped(ctypes.byref(sh), pr, 3, None) == -1            # at most two problems
+    assert lib.supir_gemm_grouped(ctypes.byref(sh), pr, 2, None) == -1            # null operands
+    fake = 0x10000
+    for q in pr:
+        q.A, q.W, q.C, q.lda, q.ldc = fake, fake, fake, 1280, 1280
+    sh.tile = 32
+    assert lib.supir_gemm_grouped(ctypes.byref(sh), pr, 2, None) == -2            # tile 32 has no two-problem form
+    sh.tile, sh.M = 35, 2000
+    assert lib.supir_gemm_grouped(ctypes.byref(sh), pr, 2, None) == -2            # inexact shape
+    assert lib.supir_flash_attn_d64_grouped(None, 2, 2, 20, 1024, 0.125, None) == -1
+    assert lib.supir_groupnorm_grouped(None, 2, 2, 1024, 1280, 1e-5, 1, None) == -1
