@@ -171,10 +171,21 @@ def cpu_baseline(model, device, budget_s=60.0):
     if UNET_STEP_TFLOP[128] / rate <= budget_s:
         x1 = synth_tensor("bench.x", (2, 4, 128, 128))
         cond1 = dict(cond, control=synth_tensor("bench.lq", (2, 4, 128, 128)))
-        with torch.no_grad():
-            t0 = time.time()
-            O.control_wrapper(sd, x1, t, cond1, 1.0)
-            step_1024_s = time.time() - t0
+        # the small sample may prefer fewer threads than the production-size call (its GEMMs are 16x larger): try twice the count too
+        per_threads = {}
+        for th in (threads, 2 * threads):
+            if th > (os.cpu_count() or 1) or (per_threads and th > 64):
+                continue
+            torch.set_num_threads(th)
+            with torch.no_grad():
+                t0 = time.time()
+                O.control_wrapper(sd, x1, t, cond1, 1.0)
+                per_threads[th] = time.time() - t0
+        threads = min(per_threads, key=per_threads.get)
+        torch.set_num_threads(threads)
+        step_1024_s = per_threads[threads]
+        res["cores"] = threads
+        res["unet_step_1024px_seconds_by_threads"] = {k: round(v, 2) for k, v in per_threads.items()}
         res["unet_step_1024px_cfg_doubled_s"] = round(step_1024_s, 2)
         res["unet_step_1024px_tflops"] = round(UNET_STEP_TFLOP[128] / step_1024_s, 3)
     if cfg1_tflop / rate <= budget_s:

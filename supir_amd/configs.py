@@ -31,7 +31,8 @@ def supir_v0_config(transformer_depth=None, sampler="RestoreEDMSampler", sampler
             "control_stage_config": {"target": "SUPIR.modules.SUPIR_v0.GLVControl", "params": dict(unet, input_upscale=1)},
             "network_config": {"target": "SUPIR.modules.SUPIR_v0.LightGLVUNet",
                                "params": dict(unet, mode="XL-base", project_type="ZeroSFT", project_channel_scale=2)},
-            "conditioner_config": None,  # text encoders are out of scope; cond=(c, uc) is passed in
+            "conditioner_config": None,  # bench / smoke pass prepared cond=(c, uc) (no tokeniser vocabulary in this image); the YAML's
+            # conditioner_config builds supir_amd.modules.conditioner through the plugin like every other target
             "first_stage_config": {"target": "sgm.models.autoencoder.AutoencoderKLInferenceWrapper",
                                    "params": {"ckpt_path": None, "embed_dim": 4, "monitor": "val/rec_loss",
                                               "ddconfig": dict(_VAE_DD), "lossconfig": {"target": "torch.nn.Identity"}}},

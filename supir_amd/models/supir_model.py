@@ -154,7 +154,7 @@ class SUPIRModel(nn.Module):
 
     def prepare_condition(self, _z, p, p_p, n_p, N):
         if self.conditioner is None:
-            raise RuntimeError("no text conditioner attached (out of scope: SURVEY.md section 2); pass cond=(c, uc) with "
+            raise RuntimeError("no text conditioner attached (conditioner_config was None); pass cond=(c, uc) with "
                                "crossattn [N,77,2048] / vector [N,2816], or attach a conditioner object")
         batch = {"original_size_as_tuple": torch.tensor([1024, 1024]).repeat(N, 1).to(_z.device),
                  "crop_coords_top_left": torch.tensor([0, 0]).repeat(N, 1).to(_z.device),
