@@ -190,6 +190,9 @@ class VAEHook:
         in_b, out_b = split_tiles(height, width, self.tile_size, self.pad, dec)
         rank, world, group = self._ranks()
         mine = assign_tiles(len(in_b), rank, world)
+        if not mine:
+            raise RuntimeError(f"tile-parallel tiled VAE: {len(in_b)} tiles for {world} ranks leaves rank {rank} without work; use a "
+                               "process group no larger than the tile count")
         z = z.float()
         # shape groups of this rank's tiles, in order of first appearance
         groups = {}
