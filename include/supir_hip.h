@@ -252,6 +252,16 @@ int supir_prefetch(const void* p, size_t bytes, void* sink, void* stream);
  * No reference counterpart (the reference's cuBLAS / cuDNN calls meet every weight cold each step as well). */
 int supir_set_next_prefetch(const void* p, size_t bytes);
 
+/* Split-K form of supir_conv3x3_bf16 for convolutions whose tile grid is a fraction of the machine and whose K = 9 * Cin is long -- the
+ * `mlp_shared` convolutions of ZeroSFT (SUPIR/modules/SUPIR_v0.py:72-75, 100: label_nc -> 128 channels: 64 tiles of 64 x 64 at 32 x 32
+ * with 180 K steps each).  The grid becomes ksplit x the tile grid; split s accumulates K steps [s, s + 1) * K / ksplit (with ksplit = 9:
+ * one filter tap each) and writes its fp32 partial at partials[s][M][Cout] (M = B * OH * OW); supir_splitk_finalize then sums the partials
+ * in split order (deterministic), adds the bias, applies the activation (0 none, 1 SiLU) and stores bf16.  tile 0..3 (csrc/gemm.hip);
+ * (9 * Cin) % (64 * ksplit) == 0, Cin % 64 == 0, Cout % 4 == 0. */
+int supir_conv3x3_bf16_splitk(const void* X, const void* W, float* partials, int B, int H, int Wd, int Cin, int ldx, int Cout, int OH,
+                              int OW, int stride, int pad_t, int pad_l, int upsample, int ksplit, int tile, void* stream);
+int supir_splitk_finalize(const float* partials, int ksplit, int M, int N, const float* bias, int act, void* out, int ldo, void* stream);
+
 /* ---- Grouped launches: n (1 or 2) independent problems of identical shape in ONE kernel launch ------------------------------------
  * SUPIR runs two networks of identical architecture on independent data inside every sampling step: GLVControl (the control
  * branch, SUPIR/modules/SUPIR_v0.py:499-540) and the encoder half of LightGLVUNet (:600-625) -- the same ResBlock /

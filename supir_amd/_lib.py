@@ -78,6 +78,8 @@ class GnProblem(ctypes.Structure):
 GROUP_GEMM, GROUP_CONV3X3, GROUP_QKV = 0, 1, 2
 SIGNATURES.update({
     "supir_gemm_grouped": [P, P, I, P],
+    "supir_conv3x3_bf16_splitk": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "supir_splitk_finalize": [P, I, I, I, P, I, P, I, P],
     "supir_flash_attn_d64_grouped": [P, I, I, I, I, F, P],
     "supir_groupnorm_grouped": [P, I, I, I, I, F, I, P],
 })

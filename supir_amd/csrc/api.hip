@@ -136,6 +136,28 @@ int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int 
     return supir_gemm_launch(a, true, (hipStream_t)stream, tile);
 }
 
+int supir_conv3x3_bf16_splitk(const void* X, const void* W, float* partials, int B, int H, int Wd, int Cin, int ldx, int Cout, int OH,
+                              int OW, int stride, int pad_t, int pad_l, int upsample, int ksplit, int tile, void* stream) {
+    if (!X || !W || !partials) return SUPIR_ERR_ARG;
+    if (B <= 0 || H <= 0 || Wd <= 0 || OH <= 0 || OW <= 0 || ksplit < 2 || tile < 0 || tile > 3) return SUPIR_ERR_ARG;
+    if ((stride != 1 && stride != 2) || (upsample && stride != 1) || Cout % 4) return SUPIR_ERR_SHAPE;
+    GemmArgs a{};
+    a.A = (const bf16_t*)X; a.Wt = (const bf16_t*)W; a.C = partials;
+    a.M = B * OH * OW; a.N = Cout; a.K = 9 * Cin; a.lda = ldx; a.ldc = Cout;
+    a.rows_per_batch = OH * OW;
+    a.H = H; a.W = Wd; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.up = upsample ? 1 : 0;
+    a.out_mode = 1; a.alpha = 1.0f; a.ksplit = ksplit;
+    take_prefetch(a);
+    if (a.gn_part_out) return SUPIR_ERR_ARG;
+    return supir_gemm_launch(a, true, (hipStream_t)stream, tile);
+}
+
+int supir_splitk_finalize(const float* partials, int ksplit, int M, int N, const float* bias, int act, void* out, int ldo, void* stream) {
+    if (!partials || !out) return SUPIR_ERR_ARG;
+    return supir_splitk_finalize_launch(partials, ksplit, M, N, N, bias, act, (bf16_t*)out, ldo, (hipStream_t)stream);
+}
+
 int supir_flash_attn_d64_ex(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
                             int ldk, int ldvt, int ldo, float scale, int flags, void* stream) {
     if (!Q || !K || !Vt || !O || (flags & ~1)) return SUPIR_ERR_ARG;

@@ -84,13 +84,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
     const int half = lane >> 5, l31 = lane & 31;
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    // split-K: block = split * tiles + tile (GemmArgs::ksplit); bid = the tile part
+    const int ks_split = p.ksplit > 1 ? (int)blockIdx.x / (tiles_m * tiles_n) : 0;
+    const int bid = p.ksplit > 1 ? (int)blockIdx.x - ks_split * tiles_m * tiles_n : (int)blockIdx.x;
     // Workgroup -> tile: block b runs on XCD b % 8, and every XCD has a private 4 MB L2.  The host picks the partition of
     // the tile grid over the 8 XCDs that minimises what the L2s have to pull in (each XCD touching an operand panel
     // fetches its own copy): a gm x gn grid of XCD regions (each needing 1/gm of A and 1/gn of W), or, when the tile
     // counts do not divide, contiguous 1-D id ranges; `order` = which tile index runs fastest inside a region.
     int tile_m, tile_n;
     if (p.gm > 0) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd = bid & 7, idx = bid >> 3;
         const int rm = tiles_m / p.gm, rn = tiles_n / p.gn;
         const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
         int lm, ln;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
         tile_m = xm * rm + lm;
         tile_n = xn * rn + ln;
     } else {
-        const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        const int id = xcd_remap(bid, tiles_m * tiles_n);
         if (p.order == 0) { tile_n = id / tiles_m; tile_m = id - tile_n * tiles_m; }
         else { tile_m = id / tiles_n; tile_n = id - tile_m * tiles_n; }
     }
@@ -135,7 +138,18 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
     const int VH = p.up ? 2 * p.H : p.H, VW = p.up ? 2 * p.W : p.W;
     const bf16_t* zero = (const bf16_t*)g_zero_page;
 
-    int ld_k0 = KS > 1 ? kg * 64 : 0, ld_cin0 = 0, ld_ky = 0, ld_kx = 0;  // position of the NEXT tile to stage
+    const int nk_all = (p.K >> 6) / KS;                                     // K steps of this group without split-K
+    const int nk = p.ksplit > 1 ? nk_all / p.ksplit : nk_all;               // ... of this workgroup (the host guarantees divisibility)
+    const int k_begin = ks_split * nk * 64;                                 // (split-K only with KS == 1)
+    int ld_k0 = (KS > 1 ? kg * 64 : 0) + k_begin, ld_cin0 = 0, ld_ky = 0, ld_kx = 0;  // position of the NEXT tile to stage
+    if constexpr (CONV) {
+        if (k_begin > 0) {
+            const int tap0 = k_begin / p.Cin;
+            ld_cin0 = k_begin - tap0 * p.Cin;
+            ld_ky = tap0 / 3;
+            ld_kx = tap0 - ld_ky * 3;
+        }
+    }
     // conv: the tap (ky, kx) only changes every Cin/64 K steps, so the gather address of each A row (or "padding": null ->
     // zero page) is computed once per tap, not once per load: the im2col arithmetic was ~800 of the 1800-1950 cycles a K step
     // of the 128x128 conv tile took (s_memtime; the plain GEMM's K step is ~1050)
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
                                              (__attribute__((address_space(3))) void*)(smem + KS * S * STAGE), 4, 0, 0);
         }
     };
-    const int nk = (p.K >> 6) / KS;   // K steps of this group (the host only picks KS > 1 when K % (64 * KS) == 0)
+    // nk (above) = K steps of this group / workgroup (the host only picks KS > 1 when K % (64 * KS) == 0)
 #ifdef SUPIR_GEMM_TIMELINE
     unsigned long long tl_wait = 0, tl_bar = 0, tl_issue = 0, tl_comp = 0;
     const unsigned long long tl_t0 = TL_NOW();
@@ -570,7 +584,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
                             v[e] = t;
                         }
                         if constexpr (MODE == 1) {
-                            if (ok) *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+                            if (ok) *(f32x4*)((float*)p.C + (size_t)ks_split * p.M * p.ldc + (size_t)m * p.ldc + n) = v;
                         } else {
                             const u32x2 o = {f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3])};
                             const float r0 = bflo2f(o[0]), r1 = bfhi2f(o[0]), r2 = bflo2f(o[1]), r3 = bfhi2f(o[1]);
@@ -740,7 +754,7 @@ static int launch_gemm(const GemmArgs& a_in, hipStream_t st) {
         constexpr int lds = KS * S * (BM + BN) * 128 + 256;
         supir_choose_xcd_grid(a, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a_bytes, 2.0 * (double)a.N * a.K, CONV ? 9 : 1, 163840 / lds);
     }
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * (a.ksplit > 1 ? a.ksplit : 1);
     constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // ring(s) + the prefetch scratch row
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, S, CONV, TRANS, KS>;
     static bool attr_set = false;
@@ -806,6 +820,38 @@ static int dispatch_gemm(const GemmArgs& a, hipStream_t st, int force_tile) {
 #undef SUPIR_GEMM_CASE
 }
 
+// split-K finalize: out[m][n] = act(sum_s part[s][m][n] + bias[n]) in bf16; the partials are summed in split order (deterministic)
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ part, int ksplit, int M, int N, int ld_part,
+                                                              const float* __restrict__ bias, int act, bf16_t* __restrict__ out, int ldo) {
+    const int nv = N >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * nv) return;
+    const int m = (int)(idx / nv), n = (int)(idx - (long)m * nv) * 4;
+    f32x4 acc = *(const f32x4*)(part + (size_t)m * ld_part + n);
+    for (int s = 1; s < ksplit; ++s) {
+        const f32x4 v = *(const f32x4*)(part + ((size_t)s * M + m) * ld_part + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = acc[e] + (bias ? bias[n + e] : 0.f);
+        if (act == 1) t = silu_f(t);
+        y[e] = t;
+    }
+    const u32x2 o = {f2bf_pk(y[0], y[1]), f2bf_pk(y[2], y[3])};
+    *(u32x2*)(out + (size_t)m * ldo + n) = o;
+}
+
+int supir_splitk_finalize_launch(const float* part, int ksplit, int M, int N, int ld_part, const float* bias, int act, bf16_t* out, int ldo,
+                                 hipStream_t st) {
+    if (ksplit < 1 || M <= 0 || N <= 0 || N % 4 || ld_part % 4 || ldo % 4 || act < 0 || act > 1) return SUPIR_ERR_SHAPE;
+    const long total = (long)M * (N / 4);
+    SUPIR_LAUNCH(splitk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, ksplit, M, N, ld_part, bias, act, out, ldo);
+    return SUPIR_LAUNCH_STATUS();
+}
+
 // (sum, sum of squares) partials [M][ld][2] -> (mean, rstd) [M][2]; one thread per row, fixed summation order
 __global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int M,
                                                                 int ld, int slots, int dim, float eps) {
@@ -849,6 +895,11 @@ int supir_gemm_launch(const GemmArgs& a_in, bool conv, hipStream_t st, int force
         a.order = cost_n_fast < cost_m_fast ? 1 : 0;
     }
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return SUPIR_ERR_ARG;
+    if (a.ksplit > 1) {   // split-K: fp32 partials from the gemm.hip tiles 0..3 only, no epilogue terms, whole K steps per split
+        if (force_tile < 0 || force_tile > 3 || a.out_mode != 1 || a.bias || a.res || a.rowbias || a.act != 0 || a.alpha != 1.0f ||
+            a.rowstats_out || a.ln_stats || a.gn_part_out || a.K % (64 * a.ksplit) != 0)
+            return SUPIR_ERR_SHAPE;
+    }
     if (a.gn_part_out && (force_tile < 32 || force_tile > 35)) return SUPIR_ERR_SHAPE;   // GroupNorm partials: gemm16 epilogues only
     if (force_tile == 37) return conv ? SUPIR_ERR_SHAPE : supir_gemm_big_launch(a, st);   // 256 x 320 GEGLU tile (gemm_big.hip)
     if (force_tile >= 32) {   // the 16x16x32-MFMA, 256-workgroup tiles (gemm16.hip): exact shapes only

@@ -35,6 +35,11 @@ struct GemmArgs {
     // ---- GroupNorm statistics from the producer (supir_set_next_gn_partials): per (batch, tile row of BM tokens, 10-channel unit) the
     // (sum, sum of squares) of the bf16 values this launch stores: gn_part_out[((b * (rows_per_batch / BM) + chunk) * (N / 10) + unit) * 2]
     float* gn_part_out;
+    // ---- split-K (supir_conv3x3_bf16_splitk): ksplit > 1 -> the grid is ksplit x the tile grid; workgroup (tile, s) accumulates K
+    // steps [s, s + 1) * K / ksplit only and stores its fp32 partial at C + s * M * ldc (out_mode 1, no epilogue terms); a second
+    // launch (supir_splitk_finalize) sums the partials in a fixed order and applies bias / activation.  For the convolutions whose
+    // tile grid is a fraction of the machine and whose K is long (ZeroSFT mlp_shared: 1280 -> 128 at 32 x 32 = 64 tiles x 180 K steps)
+    int ksplit;
 };
 
 // Grouped launch: NP independent problems of IDENTICAL shape in one grid (supir_gemm_grouped & co).  Block b runs on XCD b % 8, so
@@ -90,6 +95,8 @@ struct GnArgsN {
 };
 
 int supir_gemm_select_tile(int M, int N, int act, int force_tile);
+int supir_splitk_finalize_launch(const float* part, int ksplit, int M, int N, int ld_part, const float* bias, int act, bf16_t* out, int ldo,
+                                 hipStream_t st);
 int supir_rowstats_finalize_launch(const float* part, float* out, int M, int ld, int slots, int dim, float eps, hipStream_t st);
 int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile);
 // nx = XCDs this problem's tiles are spread over (8; 4 for each problem of a two-problem grouped launch)

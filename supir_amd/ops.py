@@ -73,6 +73,9 @@ def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1, group=1):
     g = ",x2" if group == 2 else ""
     if tile == 37:
         return f"geglu_big_kernel<256,320,4x2{g}>"
+    if tile is not None and tile >= 64:      # tap-split convolution (supir_conv3x3_bf16_splitk + supir_splitk_finalize)
+        name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2"][tile - 64]
+        return f"gemm_bf16_kernel<{name},conv,split9>+finalize"
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}{g}>"
@@ -655,6 +658,7 @@ G16_TILES = {32, 33, 34, 35}   # enabled members of the family (tools/step_ab.py
 _G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3)}   # tile: (BM, BN, K groups, ring)
 USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc/gemm16.hip) in the autotune lists
 USE_GEMM_BIG = _os.environ.get("SUPIR_GEMM_BIG", "1") != "0"   # tile 37 (csrc/gemm_big.hip) in the GEGLU autotune lists
+USE_CONV_SPLIT = _os.environ.get("SUPIR_CONV_SPLIT", "1") != "0"   # tap-split conv3x3 (codes 64 + tile) in the autotune lists of small-grid convs
 
 
 def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu16=False, big_ok=True):
@@ -950,7 +954,20 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
         ld_rb = rowbias.stride(0)
     om = 0 if out.dtype == DT else 1
 
+    M_all = B * OH * OW
+    split_ws = []
+
     def launch(t, outp=None):
+        if t >= 64:
+            # tap-split form (supir_conv3x3_bf16_splitk): nine fp32 partials + a finalize launch (bias, SiLU, bf16), codes 64 + tile
+            if not split_ws:
+                split_ws.append(torch.empty(9 * M_all * Cout, dtype=torch.float32, device=x.device))
+            rc = lib.supir_conv3x3_bf16_splitk(x.data_ptr(), w.data_ptr(), split_ws[0].data_ptr(), B, H, W, Cin, ldx, Cout, OH, OW, stride,
+                                               pad[0], pad[1], 1 if upsample else 0, 9, t - 64, _stream())
+            if rc != 0:
+                return rc
+            return lib.supir_splitk_finalize(split_ws[0].data_ptr(), 9, M_all, Cout, _p(bias), act, (out if outp is None else outp).data_ptr(),
+                                             ldy, _stream())
         return lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), (out if outp is None else outp).data_ptr(), B, H, W, Cin, ldx, Cout,
                                       ldy, OH, OW, stride, pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb,
                                       _p(residual), ldr, act, om, alpha, t, _stream())
@@ -967,6 +984,10 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
             for t, (bm, bn, ks, s_) in _G16.items():   # same predicate as supir_gemm16_supported(conv)
                 if t in G16_TILES and M_ % bm == 0 and Cout % bn == 0 and Cin % (64 * ks) == 0 and (9 * Cin // 64) // ks >= s_ - 1:
                     cands.append(t)
+        # tap-split candidates for convolutions whose tile grid is a fraction of the machine: one workgroup set per filter tap
+        if USE_CONV_SPLIT and om == 0 and act in (0, 1) and residual is None and rowbias is None and alpha == 1.0 and Cin % 64 == 0 \
+                and Cout % 4 == 0 and ldy % 4 == 0 and ((M_ + 63) // 64) * ((Cout + 63) // 64) <= 128:
+            cands += [64 + 1, 64 + 2, 64 + 3]
         cands = tuple(cands)
         if inplace:
             tile = _TUNE.get(key, -1)
@@ -976,6 +997,8 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
             tile = -1
         single_tile = tile
         tile = _pair_tile(key, tile, cands)
+    if tile >= 64 and (act not in (0, 1) or residual is not None or rowbias is not None or om != 0):
+        raise _lib.SupirHipError("conv3x3: the tap-split tiles (64 + t) take no residual / row bias / fp32 output")
     part = _gn_part_alloc(tile, B, OH * OW, Cout, x.device) if (gn_part and om == 0) else None
 
     def make(t, outp=None):
@@ -991,7 +1014,7 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
                    single_tile=single_tile, cands=cands, make=make, w=w, part=part, out=out, inplace=inplace,
                    trace=("conv3x3", 2.0 * M * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + Cout * 9 * Cin + M * Cout),
                           dict(M=M, N=Cout, K=9 * Cin, act=act, tile=tile)),
-                   keep=(x, w, bias, rowbias, residual, out, part)))
+                   keep=(x, w, bias, rowbias, residual, out, part, split_ws)))
     return (out, part) if gn_part else out
 
 

@@ -812,3 +812,24 @@ def test_flash_attn_causal(B, H, T):
     check(out, ref, rel=6e-3, name="causal attention")
     # the first query only sees the first key: its output row is exactly v[0]
     assert torch.equal(out[:, 0], v[:, 0])
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,base", [(2, 32, 32, 1280, 128, 1, 3), (2, 32, 32, 640, 128, 1, 1), (2, 64, 64, 640, 128, 1, 2),
+                                                    (1, 24, 20, 128, 64, 0, 3), (2, 16, 16, 320, 132, 1, 3)])
+def test_conv3x3_tap_split(B, H, W, Cin, Cout, act, base):
+    """supir_conv3x3_bf16_splitk + supir_splitk_finalize (tile codes 64 + t of ops.conv3x3): nine per-tap fp32 partials summed in a
+    fixed order, bias + SiLU in the finalize pass -- against fp32 conv2d and against the single-launch form (same inputs; only the fp32
+    summation order over taps differs), bitwise repeatable."""
+    x = rnd(B, H, W, Cin).to(BF)
+    w = rnd(Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
+    bias = rnd(Cout, seed=2)
+    out = ops.conv3x3(x, w, bias, act=act, tile=64 + base)
+    out2 = ops.conv3x3(x, w, bias, act=act, tile=64 + base)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1)
+    ref = (F.silu(ref) if act else ref).permute(0, 2, 3, 1)
+    check(out, ref, name=f"conv split9 {(B, H, W, Cin, Cout)}")
+    assert torch.equal(out, out2)
+    one = ops.conv3x3(x, w, bias, act=act, tile=3)
+    assert ((out.float() - one.float()).norm() / one.float().norm()).item() <= 3e-3
+    with pytest.raises(Exception):
+        ops.conv3x3(x, w, bias, act=act, residual=out, tile=64 + base)      # no residual epilogue in the split form

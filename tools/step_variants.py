@@ -2,6 +2,9 @@
   file    kernels picked by the shipped tune file (supir_amd/tune_gfx950.json)
   retune  autotune state cleared and re-timed on this box
   gnv1    GroupNorm apply kernel v1 (LDS table) instead of v2 (SUPIR_GN_APPLY=v1)
+  nomlp   (upper bound, wrong results) the adapters' mlp_shared convolutions (Cc -> 128, small-N implicit GEMMs on the side stream) skipped:
+          what making them free would be worth
+  noside  (upper bound, wrong results) all adapter control sides skipped (cached outputs of an earlier call)
 Each variant re-captures its graph and is timed twice, interleaved.  Usage: python tools/step_variants.py [variant ...]"""
 import json
 import os
@@ -26,9 +29,38 @@ file_tune, file_choice = dict(ops._TUNE), dict(ops._CHOICE)
 retuned = None
 
 
+from supir_amd.modules import supir_v0 as _S  # noqa: E402
+_orig_sft_side, _orig_xattn_side = _S.ZeroSFT.control_side, _S.ZeroCrossAttn.control_side
+_cache = {}
+
+
+def _sft_side_nomlp(self, c):
+    ch = _S.to_nhwc(c)
+    key = ("actv", id(self))
+    if key not in _cache:
+        m = self.mlp_shared[0]
+        _cache[key] = _S.ops.conv3x3(ch, m.w(), m.b32(), act=1)
+    wgb, bgb = self._w_gamma_beta()
+    return _S.ops.conv3x3(_cache[key], wgb, bgb)
+
+
+def _side_cached(orig):
+    def f(self, c):
+        key = ("side", id(self))
+        if key not in _cache:
+            _cache[key] = orig(self, c)
+        return _cache[key]
+    return f
+
+
 def configure(v):
     global retuned
     os.environ.pop("SUPIR_GN_APPLY", None)
+    _S.ZeroSFT.control_side, _S.ZeroCrossAttn.control_side = _orig_sft_side, _orig_xattn_side
+    if v == "nomlp":
+        _S.ZeroSFT.control_side = _sft_side_nomlp
+    if v == "noside":
+        _S.ZeroSFT.control_side, _S.ZeroCrossAttn.control_side = _side_cached(_orig_sft_side), _side_cached(_orig_xattn_side)
     ops._TUNE.clear()
     ops._CHOICE.clear()
     if v == "retune":
