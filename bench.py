@@ -78,14 +78,23 @@ def kernel_profile(model, latent, device):
             "control": synth_tensor("bench.lq", (B, 4, latent, latent)).to(device)}
     t = torch.full((B,), 500, dtype=torch.int64, device=device)
     model.model.enable_graph(False)
+    import gc
     with torch.no_grad():
         for _ in range(2):
             model.model(x, t, cond, 1.0)
         torch.cuda.synchronize()
-        tr = ops.start_trace(timed=True)
-        model.model(x, t, cond, 1.0)
-        torch.cuda.synchronize()
-        tr = ops.finish_timing(ops.stop_trace())
+        # the event pair of a launch also spans whatever the HOST does between recording the first event and issuing the kernel: a
+        # generation-2 garbage collection there (tens of ms on a process holding the full model) once showed up as a 54 ms "launch"
+        # of one GEMM (profiles/r03/bench_gc_pause_in_kernel_profile.json) -- collect now, keep the collector off while timing
+        gc.collect()
+        gc.disable()
+        try:
+            tr = ops.start_trace(timed=True)
+            model.model(x, t, cond, 1.0)
+            torch.cuda.synchronize()
+            tr = ops.finish_timing(ops.stop_trace())
+        finally:
+            gc.enable()
     agg, by_shape = collections.OrderedDict(), collections.OrderedDict()
     for r in tr:
         k = r["kernel"]
@@ -246,10 +255,16 @@ def vae_colorfix_profile(model, P, device):
         run()
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) * 1e3
-        ops.start_trace(timed=True)
-        run()
-        torch.cuda.synchronize()
-        tr = ops.finish_timing(ops.stop_trace())
+        import gc
+        gc.collect()
+        gc.disable()
+        try:
+            ops.start_trace(timed=True)
+            run()
+            torch.cuda.synchronize()
+            tr = ops.finish_timing(ops.stop_trace())
+        finally:
+            gc.enable()
     agg = collections.OrderedDict()
     for r in tr:
         k = r["kernel"]
