@@ -7,12 +7,14 @@ reference does (supir_amd/modules/conditioner.py: both towers on the HIP kernels
 does: synthetic conditioning, no tokeniser vocabulary files in this image), or a `conditioner` object with the reference's
 `get_unconditional_conditioning(batch, batch_uc)` method can be attached.
 """
+import contextlib
 import copy
 import random
 
 import torch
 import torch.nn as nn
 
+from .. import weights as Wt
 from ..modules.vae import DiagonalGaussianDistribution
 from ..plugin import get_obj_from_str, instantiate_from_config
 
@@ -57,26 +59,50 @@ class SUPIRModel(nn.Module):
         self.ae_dtype = _DT[ae_dtype]
         self.model.dtype = _DT[diffusion_dtype]
         self.p_p, self.n_p = p_p, n_p
+        self._ae_dtype_noted = None
 
     # ------------------------------------------------------------------ first stage
+    @contextlib.contextmanager
+    def _ae_scope(self):
+        """The reference runs the three VAE entry points under `torch.autocast("cuda", dtype=self.ae_dtype)` (SUPIR_model.py:41-69;
+        `model.ae_dtype = ...` is part of test.py's attribute protocol, test.py:67).  Here `ae_dtype` selects the element type of
+        the VAE kernels for the call: torch.bfloat16 (test.py's default) -> bf16, the reference's own arithmetic for that request.
+        torch.float32 (`--ae_dtype fp32`) is computed by the reference in TRUE fp32 (autocast disables itself for float32); this
+        path has no fp32 kernels and serves it in bf16 -- said once per request with a RuntimeWarning, a RuntimeError under
+        SUPIR_STRICT_DTYPE=1.  torch.float16 is refused like the reference's constructor refuses it (SUPIR_model.py:23-24)."""
+        dt = self.ae_dtype
+        if dt == torch.float16:
+            raise RuntimeError("fp16 cause NaN in AE")
+        if dt != torch.bfloat16 and self._ae_dtype_noted != dt:
+            self._ae_dtype_noted = dt
+            Wt.note_downgrade("SUPIRModel.ae_dtype", f"{dt} (test.py --ae_dtype fp32)", "torch.bfloat16",
+                              "the reference computes this request in true fp32 (torch.autocast disables itself for float32, "
+                              "SUPIR/models/SUPIR_model.py:41-69); this path has bf16 VAE kernels only (decoder rel-L2 vs fp32 "
+                              "~1e-2 at 512 px).", stacklevel=5)
+        with Wt.compute_dtype(torch.bfloat16):
+            yield
+
     @torch.no_grad()
     def encode_first_stage(self, x, noise=None):
         fs = self.first_stage_model
-        post = DiagonalGaussianDistribution(fs.quant_conv(fs.encoder(x)))
-        return self.scale_factor * post.sample(noise)
+        with self._ae_scope():
+            post = DiagonalGaussianDistribution(fs.quant_conv(fs.encoder(x)))
+            return self.scale_factor * post.sample(noise)
 
     @torch.no_grad()
     def encode_first_stage_with_denoise(self, x, use_sample=True, is_stage1=False, noise=None):
         fs = self.first_stage_model
-        h = fs.denoise_encoder_s1(x) if is_stage1 else fs.denoise_encoder(x)
-        post = DiagonalGaussianDistribution(fs.quant_conv(h))
-        z = post.sample(noise) if use_sample else post.mode()
-        return self.scale_factor * z
+        with self._ae_scope():
+            h = fs.denoise_encoder_s1(x) if is_stage1 else fs.denoise_encoder(x)
+            post = DiagonalGaussianDistribution(fs.quant_conv(h))
+            z = post.sample(noise) if use_sample else post.mode()
+            return self.scale_factor * z
 
     @torch.no_grad()
     def decode_first_stage(self, z):
         fs = self.first_stage_model
-        return fs.decoder(fs.post_quant_conv(z, in_scale=1.0 / self.scale_factor)).float()
+        with self._ae_scope():
+            return fs.decoder(fs.post_quant_conv(z, in_scale=1.0 / self.scale_factor)).float()
 
     @torch.no_grad()
     def batchify_denoise(self, x, is_stage1=False):

@@ -100,6 +100,10 @@ class DiscreteDenoiserWithControl(nn.Module):
         (denoiser.py:49-73, denoiser_scaling.py:16-22).  None when the configuration is not the one SUPIR ships."""
         if not (isinstance(self.scaling, EpsScaling) and self.quantize_c_noise):
             return None
+        if self.sigmas.dtype != torch.float32:
+            # `model.half()` (test.py --loading_half_params) halves this buffer as it does the reference's: __call__ then does its
+            # scalar arithmetic in fp16 like the reference; the fp32 host mirror would not reproduce that -> generic path
+            return None
         key = (self.sigmas.data_ptr(), self.sigmas._version, self.sigmas.device)   # `denoiser.sigmas` is a checkpoint key
         cached = self.__dict__.get("_host_table")
         if cached is None or cached[0] != key:

@@ -1,12 +1,18 @@
 """ControlWrapper (sgm/modules/diffusionmodules/wrappers.py:68-102): control_model -> diffusion_model -> fp32.
 
 `dtype` follows the attribute protocol (`model.model.dtype = ...`, test.py:67-68) and selects the element type the kernels run in
-(`effective_dtype`): torch.bfloat16 / torch.float32 -> bf16 MFMA operands with fp32 accumulation (libsupir_hip.so; the reference
-itself autocasts fp32 requests); torch.float16 (the reference's default `diff_dtype`, options/SUPIR_v0.yaml:5, test.py:68) -> the
-fp16 build of the same kernels (libsupir_hip_f16.so: fp16 MFMA operands and activations, fp32 accumulation and epilogues), i.e.
-the reference's own precision for BASELINE config 5.  FP16_NATIVE = False (env SUPIR_FP16_NATIVE=0) restores the earlier
-behaviour for fp16 requests: served by bf16, never silently -- the first call emits a RuntimeWarning saying that fp16 (10 mantissa
-bits) is computed in bf16 (7 bits, wider exponent), and SUPIR_STRICT_DTYPE=1 turns that into an error.
+(`effective_dtype`):
+  * torch.bfloat16 -> bf16 MFMA operands, fp32 accumulation and epilogues (libsupir_hip.so): the reference's own arithmetic for
+    that request (`torch.autocast("cuda", dtype=torch.bfloat16)`, wrappers.py:87);
+  * torch.float16 (the reference's default `diff_dtype`, options/SUPIR_v0.yaml:5, test.py:68) -> the fp16 build of the same kernels
+    (libsupir_hip_f16.so: fp16 MFMA operands and activations, fp32 accumulation and epilogues), again the reference's own precision.
+    FP16_NATIVE = False (env SUPIR_FP16_NATIVE=0) serves fp16 requests by bf16 instead -- never silently (RuntimeWarning on the
+    first call; SUPIR_STRICT_DTYPE=1 turns it into an error);
+  * torch.float32 (`test.py --diff_dtype fp32`; also the constructor default) -> served in **bf16**, which is NARROWER than what the
+    reference computes for that request: `torch.autocast("cuda", dtype=torch.float32)` disables itself ("In CUDA autocast, but the
+    target dtype is not supported. Disabling autocast.") and the reference's networks then run in plain fp32.  There are no fp32
+    kernels on this path (bf16 / fp16 MFMA only), so the first call says so with a RuntimeWarning and SUPIR_STRICT_DTYPE=1 makes
+    it a RuntimeError: a caller that needs true fp32 network arithmetic must use the reference's modules.
 
 Optional hipGraph replay: one CFG-doubled step is ~1700 kernel launches issued from Python; `enable_graph()` captures
 them once per (shape, control_scale) and replays the graph on later steps (inputs copied into static buffers).
@@ -65,7 +71,7 @@ class ControlWrapper(nn.Module):
         self.prefetch_kind = "inline"
         self._side = None
         self._warm = False
-        self._dtype_noted = False
+        self._dtype_noted = None   # the dtype request _note_dtype last reported on
         self._last_cdt = None
 
     @property
@@ -204,18 +210,19 @@ class ControlWrapper(nn.Module):
         return out
 
     def _note_dtype(self):
-        if self._dtype_noted:
+        """Once per requested dtype: say when the kernels compute narrower than the request (module docstring)."""
+        if self._dtype_noted == self.dtype:
             return
-        self._dtype_noted = True
+        self._dtype_noted = self.dtype
         if self.dtype == torch.float16 and not FP16_NATIVE:
-            import warnings
-            msg = ("ControlWrapper.dtype is torch.float16 (the reference's default diff_dtype), but SUPIR_FP16_NATIVE=0 serves it in "
-                   "bfloat16 MFMA with fp32 accumulation: 7 mantissa bits instead of fp16's 10 (per-call rel-L2 vs fp32 ~7e-3 "
-                   "instead of ~1e-3).  Set model.model.dtype = torch.bfloat16 (test.py --diff_dtype bf16) to acknowledge, "
-                   "SUPIR_FP16_NATIVE=1 to run the fp16 build of the kernels, or SUPIR_STRICT_DTYPE=1 to make this an error.")
-            if os.environ.get("SUPIR_STRICT_DTYPE") == "1":
-                raise RuntimeError(msg)
-            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+            Wt.note_downgrade("ControlWrapper.dtype", "torch.float16 (the reference's default diff_dtype)", "torch.bfloat16",
+                              "SUPIR_FP16_NATIVE=0 keeps fp16 requests off the fp16 build of the kernels; bf16 has 7 mantissa bits "
+                              "instead of fp16's 10 (per-call rel-L2 vs fp32 ~7e-3 instead of ~1e-3).", stacklevel=4)
+        elif self.dtype not in (torch.float16, torch.bfloat16):
+            Wt.note_downgrade("ControlWrapper.dtype", f"{self.dtype} (test.py --diff_dtype fp32)", "torch.bfloat16",
+                              "the reference computes this request in true fp32 (torch.autocast disables itself for float32, "
+                              "sgm/modules/diffusionmodules/wrappers.py:87); this path has bf16 / fp16 kernels only "
+                              "(per-call rel-L2 vs fp32 ~7e-3).", stacklevel=4)
 
     def forward(self, x, t, c, control_scale=1, **kwargs):
         self._note_dtype()

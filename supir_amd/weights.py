@@ -26,8 +26,23 @@ def cdt():
 
 
 def as_compute_dtype(dtype):
-    """Map a requested module dtype to the kernel element type: fp16 stays fp16, everything else (bf16, fp32) is served by bf16."""
+    """Map a requested module dtype to the kernel element type: fp16 stays fp16, everything else (bf16, fp32) is served by bf16.
+    An fp32 request is a DOWNGRADE (the reference computes such a request in fp32, see note_downgrade): callers that own a
+    request say so through note_downgrade before opening the scope."""
     return torch.float16 if dtype == torch.float16 else BF16
+
+
+def note_downgrade(what, requested, served, why, stacklevel=3):
+    """The caller asked for `requested` arithmetic and gets `served` (fewer mantissa bits): never silently.  A RuntimeWarning,
+    or -- with SUPIR_STRICT_DTYPE=1 in the environment -- a RuntimeError, so that a pipeline that needs the reference's own
+    precision for that request fails instead of drifting."""
+    import os
+    import warnings
+    msg = (f"{what} is {requested} but the MI355X path serves it in {served} MFMA arithmetic with fp32 accumulation: {why}  "
+           f"Set the attribute to {served} to acknowledge, or SUPIR_STRICT_DTYPE=1 to make this an error.")
+    if os.environ.get("SUPIR_STRICT_DTYPE") == "1":
+        raise RuntimeError(msg)
+    warnings.warn(msg, RuntimeWarning, stacklevel=stacklevel)
 
 
 @contextlib.contextmanager

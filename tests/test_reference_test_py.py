@@ -1,0 +1,258 @@
+"""The drop-in contract, end to end: the REFERENCE's `test.py` -- the file itself, run verbatim through `runpy` by
+tools/run_reference_test_py.py -- on this package's classes (VERDICT r03 "missing" 1).
+
+Exercised links (reference lines): the unconditional `llava.llava_agent` import (test.py:5), `CKPT_PTH` (:6), the device gate
+(:10-17), `create_SUPIR_model('options/SUPIR_v0.yaml', SUPIR_sign=...)` with checkpoint loading (:62, SUPIR/util.py:34-47),
+`model.half()` (:63-64), `model.init_tile_vae(...)` (:65-66), `model.ae_dtype = convert_dtype(...)` / `model.model.dtype = ...`
+(:67-68), `model.to(SUPIR_device)` (:69), `PIL2Tensor` -> `batchify_denoise` -> `Tensor2PIL` (:80-87), `captions = ['']` through the
+real `transformers.CLIPTokenizer` (:92-94), `batchify_sample(LQ_img, captions, ...)` with test.py's keyword set (:97-102) and
+`Tensor2PIL(...).save` (:104).
+
+What is configuration, not code, and therefore supplied by the test: the working directory's `options/SUPIR_v0.yaml` (the
+reference's file with transformer depth [1, 1, 2] and one checkpoint path), the "checkpoint" behind that path (synthetic weights,
+served by patching SUPIR.util.load_state_dict -- test infrastructure standing in for a 10 GB file), a byte-level CLIP vocabulary,
+and the pip packages this image lacks (oracle/ref_import.py's inert stubs).
+
+CPU tier: kernels are served by tests/torch_ops.py (bf16 rounding kept) and 'cuda:0' is mapped to the CPU, so what is checked
+here is the FLOW: a PNG is written, and it equals -- byte for byte -- what direct calls of batchify_denoise / batchify_sample on
+the same model give.  The `gpu` variant runs the same thing on the HIP kernels wherever a reference checkout is mounted next to a
+GPU (not on the driver's GPU box: no /root/reference there); tests/test_testpy_flow_gpu.py replays the same call sequence without
+the reference's file so that the GPU tier always covers it."""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_import
+
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason="reference checkout not mounted")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEPTH = [1, 1, 2]
+
+
+# ------------------------------------------------------------------------------------------------ environment pieces
+def write_byte_level_clip_vocab(path):
+    """A CLIP-format BPE vocabulary with no merges (every byte its own token): loads through the real transformers.CLIPTokenizer."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    chars = [chr(c) for c in cs]
+    vocab = {}
+    for u in chars:
+        vocab[u] = len(vocab)
+    for u in chars:
+        vocab[u + "</w>"] = len(vocab)
+    vocab["<|startoftext|>"], vocab["<|endoftext|>"] = 49406, 49407
+    os.makedirs(path, exist_ok=True)
+    json.dump(vocab, open(os.path.join(path, "vocab.json"), "w"))
+    open(os.path.join(path, "merges.txt"), "w").write("#version: 0.2\n")
+    return path
+
+
+def write_workdir(tmp, ckpt_name="synthetic.ckpt"):
+    """options/SUPIR_v0.yaml of the reference, as is, except: reduced transformer depth and ONE checkpoint path."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ref_import.REF_ROOT, "options", "SUPIR_v0.yaml")))
+    cfg["SDXL_CKPT"], cfg["SUPIR_CKPT"], cfg["SUPIR_CKPT_F"], cfg["SUPIR_CKPT_Q"] = ckpt_name, None, None, ckpt_name
+    p = cfg["model"]["params"]
+    p["network_config"]["params"]["transformer_depth"] = list(DEPTH)
+    p["control_stage_config"]["params"]["transformer_depth"] = list(DEPTH)
+    os.makedirs(os.path.join(tmp, "options"), exist_ok=True)
+    yaml.safe_dump(cfg, open(os.path.join(tmp, "options", "SUPIR_v0.yaml"), "w"))
+    return tmp
+
+
+_SD = {}
+
+
+def synthetic_checkpoint():
+    """Reference-keyed state dict with supir_amd.synth weights for every parameter of the depth-[1,1,2] model: UNet / control / VAE
+    keys from the committed manifest of the REAL reference, conditioner keys from this package's (reference-compatible) towers."""
+    if "sd" not in _SD:
+        from supir_amd.modules import conditioner as CD
+        from supir_amd.synth import synth_param
+        man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest_mini.json")))
+        with torch.device("meta"):
+            towers = {"conditioner.embedders.0.": CD.FrozenCLIPEmbedder(layer="hidden", layer_idx=11),
+                      "conditioner.embedders.1.": CD.FrozenOpenCLIPEmbedder2(arch="ViT-bigG-14", layer="penultimate",
+                                                                             always_return_pooled=True, legacy=False)}
+        for pfx, m in towers.items():
+            for k, v in m.state_dict().items():
+                if v.is_floating_point():
+                    man[pfx + k] = list(v.shape)
+        sd = {k: synth_param(k, shape) for k, shape in man.items()}
+        # LayerNorm / embedding tables of the text towers want O(1) / small values, not the conv-style fan-in scaling
+        for k in sd:
+            if k.startswith("conditioner.") and (".ln_" in k or "layer_norm" in k or "ln_final" in k) and k.endswith("weight"):
+                sd[k] = 1.0 + 0.1 * sd[k]
+        _SD["sd"] = sd
+    return _SD["sd"]
+
+
+@contextlib.contextmanager
+def cuda_is_the_cpu():
+    """test.py insists on 'cuda:0' (test.py:10-17,69,81): on a box without a GPU, map every cuda device request to the CPU."""
+    def fix(a):
+        if isinstance(a, str) and a.startswith("cuda"):
+            return "cpu"
+        if isinstance(a, torch.device) and a.type == "cuda":
+            return torch.device("cpu")
+        return a
+
+    t_to, m_to, count = torch.Tensor.to, torch.nn.Module.to, torch.cuda.device_count
+
+    def tensor_to(self, *a, **kw):
+        return t_to(self, *[fix(x) for x in a], **{k: fix(v) for k, v in kw.items()})
+
+    def module_to(self, *a, **kw):
+        return m_to(self, *[fix(x) for x in a], **{k: fix(v) for k, v in kw.items()})
+
+    torch.Tensor.to, torch.nn.Module.to, torch.cuda.device_count = tensor_to, module_to, (lambda: 1)
+    try:
+        yield
+    finally:
+        torch.Tensor.to, torch.nn.Module.to, torch.cuda.device_count = t_to, m_to, count
+
+
+@pytest.fixture(scope="module")
+def launcher():
+    """Import stubs for the pip packages this image lacks, real reference packages (not alias shells) in sys.modules, the
+    synthetic checkpoint behind SUPIR.util.load_state_dict."""
+    ref_import._install_stubs()
+    if ref_import.REF_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REF_ROOT)
+    for name in [n for n in sys.modules if n.split(".")[0] in ("sgm", "SUPIR")]:
+        if getattr(sys.modules[name], "__file__", None) is None:     # alias shells left by an install() without the checkout
+            del sys.modules[name]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import run_reference_test_py as L
+    from supir_amd import plugin
+    plugin.install()
+    with ref_import.quiet():
+        import SUPIR.util as U
+    real = U.load_state_dict
+    U.load_state_dict = lambda path, location="cpu": synthetic_checkpoint() if str(path).startswith("synthetic") else real(path, location)
+    yield L
+    U.load_state_dict = real
+
+
+def _inputs(tmp_path):
+    from PIL import Image
+    img_dir, save_dir = tmp_path / "in", tmp_path / "out"
+    img_dir.mkdir(parents=True)
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 256, size=(12, 10, 3), dtype=np.uint8)          # blocky random picture, 60 x 72 px
+    Image.fromarray(np.kron(base, np.ones((6, 6, 1), dtype=np.uint8))).save(img_dir / "lq.png")
+    return str(img_dir), str(save_dir)
+
+
+def _run_test_py(launcher, tmp_path, extra, backend_fp32=False):
+    from tests import torch_ops
+    img_dir, save_dir = _inputs(tmp_path)
+    work = write_workdir(str(tmp_path / "work"))
+    tok = write_byte_level_clip_vocab(str(tmp_path / "clip_vocab"))
+    args = ["--img_dir", img_dir, "--save_dir", save_dir, "--no_llava", "--min_size", "64", "--edm_steps", "2",
+            "--diff_dtype", "bf16"] + list(extra)
+    out = io.StringIO()
+    old_env = os.environ.pop("SUPIR_CLIP_TOKENIZER", None)
+    try:
+        with torch_ops.installed(fp32=backend_fp32), cuda_is_the_cpu(), contextlib.redirect_stdout(out):
+            g = launcher.run(ref_import.REF_ROOT, args, workdir=work, tokenizer=tok)
+            direct = _direct_calls(g, img_dir)
+    finally:
+        os.environ.pop("SUPIR_CLIP_TOKENIZER", None)
+        if old_env is not None:
+            os.environ["SUPIR_CLIP_TOKENIZER"] = old_env
+    return g, save_dir, direct, out.getvalue()
+
+
+def _direct_calls(g, img_dir):
+    """The same work through direct calls on the model test.py built (its globals come back from runpy): what the PNG must equal."""
+    from PIL import Image
+    from supir_amd.utils.imageio import PIL2Tensor, Tensor2PIL
+    model, a = g["model"], g["args"]
+    img = Image.open(os.path.join(img_dir, "lq.png"))
+    lq, h0, w0 = PIL2Tensor(img, upsacle=a.upscale, min_size=a.min_size)
+    lq = lq.unsqueeze(0)[:, :3]
+    out = model.batchify_sample(lq, [""], num_steps=a.edm_steps, restoration_scale=a.s_stage1, s_churn=a.s_churn, s_noise=a.s_noise,
+                                cfg_scale=a.s_cfg, control_scale=a.s_stage2, seed=a.seed, num_samples=a.num_samples, p_p=a.a_prompt,
+                                n_p=a.n_prompt, color_fix_type=a.color_fix_type, use_linear_CFG=a.linear_CFG,
+                                use_linear_control_scale=a.linear_s_stage2, cfg_scale_start=a.spt_linear_CFG,
+                                control_scale_start=a.spt_linear_s_stage2)
+    return np.asarray(Tensor2PIL(out[0], h0, w0))
+
+
+def _check(g, save_dir, direct):
+    from PIL import Image
+    import supir_amd.models.supir_model as M
+    import supir_amd.modules.wrappers as W
+    model = g["model"]
+    assert type(model) is M.SUPIRModel and type(model.model) is W.ControlWrapper          # test.py built THIS package's classes
+    assert g["captions"] == [""] and g["llava_agent"] is None
+    files = sorted(os.listdir(save_dir))
+    assert files == ["lq_0.png"]
+    png = np.asarray(Image.open(os.path.join(save_dir, files[0])))
+    assert png.shape == (72, 60, 3) and png.dtype == np.uint8                              # back at the input's own size (h0, w0)
+    assert png.std() > 1.0                                                                 # a picture, not a constant
+    assert np.array_equal(png, direct)                                                     # == the direct calls, byte for byte
+    return model
+
+
+def test_reference_test_py_verbatim_default_flags(launcher, tmp_path):
+    g, save_dir, direct, log = _run_test_py(launcher, tmp_path, [])
+    model = _check(g, save_dir, direct)
+    assert model.ae_dtype == torch.bfloat16 and model.model.dtype == torch.bfloat16      # test.py:67-68 arrived
+    # the conditioner ran on real token ids: '' + a_prompt vs n_prompt give different cond / uncond text features
+    assert type(model.conditioner).__name__ == "GeneralConditionerWithControl"
+
+
+def test_reference_test_py_verbatim_tiled_vae(launcher, tmp_path):
+    g, save_dir, direct, _ = _run_test_py(launcher, tmp_path, ["--use_tile_vae", "--encoder_tile_size", "256",
+                                                                 "--decoder_tile_size", "32"])
+    model = _check(g, save_dir, direct)
+    from supir_amd.utils.tilevae import VAEHook
+    fs = model.first_stage_model
+    assert all(isinstance(n.forward, VAEHook) for n in (fs.encoder, fs.denoise_encoder, fs.decoder))   # test.py:65-66 took effect
+
+
+def test_reference_test_py_verbatim_loading_half_params(launcher, tmp_path):
+    """`model.half()` (test.py:63-64; SURVEY q13: fp16 masters under bf16 compute): every floating parameter is fp16 and the
+    derived kernel layouts are rebuilt from them."""
+    g, save_dir, direct, _ = _run_test_py(launcher, tmp_path, ["--loading_half_params"])
+    model = _check(g, save_dir, direct)
+    assert all(p.dtype == torch.float16 for p in model.parameters() if p.is_floating_point())
+
+
+def test_fp32_requests_are_not_served_silently(launcher, tmp_path):
+    """`--diff_dtype fp32 --ae_dtype fp32` (test.py:52-53): the reference computes those in true fp32 (autocast disables itself);
+    this path serves bf16 and must say so -- RuntimeWarning by default, RuntimeError under SUPIR_STRICT_DTYPE=1."""
+    with pytest.warns(RuntimeWarning) as rec:
+        g, save_dir, direct, _ = _run_test_py(launcher, tmp_path, ["--diff_dtype", "fp32", "--ae_dtype", "fp32"])
+    msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]
+    assert any("ControlWrapper.dtype" in m and "torch.float32" in m for m in msgs), msgs
+    assert any("SUPIRModel.ae_dtype" in m and "torch.float32" in m for m in msgs), msgs
+    _check(g, save_dir, direct)
+    # strict mode, on the model test.py built (no second construction): both requests become errors
+    from tests import torch_ops
+    model = g["model"]
+    os.environ["SUPIR_STRICT_DTYPE"] = "1"
+    try:
+        with torch_ops.installed(fp32=False):
+            model._ae_dtype_noted = None
+            with pytest.raises(RuntimeError, match="ae_dtype"):
+                model.batchify_denoise(torch.zeros(1, 3, 64, 64))
+            model.model._dtype_noted = None
+            with pytest.raises(RuntimeError, match="ControlWrapper.dtype"):
+                model.model(torch.zeros(2, 4, 8, 8), torch.zeros(2, dtype=torch.int64), {})
+    finally:
+        del os.environ["SUPIR_STRICT_DTYPE"]

@@ -1,0 +1,122 @@
+"""The call sequence of the reference's test.py (test.py:61-104), replayed on the GPU against this package's classes WITHOUT the
+reference's file (there is no /root/reference on the GPU box; tests/test_reference_test_py.py runs the file itself verbatim wherever
+a checkout is mounted): build the model from a reference-style config with the text conditioner, load a reference-keyed
+checkpoint, `[.half()]`, `[init_tile_vae]`, set `ae_dtype` / `model.dtype` through the attribute protocol, `.to('cuda:0')`,
+PIL image -> `PIL2Tensor` -> `batchify_denoise` -> `Tensor2PIL`, `captions = ['']` -> `batchify_sample(LQ_img, captions, ...)` with
+test.py's keyword set -> `Tensor2PIL(...).save`.  Checks: a PNG of the input's size comes out, the run is reproducible bit for
+bit, fp16 masters (`--loading_half_params`) change the result only at the fp16-rounding level of the weights, the tiled VAE
+variant stays within the tiled-VAE tolerance of the untiled one, and fp32 requests are announced (never served silently)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_reference_test_py import DEPTH, synthetic_checkpoint, write_byte_level_clip_vocab  # noqa: E402
+
+A_PROMPT = ("Cinematic, High Contrast, highly detailed, taken using a Canon EOS R camera, hyper detailed photo - realistic maximum "
+            "detail, 32k, Color Grading, ultra HD, extreme meticulous detailing, skin pore detailing, hyper sharpness, perfect without "
+            "deformations.")
+N_PROMPT = ("painting, oil painting, illustration, drawing, art, sketch, oil painting, cartoon, CG Style, 3D render, unreal engine, "
+            "blurring, dirty, messy, worst quality, low quality, frames, watermark, signature, jpeg artifacts, deformed, lowres, "
+            "over-smooth")
+
+
+def _config():
+    """supir_amd.configs.supir_v0_config + the conditioner block of options/SUPIR_v0.yaml:66-106 (same targets and params)."""
+    from supir_amd.configs import supir_v0_config
+    cfg = supir_v0_config(transformer_depth=DEPTH)
+    E = "sgm.modules.encoders.modules."
+    cfg["params"]["conditioner_config"] = {"target": "sgm.modules.GeneralConditionerWithControl", "params": {"emb_models": [
+        {"is_trainable": False, "input_key": "txt", "target": E + "FrozenCLIPEmbedder", "params": {"layer": "hidden", "layer_idx": 11}},
+        {"is_trainable": False, "input_key": "txt", "target": E + "FrozenOpenCLIPEmbedder2",
+         "params": {"arch": "ViT-bigG-14", "version": "laion2b_s39b_b160k", "freeze": True, "layer": "penultimate",
+                    "always_return_pooled": True, "legacy": False}},
+        {"is_trainable": False, "input_key": "original_size_as_tuple", "target": E + "ConcatTimestepEmbedderND", "params": {"outdim": 256}},
+        {"is_trainable": False, "input_key": "crop_coords_top_left", "target": E + "ConcatTimestepEmbedderND", "params": {"outdim": 256}},
+        {"is_trainable": False, "input_key": "target_size_as_tuple", "target": E + "ConcatTimestepEmbedderND", "params": {"outdim": 256}}]}}
+    cfg["params"]["diffusion_dtype"] = "fp16"       # the YAML's default (options/SUPIR_v0.yaml:5); test.py overrides it below
+    return cfg
+
+
+def _flow(tmp_path, tag, half=False, tile_vae=False, ae_dtype=torch.bfloat16, diff_dtype=torch.bfloat16, steps=4):
+    from PIL import Image
+    from supir_amd.plugin import instantiate_from_config
+    from supir_amd.utils.imageio import PIL2Tensor, Tensor2PIL
+    model = instantiate_from_config(_config()).cpu()                                   # SUPIR/util.py:36
+    res = model.load_state_dict(synthetic_checkpoint(), strict=False)                  # :38-47
+    assert not res.unexpected_keys
+    if half:
+        model = model.half()                                                           # test.py:63-64
+    if tile_vae:
+        model.init_tile_vae(encoder_tile_size=128, decoder_tile_size=16)               # :65-66
+    model.ae_dtype = ae_dtype                                                          # :67
+    model.model.dtype = diff_dtype                                                     # :68
+    model = model.to("cuda:0")                                                         # :69
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 256, size=(12, 10, 3), dtype=np.uint8)
+    lq_pil = Image.fromarray(np.kron(base, np.ones((6, 6, 1), dtype=np.uint8)))        # 60 x 72 px
+    lq, h0, w0 = PIL2Tensor(lq_pil, upsacle=1, min_size=256)                           # :80
+    lq = lq.unsqueeze(0).to("cuda:0")[:, :3]
+    lq512, h1, w1 = PIL2Tensor(lq_pil, upsacle=1, min_size=256, fix_resize=512)        # :84
+    clean = model.batchify_denoise(lq512.unsqueeze(0).to("cuda:0")[:, :3])             # :86
+    clean_pil = Tensor2PIL(clean[0], h1, w1)                                           # :87
+    assert clean_pil.size == (w1, h1)
+    captions = [""]                                                                    # :93
+    samples = model.batchify_sample(lq, captions, num_steps=steps, restoration_scale=-1, s_churn=5, s_noise=1.01, cfg_scale=4.0,
+                                    control_scale=1.0, seed=1234, num_samples=1, p_p=A_PROMPT, n_p=N_PROMPT,
+                                    color_fix_type="Wavelet", use_linear_CFG=True, use_linear_control_scale=False,
+                                    cfg_scale_start=1.0, control_scale_start=0.0)      # :97-102
+    out = tmp_path / f"{tag}_0.png"
+    Tensor2PIL(samples[0], h0, w0).save(out)                                           # :104
+    png = np.asarray(Image.open(out))
+    assert png.shape == (h0, w0, 3) and png.std() > 1.0 and torch.isfinite(samples).all()
+    return model, samples.float().cpu(), png
+
+
+@pytest.fixture(scope="module")
+def tok(tmp_path_factory):
+    old = os.environ.get("SUPIR_CLIP_TOKENIZER")
+    os.environ["SUPIR_CLIP_TOKENIZER"] = write_byte_level_clip_vocab(str(tmp_path_factory.mktemp("clip_vocab")))
+    yield
+    if old is None:
+        del os.environ["SUPIR_CLIP_TOKENIZER"]
+    else:
+        os.environ["SUPIR_CLIP_TOKENIZER"] = old
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+def test_testpy_call_sequence_on_the_gpu(tok, tmp_path):
+    model, base, png = _flow(tmp_path, "base")
+    assert model.model.effective_dtype == torch.bfloat16
+    # cond and uncond text features differ (the prompts went through the tokenizer and both towers)
+    _, again, png2 = _flow(tmp_path, "again")
+    assert torch.equal(base, again) and np.array_equal(png, png2)                      # same seed -> same bits
+    # --loading_half_params: fp16 masters, bf16 kernel copies derived from them
+    mh, half, _ = _flow(tmp_path, "half", half=True)
+    assert all(p.dtype == torch.float16 for p in mh.parameters() if p.is_floating_point())
+    e_half = _rel(half, base)
+    # --use_tile_vae: the 256-px image in 128-px encoder tiles, its 32-latent in 16-latent decoder tiles (pooled GroupNorm statistics)
+    _, tiled, _ = _flow(tmp_path, "tiled", tile_vae=True)
+    e_tiled = _rel(tiled, base)
+    # --diff_dtype fp16 (test.py's default): the fp16 build of the kernels
+    mf, f16, _ = _flow(tmp_path, "fp16", diff_dtype=torch.float16)
+    assert mf.model.effective_dtype == torch.float16
+    e_f16 = _rel(f16, base)
+    print(f"test.py flow: half-params vs fp32 masters {e_half:.3e}; tiled VAE vs untiled {e_tiled:.3e}; fp16 vs bf16 network {e_f16:.3e}")
+    assert e_half <= 5e-2 and e_tiled <= 8e-2 and e_f16 <= 5e-2
+
+
+def test_fp32_requests_warn_or_raise_on_the_gpu(tok, tmp_path, monkeypatch):
+    with pytest.warns(RuntimeWarning) as rec:
+        _flow(tmp_path, "fp32", ae_dtype=torch.float32, diff_dtype=torch.float32, steps=2)
+    msgs = [str(w.message) for w in rec]
+    assert any("ControlWrapper.dtype" in m for m in msgs) and any("SUPIRModel.ae_dtype" in m for m in msgs)
+    monkeypatch.setenv("SUPIR_STRICT_DTYPE", "1")
+    with pytest.raises(RuntimeError, match="ae_dtype"):
+        _flow(tmp_path, "strict", ae_dtype=torch.float32, steps=2)
