@@ -324,10 +324,11 @@ class GeneralConditioner(nn.Module):
         output = {}
         force_zero_embeddings = force_zero_embeddings or []
         for e in self.embedders:
-            if e.ucg_rate > 0.0 or e.legacy_ucg_val is not None:
-                # training-time conditioning dropout (modules.py:217-228): never active on the inference path, where
-                # get_unconditional_conditioning sets every rate to 0 (:177-186); refuse rather than silently ignore
-                raise NotImplementedError("ucg_rate > 0 / legacy_ucg_value are training-time options of the reference")
+            if e.ucg_rate > 0.0:
+                # training-time conditioning dropout (modules.py:217-228; legacy_ucg_value only acts together with ucg_rate > 0,
+                # :121-134): never active on the inference path, where get_unconditional_conditioning sets every rate to 0
+                # (:177-186); a direct forward() with a live rate is refused rather than silently ignored
+                raise NotImplementedError("ucg_rate > 0 is a training-time option of the reference (conditioning dropout)")
             out = e(batch[e.input_key])
             for emb in (out if isinstance(out, (list, tuple)) else [out]):
                 key = self._key_of(e, emb)
@@ -337,8 +338,17 @@ class GeneralConditioner(nn.Module):
         return output
 
     def get_unconditional_conditioning(self, batch_c, batch_uc=None, force_uc_zero_embeddings=None):
-        c = self(batch_c)
-        uc = self(batch_c if batch_uc is None else batch_uc, force_uc_zero_embeddings or [])
+        """modules.py:177-191: every embedder's ucg_rate is zeroed for the two encodes and restored afterwards, so a config that
+        carries training-time rates still serves inference."""
+        rates = [e.ucg_rate for e in self.embedders]
+        for e in self.embedders:
+            e.ucg_rate = 0.0
+        try:
+            c = self(batch_c)
+            uc = self(batch_c if batch_uc is None else batch_uc, force_uc_zero_embeddings or [])
+        finally:
+            for e, r in zip(self.embedders, rates):
+                e.ucg_rate = r
         return c, uc
 
 

@@ -150,6 +150,16 @@ _TUNE_DEFAULT = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tun
 _TUNE_FILE = _os.environ.get("SUPIR_TUNE_FILE", _TUNE_DEFAULT)
 
 
+def _packaged_tune_applies():
+    """The packaged picks were timed on gfx950: on any other device (or an unknown one) every shape is tuned on first sight."""
+    try:
+        if torch.cuda.is_available():
+            return str(getattr(torch.cuda.get_device_properties(0), "gcnArchName", "")).startswith("gfx950")
+    except Exception:
+        return False
+    return True     # no device in this process (CPU tier): nothing is launched, the entries are inert
+
+
 def load_tuning(path):
     """Merge a file written by save_tuning into the autotune state; returns the number of entries read."""
     import json as _json
@@ -161,13 +171,16 @@ def load_tuning(path):
     return len(data.get("tune", [])) + len(data.get("choice", []))
 
 
-if _TUNE_FILE and _TUNE_FILE.lower() != "none" and _os.path.exists(_TUNE_FILE):
+if _TUNE_FILE and _TUNE_FILE.lower() != "none" and _os.path.exists(_TUNE_FILE) and (_TUNE_FILE != _TUNE_DEFAULT or _packaged_tune_applies()):
     load_tuning(_TUNE_FILE)
 
 
 def save_tuning(path=None):
+    """Write the autotune state to `path`, or -- with no argument -- to the file SUPIR_TUNE_FILE names EXPLICITLY.  Never to the
+    packaged supir_amd/tune_gfx950.json by default: a tool run must not rewrite the product's picks behind the user's back
+    (tools/make_tune.py passes that path on purpose)."""
     import json as _json
-    path = path or _TUNE_FILE
+    path = path or _os.environ.get("SUPIR_TUNE_FILE")
     if path and path.lower() != "none":
         data = {"tune": sorted(([list(k), v] for k, v in _TUNE.items()), key=repr),
                 "choice": sorted(([list(k), v] for k, v in _CHOICE.items()), key=repr)}
@@ -433,11 +446,11 @@ def _group_call(a, b, tile, oa=None, ob=None, prefetch=(None, None)):
     if a.kind in ("gemm", "conv", "qkv"):
         return _gemm_group_call(a, b, tile, oa, ob, prefetch)
     if a.kind == "attn":
-        (B, H, Tq, scale), pa = a.make()
-        _, pb = b.make()
+        (B, H, Tq, scale), pa = a.make(oa)
+        _, pb = b.make(ob)
         return a.lib.supir_flash_attn_d64_grouped((_lib.AttnProblem * 2)(pa, pb), 2, B, H, Tq, scale, _stream())
-    (B, HW, C, eps, act), pa = a.make()
-    _, pb = b.make()
+    (B, HW, C, eps, act), pa = a.make(oa)
+    _, pb = b.make(ob)
     return a.lib.supir_groupnorm_grouped((_lib.GnProblem * 2)(pa, pb), 2, B, HW, C, eps, act, _stream())
 
 
@@ -454,6 +467,17 @@ def _pair_autotune(a, b, pkey, side):
     oa = _scratch_like(a.out) if a.inplace else None
     ob = _scratch_like(b.out) if b.inplace else None
     main = torch.cuda.current_stream()
+    # recorded launches skipped their single-launch tuning (_autotune returns -1 while recording): tune them here, where the
+    # operands are live, so that the "two singles" option is not timed on heuristic tiles against tuned grouped ones
+    for L, o in ((a, oa), (b, ob)):
+        if L.kind in ("gemm", "conv") and L.single_tile == -1 and L.cands and L.tkey is not None:
+            st = _TUNE.get(L.tkey)
+            if st is None:
+                times = _time_options(L.cands, lambda t, L=L, o=o: L.call(t, o))
+                st = min(times)[1] if times else -1
+                _TUNE[L.tkey] = st
+            if st in L.cands:
+                L.single_tile = st
 
     def run(t):
         if t == -2:
@@ -514,6 +538,12 @@ def _run_pair(a, b, tile):
     pfs = _pf_group([a.w, b.w]) if gemm_like else (None, None)
     ev = _ev()
     rc = _group_call(a, b, tile, prefetch=pfs)
+    if rc in (-1, -2):
+        # SUPIR_ERR_ARG / SUPIR_ERR_SHAPE: the C side refuses a pairing the Python key could not tell apart (a cached winner for a
+        # key that under-describes the problems): nothing was launched -- run the two problems one by one
+        _run_single(a)
+        _run_single(b)
+        return
     _lib.check(rc, {"attn": "supir_flash_attn_d64_grouped", "gn": "supir_groupnorm_grouped"}.get(a.kind, "supir_gemm_grouped"), a.lib)
     if a.trace is not None:
         k, fl, by, kw = a.trace
@@ -1035,17 +1065,18 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     ldo = out.stride(-2)
 
     def launch(t, outp=None):
+        o = out if outp is None else outp
         if causal:
-            return lib.supir_flash_attn_d64_ex(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
+            return lib.supir_flash_attn_d64_ex(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
                                                ldo, 0.125, 1, _stream())
-        return lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
+        return lib.supir_flash_attn_d64(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, Tq, Tk, ldq, ldk, ldvt,
                                         ldo, 0.125, _stream())
 
-    def make():
-        return (B, H, Tq, 0.125), _lib.AttnProblem(Q=q.data_ptr(), K=k.data_ptr(), Vt=vt.data_ptr(), O=out.data_ptr(), Tk=Tk, ldq=ldq,
+    def make(outp=None):
+        return (B, H, Tq, 0.125), _lib.AttnProblem(Q=q.data_ptr(), K=k.data_ptr(), Vt=vt.data_ptr(), O=(out if outp is None else outp).data_ptr(), Tk=Tk, ldq=ldq,
                                                    ldk=ldk, ldvt=ldvt, ldo=ldo, flags=1 if causal else 0)
 
-    _issue(_Launch("attn", lib, "supir_flash_attn_d64", launch, key=("attn", B, H, Tq) + _k(DT), make=make,
+    _issue(_Launch("attn", lib, "supir_flash_attn_d64", launch, key=("attn", B, H, Tq) + _k(DT), make=make, out=out,
                    trace=("attn", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * H * 64 * (2 * Tq + 2 * Tk), dict(B=B, H=H, Tq=Tq, Tk=Tk)),
                    keep=(q, k, vt, out)))
     return out
@@ -1162,27 +1193,33 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
                                  else _gn_workspace(B, x.device))
 
     def launch(t, outp=None):
+        o = out if outp is None else outp
         if use_parts:
             return lib.supir_groupnorm_nhwc_parts(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
                                                   beta.data_ptr(), eps, act, _p(mod_g), _p(mod_b), ldm, control_scale,
-                                                  out.data_ptr(), ldo, part.buf.data_ptr(), part.nchunk,
+                                                  o.data_ptr(), ldo, part.buf.data_ptr(), part.nchunk,
                                                   0 if part2 is None else part2.buf.data_ptr(), 0 if part2 is None else part2.nchunk,
                                                   _stream())
         return lib.supir_groupnorm_nhwc(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(),
                                         beta.data_ptr(), eps, act, _p(mod_g), _p(mod_b), ldm, control_scale,
-                                        out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _p(given), _stream())
+                                        o.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _p(given), _stream())
 
-    def make():
+    def make(outp=None):
         pr = _lib.GnProblem(x1=x.data_ptr(), x2=_p(x2), x1raw=_p(x1raw), x2raw=_p(x2raw), gamma=gamma.data_ptr(), beta=beta.data_ptr(),
-                            mod_g=_p(mod_g), mod_b=_p(mod_b), out=out.data_ptr(), part1=part.buf.data_ptr() if use_parts else None,
+                            mod_g=_p(mod_g), mod_b=_p(mod_b), out=(out if outp is None else outp).data_ptr(),
+                            part1=part.buf.data_ptr() if use_parts else None,
                             part2=part2.buf.data_ptr() if (use_parts and part2 is not None) else None, workspace=_p(ws), C1=C1, ld1=ld1,
                             ld2=ld2, ldm=ldm, ldo=ldo, nchunk1=part.nchunk if use_parts else 0,
                             nchunk2=part2.nchunk if (use_parts and part2 is not None) else 0, control_scale=control_scale)
         return (B, HW, C, eps, act), pr
 
     n = B * HW * C
+    # in place (ResBlock: the second norm overwrites conv1's output): a candidate timed by the pair autotune must not be applied to
+    # its own input over and over -- `inplace` sends its timing launches to a scratch output (make / launch take the override)
+    inplace = any(t is not None and t.data_ptr() == out.data_ptr() for t in (x, x2, x1raw, x2raw))
     _issue(_Launch("gn" if given is None else None, lib, "supir_groupnorm_nhwc_parts" if use_parts else "supir_groupnorm_nhwc", launch,
-                   key=("gn", B, HW, C, eps, act, use_parts) + _k(DT), make=make,
+                   key=("gn", B, HW, C, eps, act, use_parts, x2 is not None, mod_g is not None, x1raw is not None or x2raw is not None)
+                   + _k(DT), make=make, out=out, inplace=inplace,
                    trace=("groupnorm", 0, 2.0 * n * (2 + (2 if mod_g is not None else 0)), dict(B=B, HW=HW, C=C, parts=use_parts)),
                    keep=(x, x2, x1raw, x2raw, gamma, beta, mod_g, mod_b, out, ws, given, part, part2)))
     return out

@@ -185,6 +185,17 @@ def test_conditioner_routing_concat_and_control_passthrough():
     c, uc = cond.get_unconditional_conditioning(batch, dict(batch, txt=["", ""]), force_uc_zero_embeddings=["txt"])
     assert c["crossattn"].abs().sum() > 0 and uc["crossattn"].abs().sum() == 0 and uc["vector"][:, :7].abs().sum() == 0
     assert uc["vector"][:, 7:].abs().sum() > 0
+    # a config carrying training-time rates still serves inference: get_unconditional_conditioning zeroes the rates for its two
+    # encodes and restores them (modules.py:177-191); legacy_ucg_value alone (rate 0) is a no-op; a direct forward with a live rate
+    # is refused (conditioning dropout is not on this path)
+    cfgs[0] = dict(cfgs[0], ucg_rate=0.2, legacy_ucg_value="")
+    cfgs[1] = dict(cfgs[1], legacy_ucg_value="")
+    cond2 = C.GeneralConditionerWithControl(cfgs)
+    c2, uc2 = cond2.get_unconditional_conditioning(batch, dict(batch, txt=["", ""]), force_uc_zero_embeddings=["txt"])
+    assert torch.equal(c2["crossattn"], c["crossattn"]) and torch.equal(uc2["vector"], uc["vector"])
+    assert [e.ucg_rate for e in cond2.embedders] == [0.2, 0.0, 0.0]
+    with pytest.raises(NotImplementedError):
+        cond2(batch)
 
 
 def _fill(module, prefix, dev):

@@ -601,3 +601,22 @@ def test_tiled_vae_host_logic_vs_oracle_with_torch_backend():
     assert enc.shape == ref_enc.shape and dec.shape == ref_dec.shape == (2, 3, 320, 256)
     assert rel_l2(enc, ref_enc) <= 2e-5 and rel_l2(dec, ref_dec) <= 2e-5
     assert assign_tiles(7, 1, 3) == [1, 4] and assign_tiles(2, 0, 1) == [0, 1]
+
+
+def test_save_tuning_never_defaults_to_the_packaged_file(tmp_path, monkeypatch):
+    """`ops.save_tuning()` with no argument wrote the shipped supir_amd/tune_gfx950.json.  Now it writes only where it is
+    told to (an explicit path, or the file SUPIR_TUNE_FILE names)."""
+    import os
+    from supir_amd import ops
+    monkeypatch.delenv("SUPIR_TUNE_FILE", raising=False)
+    st = os.stat(ops._TUNE_DEFAULT)
+    ops.save_tuning()
+    st2 = os.stat(ops._TUNE_DEFAULT)
+    assert (st.st_mtime_ns, st.st_size) == (st2.st_mtime_ns, st2.st_size)
+    out = tmp_path / "picks.json"
+    ops.save_tuning(str(out))
+    assert out.exists() and ops.load_tuning(str(out)) >= 0
+    env = tmp_path / "env.json"
+    monkeypatch.setenv("SUPIR_TUNE_FILE", str(env))
+    ops.save_tuning()
+    assert env.exists()
