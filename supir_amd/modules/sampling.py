@@ -378,11 +378,13 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
                                            {k: v for k, v in uc.items() if k != "control"})
             static.append(cat)
         import torch.distributed as dist
+        from ..parallel import collectives_active
         world, rank = 1, 0
-        if self.tile_parallel and dist.is_available() and dist.is_initialized():
+        shared = self.tile_parallel and collectives_active(self.process_group)   # > 1 rank (or a forced 1-rank group: RCCL test)
+        if shared:
             world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
         kb = 1 if use_local_prompt else self.tile_batch
-        if world > 1:
+        if shared:
             src = dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0
             x = x.contiguous()
             dist.broadcast(x, src=src, group=self.process_group)
@@ -394,7 +396,7 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
             x_next = torch.zeros_like(x)
             count = torch.zeros_like(x)
             eps_noise = torch.randn_like(x)
-            if world > 1:
+            if shared:
                 dist.broadcast(eps_noise, src=src, group=self.process_group)
             for gi, j0 in enumerate(range(0, len(tiles), kb)):
                 if world > 1 and gi % world != rank:
@@ -431,7 +433,7 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
                 for (hi, he, wi, we), _xt in zip(grp, outs):
                     x_next[:, :, hi:he, wi:we] += _xt * tile_weights
                     count[:, :, hi:he, wi:we] += tile_weights
-            if world > 1:
+            if shared:
                 dist.all_reduce(x_next, op=dist.ReduceOp.SUM, group=self.process_group)
                 count = count_all
             x_next /= count

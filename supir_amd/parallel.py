@@ -3,8 +3,22 @@ sample (the path shards at image granularity; the reference has 
 
 backend "nccl" is RCCL on ROCm (xGMI inside a node); the same code runs over gloo on CPU for the tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# A 1-rank group has nothing to exchange, so every helper below returns early for it.  FORCE_COLLECTIVES (env
+# SUPIR_FORCE_COLLECTIVES=1) runs the collectives anyway: on a single-GPU box this is the only way to execute the RCCL code path
+# (bucketed broadcasts, all-reduces on device tensors, graph capture next to a live process group) -- tests/test_rccl_single_rank_gpu.py.
+FORCE_COLLECTIVES = os.environ.get("SUPIR_FORCE_COLLECTIVES", "0") == "1"
+
+
+def collectives_active(group=None):
+    """True when torch.distributed is initialised and the group has more than one rank (or FORCE_COLLECTIVES is set)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
 def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), payload_dtype=None, round_min_elems=1 << 16):
@@ -20,7 +34,7 @@ def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), pay
     `src` rounds its own copies too, so all ranks hold IDENTICAL masters -- but layouts DERIVED from them in fp32 (LayerNorm-folded
     W' = gamma (.) W, its column sums) then start from bf16-rounded W and differ from a single-GPU run at the bf16 noise floor,
     and an fp16 compute scope loses the three mantissa bits it would have kept.  Not used by bench.py."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return 0
     tensors = [t for k, t in module.state_dict().items() if t.is_floating_point() and not any(k.endswith(s) for s in skip)]
     groups = {}
@@ -60,7 +74,7 @@ def shard_items(n_items, rank=None, world=None):
 
 
 def max_over_ranks(seconds, device="cpu"):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -69,7 +83,7 @@ def max_over_ranks(seconds, device="cpu"):
 
 def gather_images(local, n_items, device="cpu"):
     """Optional result gather: {index: [3,H,W] tensor} from every rank -> list on rank 0 (12 MB per 1024^2 image)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return [local[i] for i in range(n_items)]
     objs = [None] * dist.get_world_size()
     dist.all_gather_object(objs, {k: v.cpu() for k, v in local.items()})
@@ -86,7 +100,7 @@ def sync_autotune(src=0, group=None):
     (and the tiles of a tile-parallel sample) are bit-identical given identical inputs.  Call it after a warm-up pass has tuned
     the shapes in use and BEFORE graphs are captured for the timed / production calls (a changed pick invalidates captured
     graphs: re-run ControlWrapper.enable_graph).  Returns the number of entries that changed on this rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_active(group):
         return 0
     from . import ops
     payload = [None]

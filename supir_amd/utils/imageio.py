@@ -148,7 +148,7 @@ def PIL2Tensor(img, upsacle=1, min_size=1024, fix_resize=None, device="cuda"):
         # two conversions are 8-bit per-pixel arithmetic: the premultiply is Pillow's own convert() on the decoded image, the
         # un-premultiply (Convert.c rgba2rgbA: CLIP8(255 * c / alpha), pass-through for alpha 0 / 255) is integer torch ops.
         pre = np.asarray(img.convert("RGBa" if img.mode == "RGBA" else "La"))
-        _, u8 = resize_bicubic_u8(torch.from_numpy(np.ascontiguousarray(pre)).to(device), w, h, want_u8=True)
+        _, u8 = resize_bicubic_u8(torch.from_numpy(np.array(pre)).to(device), w, h, want_u8=True)
         u8 = unpremultiply_u8(u8)
         return _lut(u8.device)[u8.long()].permute(2, 0, 1).contiguous(), h0, w0
     if img.mode not in ("L", "RGB"):
@@ -157,7 +157,7 @@ def PIL2Tensor(img, upsacle=1, min_size=1024, fix_resize=None, device="cuda"):
     arr = np.asarray(img)
     if arr.ndim == 2:
         arr = arr[:, :, None]
-    x = resize_bicubic_u8(torch.from_numpy(np.ascontiguousarray(arr)).to(device), w, h)
+    x = resize_bicubic_u8(torch.from_numpy(np.array(arr)).to(device), w, h)   # np.array: a writable copy (PIL hands out read-only views)
     return x, h0, w0
 
 

@@ -179,7 +179,8 @@ class VAEHook:
         if not self.tile_parallel:
             return 0, 1, None
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.process_group) == 1:
+        from ..parallel import collectives_active
+        if not collectives_active(self.process_group):
             return 0, 1, None
         return dist.get_rank(self.process_group), dist.get_world_size(self.process_group), (self.process_group or dist.group.WORLD)
 
