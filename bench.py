@@ -143,8 +143,35 @@ def _pick_threads(sample, cands=(16, 32, 64, 128)):
     return best[1], best[0], scan
 
 
+def _reference_network(sd):
+    """(callable, description) running ONE network call through the REFERENCE's own modules (ControlWrapper(LightGLVUNet) +
+    GLVControl, fp32, imported from the checkout by oracle/ref_import.py) with the weights of `sd`, or None when no checkout is
+    mounted (the GPU box: /root/reference does not exist there) or its construction fails.  Construction allocates a second fp32
+    copy of the 3.9 G network parameters (15.5 GB of host RAM, ~2 minutes)."""
+    try:
+        from oracle import ref_import as R
+        if not R.available():
+            return None
+        ns = R.load_reference()
+        net, ctl, _ = R.unet_params()
+        with R.quiet():
+            unet = ns.LightGLVUNet(**net).eval()
+            ctrl = ns.GLVControl(**ctl).eval()
+        unet.load_state_dict({k[len("model.diffusion_model."):]: v for k, v in sd.items() if k.startswith("model.diffusion_model.")})
+        ctrl.load_state_dict({k[len("model.control_model."):]: v for k, v in sd.items() if k.startswith("model.control_model.")})
+        wrap = ns.ControlWrapper(unet, dtype=torch.float32)
+        wrap.load_control_model(ctrl)
+        return wrap
+    except Exception as e:   # the baseline leg must never take the bench line down: fall back to the port
+        log(f"[cpu_baseline] reference modules unavailable ({e!r}); timing the port")
+        return None
+
+
 def cpu_baseline(model, device, budget_s=60.0):
-    """The oracle (fp32 PyTorch restatement of the reference path: kind 'port') timed on the host cores of this box.
+    """The CPU path timed on the host cores of this box.  kind "reference": the reference's own modules (when a checkout is mounted:
+    the build container); kind "port": the oracle (fp32 PyTorch restatement of the reference path) -- always the case on the GPU
+    box, where /root/reference does not exist.  profiles/r04/cpu_baseline_oracle_vs_reference_same_box.json holds both timed on one
+    box on the same call (oracle/ref_vs_port_timing.py): the port is a faithful proxy.
     Sample, bounded: first ONE CFG-doubled UNet+control call at 256x256 (1.28 TFLOP, a few seconds) to get the host's rate; if
     the projection fits the budget, BASELINE config 1 END TO END (512x512, 2 EDM steps, VAE encode / decode x2 each, colour fix:
     oracle.batchify_sample, 16.8 TFLOP) -- SURVEY.md 8(d).  `value` = 1024^2 50-step images/s extrapolated by algorithmic FLOPs
@@ -163,15 +190,23 @@ def cpu_baseline(model, device, budget_s=60.0):
         model.model(x.to(device), t.to(device), {k: v.to(device) for k, v in cond.items()}, 1.0)
         tflop_a = sum(r["flops"] for r in ops.stop_trace()) / 1e12
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if v.is_floating_point()}
+    ref = _reference_network(sd) if os.environ.get("SUPIR_CPU_BASELINE_KIND", "auto") != "port" else None
+    kind = "reference" if ref is not None else "port"
+
+    def network(xx, tt, cc):
+        """one CFG-doubled UNet + control call on the host cores, through the reference's modules or the port"""
+        if ref is not None:
+            return ref(xx, tt, dict(cc), 1.0)
+        return O.control_wrapper(sd, xx, tt, cc, 1.0)
 
     def sample():
         with torch.no_grad():
-            O.control_wrapper(sd, x, t, cond, 1.0)
+            network(x, t, cond)
 
     threads, dt_a, scan = _pick_threads(sample)
     rate = tflop_a / dt_a
     cfg1_tflop = 2 * UNET_STEP_TFLOP[64] + 2 * 1.117 + 2 * 2.515     # BASELINE.md section 2: 512^2 step, VAE enc / dec at 512^2
-    res = {"unit": "images/s", "cores": threads, "kind": "port", "host_threads_available": os.cpu_count(),
+    res = {"unit": "images/s", "cores": threads, "kind": kind, "host_threads_available": os.cpu_count(),
            "thread_scan_seconds_per_256px_call": scan,
            "sample_network_call_256px": {"tflop": round(tflop_a, 3), "seconds": round(dt_a, 2), "tflops": round(rate, 3)}}
     # the metric's own unit of work on the host cores (SURVEY.md 8(d)): ONE CFG-doubled UNet+control call at 1024^2 (latent 128^2,
@@ -188,7 +223,7 @@ def cpu_baseline(model, device, budget_s=60.0):
             torch.set_num_threads(th)
             with torch.no_grad():
                 t0 = time.time()
-                O.control_wrapper(sd, x1, t, cond1, 1.0)
+                network(x1, t, cond1)
                 per_threads[th] = time.time() - t0
         threads = min(per_threads, key=per_threads.get)
         torch.set_num_threads(threads)
@@ -215,7 +250,7 @@ def cpu_baseline(model, device, budget_s=60.0):
             # 50 measured-size steps + the VAE / colour-fix tail at 1024^2 priced at config 1's measured end-to-end rate
             tail_tflop = IMAGE_TFLOP_1024 - 50 * UNET_STEP_TFLOP[128]
             res["value"] = 1.0 / (50 * step_1024_s + tail_tflop / (cfg1_tflop / dt_1))
-            res["sample"] = (f"one CFG-doubled UNet+control call at 1024x1024 through the oracle (fp32, {UNET_STEP_TFLOP[128]:.2f} TFLOP): "
+            res["sample"] = (f"one CFG-doubled UNet+control call at 1024x1024 through {'the reference modules' if ref is not None else 'the oracle'} (fp32, {UNET_STEP_TFLOP[128]:.2f} TFLOP): "
                              f"{step_1024_s:.1f} s = {UNET_STEP_TFLOP[128] / step_1024_s:.3f} TFLOP/s, and BASELINE config 1 end to end "
                              f"(512x512, 2 EDM steps, {cfg1_tflop:.1f} TFLOP): {dt_1:.1f} s, on {threads} of {os.cpu_count()} host threads; "
                              f"value = 1 / (50 x the measured step + the {tail_tflop:.1f} TFLOP VAE / colour-fix tail at config 1's rate)")
@@ -286,6 +321,29 @@ def vae_colorfix_profile(model, P, device):
             e["frac_hbm_peak"] = round(v["bytes"] / v["us"] / 1e3 / HBM_PEAK_GBPS, 3)
         out["kernels"][k] = e
     return out
+
+
+_ROCPROF_NAMES = {"gemm16_kernel<128,80,2k,s3>": "gemm16_kernel<128, 80, 4, 1, 2, 3, false, false, false, 1>",
+                  "gemm16_kernel<128,80,2k,s2>": "gemm16_kernel<128, 80, 4, 1, 2, 2, false, false, false, 1>",
+                  "geglu_big_kernel<256,320,4x2>": "geglu_big_kernel<1>", "attn": "attn_d64_pipe_kernel<3, 4, true, 1>",
+                  "gemm16_kernel<256,160,1k,s3,qkv>": "gemm16_kernel<256, 160, 8, 1, 1, 3, false, false, true, 1>"}
+
+
+def _replay_average_us(kernel):
+    """(average microseconds, file) of `kernel` in the newest committed rocprofv3 --stats summary of the bench command."""
+    import csv
+    import glob
+    want = _ROCPROF_NAMES.get(kernel)
+    if want is None:
+        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_rocprofv3_kernel_stats*.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(f)):
+                if want in row.get("Name", ""):
+                    return float(row["AverageNs"]) / 1e3, os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None
 
 
 def _fused_step_on():
@@ -474,11 +532,32 @@ def main():
             ach = v["bytes"] / v["us"] / 1e3
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBPS, 4)}
-        roofline.update(traffic=(shapes[0]["traffic"] if shapes else None), launches_per_unet_step=v["launches"],
+        # `traffic` = HBM / fabric-side bytes per launch of this kernel (FETCH_SIZE x 2 + WRITE_SIZE from the committed rocprofv3 --pmc
+        # passes, profiles/pmc_traffic.json, averaged over its launches of the step by shape), to be read against
+        # algorithmic_mb_per_launch; None when a shape of the kernel has no counter pass
+        tr_bytes, tr_ok = 0.0, bool(shapes)
+        for e in shapes:
+            te = e.get("traffic")
+            if not te or "fetch_bytes" not in te:
+                tr_ok = False
+                break
+            tr_bytes += (te["fetch_bytes"] + te["write_bytes"]) * e["launches"]
+        traffic_per_launch = tr_bytes / v["launches"] if tr_ok else None
+        roofline.update(traffic=(round(traffic_per_launch) if traffic_per_launch is not None else None),
+                        traffic_unit="bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
+                        traffic_over_algorithmic=(round(traffic_per_launch / (v["bytes"] / v["launches"]), 3)
+                                                  if traffic_per_launch is not None else None),
+                        launches_per_unet_step=v["launches"],
                         avg_launch_us=round(v["us"] / v["launches"], 2),
                         algorithmic_gflop_per_launch=round(v["flops"] / v["launches"] / 1e9, 3),
                         algorithmic_mb_per_launch=round(v["bytes"] / v["launches"] / 1e6, 3),
                         share_of_step_time=round(v["us"] / total_us, 3), shapes=shapes)
+        # the same kernel under graph REPLAY (no event pairs, next-weight prefetch on, the other chain running beside it): its
+        # average duration in the committed rocprofv3 --kernel-trace --stats summary of this command
+        rp = _replay_average_us(name)
+        if rp is not None and v["flops"] > 0:
+            roofline.update(frac_graph_replay=round(v["flops"] / v["launches"] / (rp[0] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                            avg_launch_us_graph_replay=round(rp[0], 2), graph_replay_source=rp[1])
         # the same figures for every kernel class that takes >= 3 % of the step (the dominant one is `roofline`)
         by_kernel = []
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):

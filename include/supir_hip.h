@@ -7,9 +7,11 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
- *   - caller owns every buffer (including workspaces); the library allocates nothing.  Its only mutable state is (a) the
- *     per-thread one-shot request set by supir_set_next_prefetch and consumed by the next GEMM / conv launch of that thread,
- *     (b) the per-thread last-HIP-error code read by supir_last_hip_error; results never depend on either;
+ *   - caller owns every buffer (including workspaces); the library allocates nothing.  Its only mutable state is the per-thread
+ *     last-HIP-error code read by supir_last_hip_error -- plus, for callers of the DEPRECATED one-shot setters
+ *     (supir_set_next_prefetch / supir_set_next_gn_partials, kept for one more round), the request those park until the next
+ *     GEMM / conv launch of the thread.  New code passes the same requests as an ARGUMENT: the *_ex entry points take a
+ *     `const supir_launch_hints*` (round 4) and touch no library state; results never depend on a prefetch request;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and stream ordered, never synchronise;
  *   - return 0 on success, <0 on error (SUPIR_ERR_*); never throws;
  *   - "bf16" buffers are raw 16-bit bfloat16 (IEEE binary16 in the f16 build, see supir_elem_type); activations are NHWC / token-major: element (b, y, x, c) of a
@@ -58,6 +60,22 @@ const char* supir_elem_type(void);
 int supir_last_hip_error(void);
 const char* supir_hip_error_string(int code);
 
+/* Optional per-launch requests of the GEMM-family entry points (supir_gemm_bf16_ex, supir_gemm_bf16_ln_ex, supir_gemm_bf16_qkv_ex,
+ * supir_conv3x3_bf16_ex), passed by pointer (HOST memory, read during the call only; NULL = none):
+ *   next_weight / next_weight_bytes: this launch, after its last store, touches the first `next_weight_bytes` (whole 128-byte lines) of
+ *     `next_weight` -- the bf16 weight matrix of a LATER launch -- so that it is found in the Infinity Cache / L2 instead of HBM.
+ *     Read-only, results unaffected.  (The host mirror knows the launch order of a network call: supir_amd/ops.py WeightPrefetch.)
+ *   gn_partials_out: tiles 32..35 only, bf16 row-major output, rows_per_batch % BM == 0, N % 10 == 0 (else SUPIR_ERR_SHAPE): the launch
+ *     also writes, per batch b, tile row c (BM = 128 or 256 tokens) and 10-channel unit u, the (sum, sum of squares) of the bf16 values
+ *     it stored: gn_partials_out[((b * (rows_per_batch / BM) + c) * (N / 10) + u) * 2 + {0,1}] -- the input of supir_groupnorm_nhwc_parts.
+ * No reference counterpart (the reference's cuBLAS / cuDNN calls meet every weight cold each step and its GroupNorm always runs its
+ * own statistics pass, sgm/modules/diffusionmodules/util.py:258-276). */
+typedef struct supir_launch_hints {
+    const void* next_weight;
+    size_t next_weight_bytes;
+    float* gn_partials_out;
+} supir_launch_hints;
+
 /* C = alpha * act(A . W^T + bias + rowbias[batch]) + residual          A:[M][lda] bf16, W:[N][K] bf16 (K contiguous)
  * Replaces every nn.Linear / 1x1 nn.Conv2d on the path:
  *   sgm/modules/attention.py:87 (GEGLU.proj) :100,106 (FeedForward) :213-219 (to_q/k/v/out) :587,611 (proj_in/out)
@@ -72,6 +90,10 @@ const char* supir_hip_error_string(int code);
 int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream);
+/* the same launch with its optional requests as an argument (hints may be NULL) */
+int supir_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                       const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
+                       int out_mode, float alpha, int tile, const supir_launch_hints* hints, void* stream);
 
 /* supir_gemm_bf16 with LayerNorm folded in (BasicTransformerBlock, sgm/modules/attention.py:465-486: every nn.LayerNorm there
  * feeds an nn.Linear).  Two halves:
@@ -87,6 +109,10 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
                        const void* residual, int ldr, int act, int out_mode, int rows_per_batch, float alpha, int tile,
                        float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                        const float* ln_colsum, float ln_eps, void* stream);
+int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                          const void* residual, int ldr, int act, int out_mode, int rows_per_batch, float alpha, int tile,
+                          float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
+                          const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream);
 
 /* Fused q | k | v projection of a self-attention layer (sgm/modules/attention.py:213-219, 241-249: to_q, to_k, to_v on the
  * same LayerNorm'ed tokens) in ONE launch: W = [Wq; Wk; Wv] ([N][K], N = 3 * inner).  Columns [0, n_split) (q | k) are written
@@ -98,6 +124,10 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
 int supir_gemm_bf16_qkv(const void* A, const void* W, void* Cqk, void* Cvt, int M, int N, int n_split, int K, int lda, int ldc,
                         int ldc_vt, int rows_per_batch, const float* bias, const float* ln_stats, int ln_ld, int ln_slots,
                         const float* ln_colsum, float ln_eps, void* stream);
+/* (hints->gn_partials_out must be NULL: the fused launch emits no GroupNorm partials) */
+int supir_gemm_bf16_qkv_ex(const void* A, const void* W, void* Cqk, void* Cvt, int M, int N, int n_split, int K, int lda, int ldc,
+                           int ldc_vt, int rows_per_batch, const float* bias, const float* ln_stats, int ln_ld, int ln_slots,
+                           const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream);
 
 /* Reduce a producer's row-statistic partials [M][ld][2] to (mean, rstd) [M][2] over `dim` elements per row (fixed order).
  * Consumers then pass ln_slots = 0 and ln_stats = that [M][2] array: two floats per row instead of `slots` partials. */
@@ -118,6 +148,10 @@ int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int 
                        int ldy, int OH, int OW, int stride, int pad_t, int pad_l, int upsample, const float* bias,
                        const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,
                        float alpha, int tile, void* stream);
+int supir_conv3x3_bf16_ex(const void* X, const void* W, void* Y, int B, int H, int Wd, int Cin, int ldx, int Cout,
+                          int ldy, int OH, int OW, int stride, int pad_t, int pad_l, int upsample, const float* bias,
+                          const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,
+                          float alpha, int tile, const supir_launch_hints* hints, void* stream);
 
 /* softmax(Q K^T * scale) V for head dim 64.  Q:[B][Tq][ldq], K:[B][Tk][ldk] with head h at columns h*64..h*64+63;
  * Vt:[B][H*64][ldvt] is V transposed per batch (SUPIR_OUT_BF16_T output of the to_v projection), ldvt >= roundup(Tk,64),
@@ -161,6 +195,7 @@ int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, cons
                          size_t workspace_bytes, const float* given_mean_var, void* stream);
 
 /* GroupNorm with the statistics supplied by the PRODUCER of its input(s) instead of a statistics pass over the tensor:
+ *   supir_launch_hints.gn_partials_out of the producing *_ex launch (preferred), or the DEPRECATED
  *   supir_set_next_gn_partials(buf) -- per calling thread, one-shot (like supir_set_next_prefetch): the next supir_gemm_bf16 /
  *     supir_gemm_bf16_ln / supir_conv3x3_bf16 launch (tiles 32..35 only, bf16 row-major output, rows_per_batch % BM == 0,
  *     N % 10 == 0; anything else -> SUPIR_ERR_SHAPE) also writes, per batch b, tile row c (BM = 128 or 256 tokens) and 10-channel
@@ -245,7 +280,9 @@ int supir_edm_step_post(const float* net_out, const float* x_hat, const float* x
  * autocast casts every step (sgm/modules/diffusionmodules/wrappers.py:87). */
 int supir_prefetch(const void* p, size_t bytes, void* sink, void* stream);
 
-/* One-shot request, consumed by the NEXT supir_gemm_bf16 / supir_gemm_bf16_ln / supir_conv3x3_bf16 call made from this thread:
+/* DEPRECATED (round 4; removed next round) -- pass supir_launch_hints.next_weight to the *_ex entry points instead: a caller that
+ * interleaves launches for two streams from one thread can arm the wrong launch with a thread-local one-shot.
+ * One-shot request, consumed by the NEXT supir_gemm_bf16 / supir_gemm_bf16_ln / supir_conv3x3_bf16 call made from this thread:
  * that launch, after its last store, touches the first `bytes` (whole 128-byte lines) of `p` so that a LATER launch finds
  * them in the Infinity Cache / L2 instead of HBM.  `p` is the bf16 weight matrix of that later launch (the host mirror knows
  * the launch order of a network call: supir_amd/ops.py WeightPrefetch).  Read-only, results unaffected; bytes = 0 cancels.
@@ -263,6 +300,9 @@ int supir_conv3x3_bf16_splitk(const void* X, const void* W, float* partials, int
 int supir_splitk_finalize(const float* partials, int ksplit, int M, int N, const float* bias, int act, void* out, int ldo, void* stream);
 
 /* ---- Grouped launches: n (1 or 2) independent problems of identical shape in ONE kernel launch ------------------------------------
+ * EXPERIMENTAL (round 3): correct and tested (bitwise equal to the single launches, tests/test_grouped_gpu.py), but NOT used by the
+ * product's default path -- on the 1024^2 step two free-running chains of single launches measured faster than grouped launches
+ * (every grouped launch is a join of the two chains: DESIGN.md section 3).  The entry points and struct layouts may change.
  * SUPIR runs two networks of identical architecture on independent data inside every sampling step: GLVControl (the control
  * branch, SUPIR/modules/SUPIR_v0.py:499-540) and the encoder half of LightGLVUNet (:600-625) -- the same ResBlock /
  * SpatialTransformer stack, layer for layer the same shapes, different weights and inputs.  With the CFG-doubled batch of one

@@ -75,8 +75,17 @@ class GnProblem(ctypes.Structure):
                 ("nchunk1", I), ("nchunk2", I), ("control_scale", F)]
 
 
+class LaunchHints(ctypes.Structure):
+    """supir_launch_hints: optional per-launch requests of the *_ex GEMM-family entry points (next-weight prefetch, GroupNorm partials)."""
+    _fields_ = [("next_weight", P), ("next_weight_bytes", c_size_t), ("gn_partials_out", P)]
+
+
 GROUP_GEMM, GROUP_CONV3X3, GROUP_QKV = 0, 1, 2
 SIGNATURES.update({
+    "supir_gemm_bf16_ex": SIGNATURES["supir_gemm_bf16"][:-1] + [P, P],
+    "supir_gemm_bf16_ln_ex": SIGNATURES["supir_gemm_bf16_ln"][:-1] + [P, P],
+    "supir_gemm_bf16_qkv_ex": SIGNATURES["supir_gemm_bf16_qkv"][:-1] + [P, P],
+    "supir_conv3x3_bf16_ex": SIGNATURES["supir_conv3x3_bf16"][:-1] + [P, P],
     "supir_gemm_grouped": [P, P, I, P],
     "supir_conv3x3_bf16_splitk": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "supir_splitk_finalize": [P, I, I, I, P, I, P, I, P],

@@ -15,6 +15,8 @@ static thread_local const char* g_pf_ptr = nullptr;
 static thread_local unsigned g_pf_lines = 0;
 // one-shot request for GroupNorm partial statistics from the producer (supir_set_next_gn_partials), same scope and lifetime
 static thread_local float* g_gn_part_out = nullptr;
+// DEPRECATED path (supir_set_next_prefetch / supir_set_next_gn_partials + the entry points without a hints argument): the
+// thread-local one-shot request, consumed here
 static void take_prefetch(GemmArgs& a) {
     a.pf_ptr = g_pf_ptr;
     a.pf_lines = g_pf_lines;
@@ -22,6 +24,22 @@ static void take_prefetch(GemmArgs& a) {
     g_pf_lines = 0;
     a.gn_part_out = g_gn_part_out;
     g_gn_part_out = nullptr;
+}
+// The *_ex entry points carry the same two requests as an ARGUMENT (supir_launch_hints, may be NULL): no library state involved.
+// hints == SUPIR_HINTS_FROM_TLS marks a call that came in through a legacy entry point.
+static const supir_launch_hints* const SUPIR_HINTS_FROM_TLS = (const supir_launch_hints*)(uintptr_t)1;
+static int apply_hints(GemmArgs& a, const supir_launch_hints* h) {
+    if (h == SUPIR_HINTS_FROM_TLS) {
+        take_prefetch(a);
+        return SUPIR_OK;
+    }
+    if (!h) return SUPIR_OK;
+    if (h->next_weight_bytes && !h->next_weight) return SUPIR_ERR_ARG;
+    const size_t lines = h->next_weight_bytes / 128;
+    a.pf_ptr = (const char*)h->next_weight;
+    a.pf_lines = lines > 0x7fffffffu ? 0x7fffffffu : (unsigned)lines;
+    a.gn_part_out = h->gn_partials_out;
+    return SUPIR_OK;
 }
 
 extern "C" {
@@ -47,9 +65,9 @@ const char* supir_target_arch(void) { return "gfx950"; }
 const char* supir_elem_type(void) { return SUPIR_ELEM_NAME; }
 int supir_gemm_tile_for(int M, int N, int act) { return supir_gemm_select_tile(M, N, act, -1); }
 
-int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
-                    const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
-                    int out_mode, float alpha, int tile, void* stream) {
+int supir_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                       const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
+                       int out_mode, float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
     if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 37 || tile == 36) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
@@ -61,14 +79,21 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
     a.act = act; a.out_mode = out_mode; a.alpha = alpha;
     if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)))
         return SUPIR_ERR_SHAPE;
-    take_prefetch(a);
+    if (const int rc = apply_hints(a, hints)) return rc;
     return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
 }
 
-int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
-                       const void* residual, int ldr, int act, int out_mode, int rows_per_batch, float alpha, int tile,
-                       float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
-                       const float* ln_colsum, float ln_eps, void* stream) {
+int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                    const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
+                    int out_mode, float alpha, int tile, void* stream) {
+    return supir_gemm_bf16_ex(A, W, C, M, N, K, lda, ldc, bias, rowbias, ld_rowbias, rows_per_batch, residual, ldr, act, out_mode, alpha,
+                              tile, SUPIR_HINTS_FROM_TLS, stream);
+}
+
+int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                          const void* residual, int ldr, int act, int out_mode, int rows_per_batch, float alpha, int tile,
+                          float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
+                          const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
     if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 37 || tile == 36) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
@@ -88,13 +113,21 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
         const int bn = (tile == 32 || tile == 35) ? 80 : (tile == 33 || tile == 34) ? 160 : (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
         if ((N + bn - 1) / bn > rs_ld || (rs_ld & 1)) return SUPIR_ERR_ARG;
     }
-    take_prefetch(a);
+    if (const int rc = apply_hints(a, hints)) return rc;
     return supir_gemm_launch(a, false, (hipStream_t)stream, tile);
 }
 
-int supir_gemm_bf16_qkv(const void* A, const void* W, void* Cqk, void* Cvt, int M, int N, int n_split, int K, int lda, int ldc,
-                        int ldc_vt, int rows_per_batch, const float* bias, const float* ln_stats, int ln_ld, int ln_slots,
-                        const float* ln_colsum, float ln_eps, void* stream) {
+int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
+                       const void* residual, int ldr, int act, int out_mode, int rows_per_batch, float alpha, int tile,
+                       float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
+                       const float* ln_colsum, float ln_eps, void* stream) {
+    return supir_gemm_bf16_ln_ex(A, W, C, M, N, K, lda, ldc, bias, residual, ldr, act, out_mode, rows_per_batch, alpha, tile, rowstats_out,
+                                 rs_ld, ln_stats, ln_ld, ln_slots, ln_colsum, ln_eps, SUPIR_HINTS_FROM_TLS, stream);
+}
+
+int supir_gemm_bf16_qkv_ex(const void* A, const void* W, void* Cqk, void* Cvt, int M, int N, int n_split, int K, int lda, int ldc,
+                           int ldc_vt, int rows_per_batch, const float* bias, const float* ln_stats, int ln_ld, int ln_slots,
+                           const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !Cqk || !Cvt || rows_per_batch <= 0) return SUPIR_ERR_ARG;
     if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
     GemmArgs a{};
@@ -104,8 +137,16 @@ int supir_gemm_bf16_qkv(const void* A, const void* W, void* Cqk, void* Cvt, int 
     a.rows_per_batch = rows_per_batch;
     a.alpha = 1.0f;
     a.ln_stats = ln_stats; a.ln_ld = ln_ld; a.ln_slots = ln_slots; a.ln_colsum = ln_colsum; a.ln_eps = ln_eps;
-    take_prefetch(a);
+    if (const int rc = apply_hints(a, hints)) return rc;
+    if (a.gn_part_out) return SUPIR_ERR_ARG;   // the fused q|k|v launch emits no GroupNorm partials
     return supir_gemm16_qkv_launch(a, (hipStream_t)stream);
+}
+
+int supir_gemm_bf16_qkv(const void* A, const void* W, void* Cqk, void* Cvt, int M, int N, int n_split, int K, int lda, int ldc,
+                        int ldc_vt, int rows_per_batch, const float* bias, const float* ln_stats, int ln_ld, int ln_slots,
+                        const float* ln_colsum, float ln_eps, void* stream) {
+    return supir_gemm_bf16_qkv_ex(A, W, Cqk, Cvt, M, N, n_split, K, lda, ldc, ldc_vt, rows_per_batch, bias, ln_stats, ln_ld, ln_slots,
+                                  ln_colsum, ln_eps, SUPIR_HINTS_FROM_TLS, stream);
 }
 
 int supir_rowstats_finalize(const float* partials, float* mean_rstd, int M, int ld, int slots, int dim, float eps,
@@ -114,10 +155,10 @@ int supir_rowstats_finalize(const float* partials, float* mean_rstd, int M, int 
     return supir_rowstats_finalize_launch(partials, mean_rstd, M, ld, slots, dim, eps, (hipStream_t)stream);
 }
 
-int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int Wd, int Cin, int ldx, int Cout,
-                       int ldy, int OH, int OW, int stride, int pad_t, int pad_l, int upsample, const float* bias,
-                       const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,
-                       float alpha, int tile, void* stream) {
+int supir_conv3x3_bf16_ex(const void* X, const void* W, void* Y, int B, int H, int Wd, int Cin, int ldx, int Cout,
+                          int ldy, int OH, int OW, int stride, int pad_t, int pad_l, int upsample, const float* bias,
+                          const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,
+                          float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!X || !W || !Y) return SUPIR_ERR_ARG;
     if (B <= 0 || H <= 0 || Wd <= 0 || OH <= 0 || OW <= 0) return SUPIR_ERR_ARG;
     if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || tile > 35) return SUPIR_ERR_ARG;
@@ -132,8 +173,16 @@ int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int 
     a.H = H; a.W = Wd; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
     a.up = upsample ? 1 : 0;
     a.act = act; a.out_mode = out_mode; a.alpha = alpha;
-    take_prefetch(a);
+    if (const int rc = apply_hints(a, hints)) return rc;
     return supir_gemm_launch(a, true, (hipStream_t)stream, tile);
+}
+
+int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int Wd, int Cin, int ldx, int Cout,
+                       int ldy, int OH, int OW, int stride, int pad_t, int pad_l, int upsample, const float* bias,
+                       const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,
+                       float alpha, int tile, void* stream) {
+    return supir_conv3x3_bf16_ex(X, W, Y, B, H, Wd, Cin, ldx, Cout, ldy, OH, OW, stride, pad_t, pad_l, upsample, bias, rowbias, ld_rowbias,
+                                 residual, ldr, act, out_mode, alpha, tile, SUPIR_HINTS_FROM_TLS, stream);
 }
 
 int supir_conv3x3_bf16_splitk(const void* X, const void* W, float* partials, int B, int H, int Wd, int Cin, int ldx, int Cout, int OH,

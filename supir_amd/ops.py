@@ -232,7 +232,7 @@ class WeightPrefetch:
     """Record the order in which weight matrices are consumed during one network call; while the same call is replayed
     (normally: captured into a hipGraph) make the launch of op i pull the weight of op i+distance towards the caches.
 
-    mode "inline" (default): `supir_set_next_prefetch` -- op i's own GEMM kernel touches the later weight after its last
+    mode "inline" (default): supir_launch_hints.next_weight of the launch -- op i's own GEMM kernel touches the later weight after its last
     store; no extra launches, streams or graph edges.  mode "stream": a `supir_prefetch` launch per op on a dedicated stream
     behind an event edge (kept for tools/cold_probe.py; measured slower end to end: +1168 graph nodes per step)."""
 
@@ -265,9 +265,6 @@ class WeightPrefetch:
         if self.mode == "replay":
             if self.kind == "stream" and self.stream is not None:
                 torch.cuda.current_stream().wait_stream(self.stream)     # join (required inside a capture)
-            else:
-                for lib in _lib.loaded():   # the one-shot request lives in the library that would have launched next
-                    lib.supir_set_next_prefetch(None, 0)
         self.mode = None
 
     def touch_group(self, ws):
@@ -292,17 +289,19 @@ class WeightPrefetch:
         return [nxt[k] if k < len(nxt) else None for k in range(len(ws))]
 
     def touch(self, w):
+        """The (pointer, bytes) this launch should touch on its way out (inline kind: travels with the launch as
+        supir_launch_hints.next_weight), or None (nothing planned / the stream kind, which issues its own prefetch launch here)."""
         nxt = self.touch_group([w])[0]
         if nxt is None:
-            return
+            return None
         ptr, nb = nxt
         if self.kind == "stream":
             ev = torch.cuda.Event()
             ev.record()                       # on the op's own stream: "op i is next"
             self.stream.wait_event(ev)
             _lib.load().supir_prefetch(ptr, nb, self.sink.data_ptr(), self.stream.cuda_stream)
-        else:
-            _lib.load(w.dtype).supir_set_next_prefetch(ptr, nb)
+            return None
+        return ptr, nb
 
 
 _PF = None
@@ -315,7 +314,8 @@ def set_prefetch(pf):
 
 def _pf(w):
     if _PF is not None and _PF.mode is not None:
-        _PF.touch(w)
+        return _PF.touch(w)
+    return None
 
 
 def _pf_group(ws):
@@ -326,7 +326,7 @@ def _pf_group(ws):
 
 # --------------------------------------------------------------------------------------------- GroupNorm statistics from producers
 class GnPart:
-    """What a producer GEMM / conv epilogue left behind for a GroupNorm over its output (supir_set_next_gn_partials): fp32
+    """What a producer GEMM / conv epilogue left behind for a GroupNorm over its output (supir_launch_hints.gn_partials_out): fp32
     [B, nchunk, C // 10, 2] = (sum, sum of squares) per batch, tile row and 10-channel unit of the bf16 values it stored."""
     __slots__ = ("buf", "nchunk", "C")
 
@@ -339,7 +339,7 @@ USE_GN_PARTS = _os.environ.get("SUPIR_GN_PARTS", "1") != "0"   # producers emit 
 
 def _gn_part_alloc(tile, nbatch, rows_per_batch, N, device):
     """The buffer a launch on `tile` fills with GroupNorm partials of its output, if that tile can emit them; returns the GnPart
-    or None.  (The request itself travels with the launch: the one-shot supir_set_next_gn_partials for a single launch, the
+    or None.  (The request itself travels with the launch: supir_launch_hints.gn_partials_out for a single launch, the
     problem's gn_partials_out field for a grouped one.)"""
     if not USE_GN_PARTS or tile not in _G16:
         return None
@@ -384,12 +384,14 @@ class _Launch:
 
 
 def _run_single(L):
-    if L.w is not None:
-        _pf(L.w)
-    if L.part is not None:
-        L.lib.supir_set_next_gn_partials(L.part.buf.data_ptr())
+    # per-launch requests travel WITH the launch (supir_launch_hints of the *_ex entry points): no thread-local state in the library
+    nxt = _pf(L.w) if L.w is not None else None
+    hints = None
+    if nxt is not None or L.part is not None:
+        hints = _lib.LaunchHints(next_weight=nxt[0] if nxt else None, next_weight_bytes=nxt[1] if nxt else 0,
+                                 gn_partials_out=L.part.buf.data_ptr() if L.part is not None else None)
     ev = _ev()
-    rc = L.call(L.tile, None)
+    rc = L.call(L.tile, None, hints) if hints is not None else L.call(L.tile, None)
     _lib.check(rc, L.name, L.lib)
     if L.trace is not None:
         _rec(L.trace[0], L.trace[1], L.trace[2], ev, **L.trace[3])
@@ -633,10 +635,11 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
     def wb(t):
         return (alt16[0], alt16[1]) if (t in (34, 37) and act == 2 and alt16 is not None) else (w, bias)
 
-    def launch(t, outp=None):
+    def launch(t, outp=None, hints=None):
         wq, bq = wb(t)
-        return lib.supir_gemm_bf16(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
-                                   _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, act, om, alpha, t, _stream())
+        return lib.supir_gemm_bf16_ex(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
+                                      _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, act, om, alpha, t,
+                                      None if hints is None else _ct.byref(hints), _stream())
 
     inplace = residual is not None and residual.data_ptr() == out.data_ptr()
     key = ("gemm", M, N, K, act, om) + _k(DT)
@@ -784,11 +787,11 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
     def wcb(t):
         return alt16 if (t in (34, 37) and act == 2 and alt16 is not None) else (w, colsum, bias)
 
-    def launch(t, outp=None):
+    def launch(t, outp=None, hints=None):
         wq, cq, bq = wcb(t)
-        return lib.supir_gemm_bf16_ln(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
-                                      _p(bq), _p(residual), ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots,
-                                      _p(cq), ln_eps, _stream())
+        return lib.supir_gemm_bf16_ln_ex(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
+                                         _p(bq), _p(residual), ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots,
+                                         _p(cq), ln_eps, None if hints is None else _ct.byref(hints), _stream())
 
     inplace = residual is not None and residual.data_ptr() == out.data_ptr()
     key = ("gemm", M, N, K, act, om) + _k(DT)
@@ -861,9 +864,10 @@ def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, ou
         ln_p, ln_ld, ln_slots = ln.buf.data_ptr(), ln.ld, ln.slots
         assert colsum is not None and colsum.numel() == N
 
-    def launch(t, outp=None):
-        return lib.supir_gemm_bf16_qkv(a.data_ptr(), w.data_ptr(), out_qk.data_ptr(), out_vt.data_ptr(), M, N, n_split, K, lda, n_split,
-                                       T, T, _p(bias), ln_p, ln_ld, ln_slots, _p(colsum), ln_eps, _stream())
+    def launch(t, outp=None, hints=None):
+        return lib.supir_gemm_bf16_qkv_ex(a.data_ptr(), w.data_ptr(), out_qk.data_ptr(), out_vt.data_ptr(), M, N, n_split, K, lda, n_split,
+                                          T, T, _p(bias), ln_p, ln_ld, ln_slots, _p(colsum), ln_eps,
+                                          None if hints is None else _ct.byref(hints), _stream())
 
     def make(t, outp=None):
         sh = _lib.GemmShape(kind=_lib.GROUP_QKV, tile=34, M=M, N=N, K=K, rows_per_batch=T, n_split=n_split, alpha=1.0, ln_eps=ln_eps)
@@ -924,9 +928,9 @@ def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
             torch.empty(B, N, Tpad, dtype=DT, device=a.device)
     assert out.dtype == DT
 
-    def launch(t, outp=None):
-        return lib.supir_gemm_bf16(a.data_ptr(), w.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, Tpad, _p(bias),
-                                   0, 0, T, 0, 0, 0, 2, 1.0, t, _stream())
+    def launch(t, outp=None, hints=None):
+        return lib.supir_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, Tpad, _p(bias),
+                                      0, 0, T, 0, 0, 0, 2, 1.0, t, None if hints is None else _ct.byref(hints), _stream())
 
     key = ("gemm", M, N, K, 0, 2) + _k(DT)
     cands = ()
@@ -987,7 +991,7 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
     M_all = B * OH * OW
     split_ws = []
 
-    def launch(t, outp=None):
+    def launch(t, outp=None, hints=None):
         if t >= 64:
             # tap-split form (supir_conv3x3_bf16_splitk): nine fp32 partials + a finalize launch (bias, SiLU, bf16), codes 64 + tile
             if not split_ws:
@@ -998,9 +1002,9 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
                 return rc
             return lib.supir_splitk_finalize(split_ws[0].data_ptr(), 9, M_all, Cout, _p(bias), act, (out if outp is None else outp).data_ptr(),
                                              ldy, _stream())
-        return lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), (out if outp is None else outp).data_ptr(), B, H, W, Cin, ldx, Cout,
-                                      ldy, OH, OW, stride, pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb,
-                                      _p(residual), ldr, act, om, alpha, t, _stream())
+        return lib.supir_conv3x3_bf16_ex(x.data_ptr(), w.data_ptr(), (out if outp is None else outp).data_ptr(), B, H, W, Cin, ldx, Cout,
+                                         ldy, OH, OW, stride, pad[0], pad[1], 1 if upsample else 0, _p(bias), _p(rowbias), ld_rb,
+                                         _p(residual), ldr, act, om, alpha, t, None if hints is None else _ct.byref(hints), _stream())
 
     inplace = residual is not None and residual.data_ptr() == out.data_ptr()
     key = ("conv", B, H, W, Cin, Cout, stride, bool(upsample)) + _k(DT)

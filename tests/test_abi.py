@@ -111,7 +111,7 @@ def test_grouped_launch_structs_match_the_header_layout(tmp_path):
         import pytest
         pytest.skip("no C compiler")
     pairs = {"supir_gemm_problem": _lib.GemmProblem, "supir_gemm_shape": _lib.GemmShape, "supir_attn_problem": _lib.AttnProblem,
-             "supir_gn_problem": _lib.GnProblem}
+             "supir_gn_problem": _lib.GnProblem, "supir_launch_hints": _lib.LaunchHints}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "supir_hip.h")}"', "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
@@ -142,3 +142,26 @@ def test_grouped_launch_structs_match_the_header_layout(tmp_path):
     assert lib.supir_gemm_grouped(ctypes.byref(sh), pr, 2, None) == -2            # inexact shape
     assert lib.supir_flash_attn_d64_grouped(None, 2, 2, 20, 1024, 0.125, None) == -1
     assert lib.supir_groupnorm_grouped(None, 2, 2, 1024, 1280, 1e-5, 1, None) == -1
+
+
+def test_hinted_entry_points_take_their_requests_as_an_argument():
+    """Round 4: supir_*_ex carry the next-weight prefetch / GroupNorm-partials requests in a supir_launch_hints argument (the
+    thread-local one-shot setters are deprecated shims).  Validation without a GPU: NULL hints are fine, a byte count without a pointer
+    is an argument error, the fused q|k|v launch refuses a GroupNorm-partials request, and a legacy call after an _ex call does not
+    inherit anything (no state left behind)."""
+    import ctypes
+    lib = _lib.load()
+    fake = 0x10000
+    g = (fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 32)
+    assert lib.supir_gemm_bf16_ex(*g, None, None) == -2                                   # inexact shape for tile 32: reached the dispatcher
+    bad = _lib.LaunchHints(next_weight=None, next_weight_bytes=4096, gn_partials_out=None)
+    assert lib.supir_gemm_bf16_ex(*g, ctypes.byref(bad), None) == -1                      # bytes without a pointer
+    assert lib.supir_gemm_bf16_ex(None, None, None, 64, 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 0, 1.0, -1, None, None) == -1
+    ok = _lib.LaunchHints(next_weight=fake, next_weight_bytes=4096, gn_partials_out=fake)
+    q = (fake, fake, fake, fake, 2048, 3840, 2560, 1280, 1280, 2560, 1024, 1024, None, None, 0, 0, None, 1e-5)
+    assert lib.supir_gemm_bf16_qkv_ex(*q, ctypes.byref(ok), None) == -1                   # q|k|v emits no GroupNorm partials
+    c = (fake, fake, fake, 2, 8, 8, 64, 64, 64, 64, 8, 8, 3, 1, 1, 0, None, None, 0, None, 0, 0, 0, 1.0, -1)
+    assert lib.supir_conv3x3_bf16_ex(*c, ctypes.byref(ok), None) == -2                    # stride 3: shape error, after the hints were read
+    ln = (fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, 0, 0, 1.0, 32, None, 0, None, 0, 0, None, 1e-5)
+    assert lib.supir_gemm_bf16_ln_ex(*ln, ctypes.byref(bad), None) == -1
+    assert lib.supir_gemm_bf16_ln_ex(*ln, None, None) == -2
