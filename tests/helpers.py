@@ -30,6 +30,13 @@ def golden():
     return _gold["g"]
 
 
+def golden_control():
+    """The ten GLVControl feature maps of the reference as full tensors (oracle/gen_golden_control.py)."""
+    if "c" not in _gold:
+        _gold["c"] = torch.load(os.path.join(GOLDEN_DIR, "golden_control.pt"), map_location="cpu", weights_only=False)["control_features"]
+    return _gold["c"]
+
+
 def rel_l2(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return ((a - b).norm() / (b.norm() + 1e-20)).item()

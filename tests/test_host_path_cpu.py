@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from tests import torch_ops
-from tests.helpers import build_unet, build_vae, golden, rel_l2, synth_tensor
+from tests.helpers import build_unet, build_vae, golden, golden_control, rel_l2, synth_tensor
 
 B = 2
 TOL = 2e-5     # fp32 summation-order noise of a different association of the same arithmetic (measured: 5e-8 .. 2e-6)
@@ -89,14 +89,13 @@ def test_network_call_vs_reference_golden(wrap, backend, fused_qkv):
     assert eps.dtype == torch.float32 and tuple(eps.shape) == (B, 4, 16, 16)
     assert rel_l2(eps, g["wrapper_eps"]) <= TOL and rel_l2(eps5, g["wrapper_eps_cs0.5"]) <= TOL
     assert len(hs) == 10
-    full = g.get("control_features")
+    full = golden_control()
     for i, h in enumerate(hs):
         d = g["control_digest"][i]
         assert list(h.shape) == d["shape"]
         f = h.float().contiguous().flatten()
         assert torch.allclose(torch.cat([f[:32], f[-32:]]), torch.cat([d["head"], d["tail"]]), rtol=1e-4, atol=1e-5 * d["std"])
-        if full is not None:      # full tensors of all ten feature maps (fixtures regenerated in round 4)
-            assert rel_l2(h, full[i]) <= TOL, i
+        assert h.shape == full[i].shape and rel_l2(h, full[i]) <= TOL, i   # the reference's full tensors, all ten maps
 
 
 def test_unfolded_transformer_path_matches_the_folded_one(wrap):

@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.helpers import (build_unet, build_vae, golden, manifest, rel_l2, synth_sd, synth_tensor)  # noqa: E402
+from tests.helpers import (build_unet, build_vae, golden, golden_control, manifest, rel_l2, synth_sd, synth_tensor)  # noqa: E402
 
 DEV = "cuda"
 B = 2
@@ -98,6 +98,10 @@ def test_control_features_and_wrapper_vs_reference_golden(wrap, g):
             f = h.float().contiguous().flatten().cpu()
             got, want = torch.cat([f[:32], f[-32:]]), torch.cat([d["head"], d["tail"]])
             assert (got - want).norm().item() <= 2.5e-2 * d["std"] * 8.0, (i, (got - want).norm().item(), d["std"])   # 8 = sqrt(64)
+        # all ten maps against the reference's FULL tensors (round 4: golden_control.pt)
+        errs = [rel_l2(h, full) for h, full in zip(hs, golden_control())]
+        print("control features vs reference (full tensors):", [f"{e:.2e}" for e in errs])
+        assert max(errs) <= 1.5e-2, errs
         eps = wrap(x, t, cond, 1.0)
         assert eps.dtype == torch.float32 and tuple(eps.shape) == (B, 4, 16, 16)
         e1 = rel_l2(eps, g["wrapper_eps"])

@@ -90,6 +90,9 @@ def test_control_and_wrapper(sd, g):
             assert list(h.shape) == d["shape"]
             assert rel_l2(h.flatten()[:32], d["head"]) <= TOL and rel_l2(h.flatten()[-32:], d["tail"]) <= TOL
             assert abs(h.std().item() - d["std"]) <= 1e-4 * d["std"]
+        from tests.helpers import golden_control
+        for i, (h, full) in enumerate(zip(hs, golden_control())):       # the FULL reference tensors of all ten maps (round 4)
+            assert h.shape == full.shape and rel_l2(h, full) <= TOL, i
         assert rel_l2(O.control_wrapper(sd, x, t, cond, 1.0), g["wrapper_eps"]) <= TOL
         assert rel_l2(O.control_wrapper(sd, x, t, cond, 0.5), g["wrapper_eps_cs0.5"]) <= TOL
 
