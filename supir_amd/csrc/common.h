@@ -89,6 +89,17 @@ __device__ __forceinline__ float erf_as(float x) {
 // QuickGELU x * sigmoid(1.702 x): the activation of OpenAI CLIP text towers (transformers CLIPTextModel "quick_gelu")
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// The same function as x * sigmoid(x * (c0 + c1 x^2 + c2 x^4)): a minimax fit of Phi(x) = (1 + erf(x / sqrt 2)) / 2 (scipy, [-8, 8]) with
+// max |gelu error| 2.5e-5 ABSOLUTE -- below half a bf16 ulp of the result for |result| >= 0.013 and 100x below the bf16 rounding of
+// typical activations; 8 VALU + 2 transcendental instructions instead of 15 + 2.  The argument is clamped to [-7, 7] (the fitted
+// polynomial turns over beyond |x| = 7.25; sigmoid is saturated to 1 - 2e-11 there).  Coefficients carry the -log2(e) of exp2.
+__device__ __forceinline__ float gelu_fast_f(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
+    const float u = xc * xc;
+    float pl = fmaf(1.01426305e-03f, u, -1.06775724e-01f);   // -log2(e) * (-7.03033579e-04, 7.40112920e-02)
+    pl = fmaf(pl, u, -2.30112133f);                          // -log2(e) * 1.59501577
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xc * pl));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

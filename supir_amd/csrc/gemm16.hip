@@ -62,8 +62,13 @@ __device__ __attribute__((aligned(256))) uint32_t g16_zero_page[64];
 // Used for the layer pairs GLVControl and the UNet encoder execute with identical shapes on independent data
 // (SUPIR/modules/SUPIR_v0.py:499-540 next to :600-625): M = 2048 tokens per problem fill only half the machine with tiles big
 // enough to be fed from L2 (128 x 80 at 49 FLOP per staged byte); two problems of 128 x 160 tiles are 256 workgroups at 65.
+//
+// Four-wave form (tile 38 = 128 x 80, 4x1 waves, ONE K group, 3-deep ring = 78 KB, round 4): half the threads and half the LDS of
+// tile 35, so that TWO workgroups fit a CU -- in the two-stream step one of GLVControl's and one of the UNet encoder's (VERDICT r03
+// item 2: every other tile of this family takes 104-156 KB and a CU then runs one workgroup of one chain at a time).  Same loader,
+// same fragment layout, same epilogue; the K-group exchange disappears.
 template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1>
-__global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgsN<NP> pp) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) void gemm16_kernel(const GemmArgsN<NP> pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NX = 8 / NP;                                               // XCDs per problem
     const int prob = NP == 1 ? 0 : (int)(blockIdx.x & 7) / NX;               // wave-uniform: a scalar offset into the kernarg segment
@@ -76,7 +81,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgsN<NP> pp) 
     constexpr int B_CH = BN / 8, B_Q = (B_CH + NW - 1) / NW;   // chunks of W per tile / per wave (the last q may be partial)
     constexpr int LOADS = A_Q + B_Q;                     // global->LDS instructions per wave and stage
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, MIH = MI / KS;
-    static_assert(NW * KS == 8 && (BM / 8) % NW == 0 && (NW & 1) == 0, "512 threads; A chunks divide over the waves");
+    constexpr int NWT = NW * KS, NTHREADS = 64 * NWT;   // waves / threads per workgroup (8 / 512; tile 38: 4 / 256)
+    static_assert((NWT == 8 || (NWT == 4 && KS == 1 && !MIXED && NP == 1)) && (BM / 8) % NW == 0 && (NW & 1) == 0,
+                  "512 threads (or the four-wave single-group form); A chunks divide over the waves");
     static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3), "tile / wave grid");
     static_assert(!(CONV && TRANS) && !(MIXED && (TRANS || CONV || KS != 1)), "the implicit-GEMM loader has no transposed epilogue");
     // epilogue LDS map (the rings are idle by then): [0, XCH) K-group exchange, then per-wave C staging, bias / column sums,
@@ -85,9 +92,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgsN<NP> pp) 
     constexpr int XCH = 2 * XCH_HALF;
     constexpr int C_RS = WTN * 2 + 16;                         // staged row stride (bytes): 16-byte pad against bank conflicts
     constexpr int C_STAGE = 16 * C_RS;                         // one 16-token block per wave
-    constexpr int OFF_CST = XCH, OFF_BIAS = OFF_CST + 8 * C_STAGE, OFF_RED = OFF_BIAS + 2 * BN * 4;
-    constexpr int OFF_GN = OFF_RED + WN * BM * 8;               // GroupNorm column partials: [wave 0..7][WTN][2] fp32
-    static_assert(OFF_GN + 8 * WTN * 8 <= KS * RING, "epilogue scratch must fit the LDS rings");
+    constexpr int OFF_CST = XCH, OFF_BIAS = OFF_CST + NWT * C_STAGE, OFF_RED = OFF_BIAS + 2 * BN * 4;
+    constexpr int OFF_GN = OFF_RED + WN * BM * 8;               // GroupNorm column partials: [wave 0..NWT-1][WTN][2] fp32
+    static_assert(OFF_GN + NWT * WTN * 8 <= KS * RING, "epilogue scratch must fit the LDS rings");
 
     // wave-uniform ids as scalars (readfirstlane): LDS destinations / branches on them stay on the scalar unit
     const int bwave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // wave inside the workgroup, 0..7
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgsN<NP> pp) 
     auto prefetch_next = [&]() {
         const unsigned pf_lines = p.pf_lines;
         if (pf_lines == 0) return;
-        const unsigned total_waves = gridDim.x / NP * 8, gw = (unsigned)(vidx * NX + vxcd) * 8 + bwave;   // per problem
+        const unsigned total_waves = gridDim.x / NP * NWT, gw = (unsigned)(vidx * NX + vxcd) * NWT + bwave;   // per problem
         const unsigned n_instr = (pf_lines + 63) >> 6;
         for (unsigned i = gw; i < n_instr; i += total_waves) {
             unsigned line = i * 64 + lane;
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(const GemmArgsN<NP> pp) 
         if constexpr (WN > 1) {
             if (p.rowstats_out) {   // combine the wave columns in a fixed order: one slot per tile column
                 __syncthreads();
-                for (int r = (int)threadIdx.x; r < BM; r += 512) {
+                for (int r = (int)threadIdx.x; r < BM; r += NTHREADS) {
                     float sm = 0.f, sq = 0.f;
 #pragma unroll
                     for (int w = 0; w < WN; ++w) {
@@ -699,15 +706,15 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    SUPIR_LAUNCH(kern, dim3(NP * tiles), dim3(512), smem, st, pp);
+    SUPIR_LAUNCH(kern, dim3(NP * tiles), dim3(64 * WM * WN * KS), smem, st, pp);
     return SUPIR_LAUNCH_STATUS();
 }
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    if (tile < 32 || tile > 35) return false;
-    const int bm = tile == 34 ? 256 : 128, bn = (tile == 32 || tile == 35) ? 80 : 160;
-    const int ks = tile == 34 ? 1 : 2, s = (tile == 34 || tile == 35) ? 3 : 2;
+    if ((tile < 32 || tile > 35) && tile != 38) return false;
+    const int bm = tile == 34 ? 256 : 128, bn = (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
+    const int ks = (tile == 34 || tile == 38) ? 1 : 2, s = (tile == 34 || tile == 35 || tile == 38) ? 3 : 2;
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
     if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % 10)) return false;
@@ -729,11 +736,13 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
             case 32: return launch_gemm16<128, 80, 4, 1, 2, 2, false, true>(&a, st);
             case 33: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true>(&a, st);
             case 34: return launch_gemm16<256, 160, 8, 1, 1, 3, false, true>(&a, st);
+            case 38: return launch_gemm16<128, 80, 4, 1, 1, 3, false, true>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
     const bool t = a.out_mode == 2;
     switch (tile) {
+        case 38: return t ? launch_gemm16<128, 80, 4, 1, 1, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 1, 3, false>(&a, st);
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);
         case 34: return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true>(&a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false>(&a, st);
@@ -750,7 +759,7 @@ static bool g16_same_shape(const GemmArgs& x, const GemmArgs& y) {
 
 int supir_gemm16_launch_n(const GemmArgs* a, int n, hipStream_t st, int tile, bool conv) {
     if (n == 1) return supir_gemm16_launch(a[0], st, tile, conv);
-    if (n != 2 || tile == 32) return SUPIR_ERR_SHAPE;
+    if (n != 2 || tile == 32 || tile == 38) return SUPIR_ERR_SHAPE;
     if (!supir_gemm16_supported(a[0], tile, conv) || !supir_gemm16_supported(a[1], tile, conv) || !g16_same_shape(a[0], a[1])) return SUPIR_ERR_SHAPE;
     if (conv) {
         switch (tile) {

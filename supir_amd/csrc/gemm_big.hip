@@ -53,6 +53,19 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 g) {
     return 0.5f * g * (1.0f + ys);
 }
 
+// gelu_fast_f of common.h on two values at once (round 4): x * sigmoid(x * poly(x^2)), 5 packed + 3 x 2 scalar instructions per pair
+// instead of 12 packed + 4 x 2 scalar
+__device__ __forceinline__ f32x2 gelu2_fast(f32x2 g) {
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(g[0], -7.0f, 7.0f), __builtin_amdgcn_fmed3f(g[1], -7.0f, 7.0f)};
+    const f32x2 u = xc * xc;
+    f32x2 pl = u * 1.01426305e-03f + -1.06775724e-01f;
+    pl = pl * u + -2.30112133f;
+    const f32x2 a = xc * pl;
+    const f32x2 d = {1.0f + __builtin_amdgcn_exp2f(a[0]), 1.0f + __builtin_amdgcn_exp2f(a[1])};
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return g * r;
+}
+
 constexpr int BM = 256, BN = 320, S = 2;
 constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;   // one K step (64 wide): A tile, then W tile
 constexpr int A_LOADS = BM * 8 / 512, W_LOADS = BN * 8 / 512;   // global->LDS instructions per thread per K step (4 + 5)
@@ -60,7 +73,9 @@ constexpr int LOADS = A_LOADS + W_LOADS;
 constexpr int C_RS = 80 * 2 + 16;                  // staged output row: 80 bf16 + 16 B pad
 
 // NP = 2: two problems of identical shape in one grid, problem q on XCDs [4 q, 4 q + 4) (see gemm16.hip)
-template <int NP>
+// FASTGELU: gelu2_fast instead of gelu2 in the epilogue (the product default since round 4; the exact-erf instantiation is kept
+// selectable for A/B runs: supir_debug_knob(0, 1))
+template <int NP, bool FASTGELU = true>
 __global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgsN<NP> pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NX = 8 / NP;
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgsN<NP> p
                     const f32x2 bv2 = {bv[2 * e], bv[2 * e + 1]}, bg2 = {bg[2 * e], bg[2 * e + 1]};
                     const f32x2 v = rs * (av - mu * cv2) + bv2;
                     const f32x2 g = rs * (ag - mu * cg2) + bg2;
-                    r[e] = v * gelu2(g);
+                    r[e] = v * (FASTGELU ? gelu2_fast(g) : gelu2(g));
                 }
                 const u32x2 o = {f2bf_pk(r[0][0], r[0][1]), f2bf_pk(r[1][0], r[1][1])};
                 *(u32x2*)(c_stage + l31 * C_RS + (j * 16 + 8 * rg + 4 * half) * 2) = o;
@@ -312,11 +327,17 @@ static int launch_big(const GemmArgs* a_in, hipStream_t st) {
     static_assert(4096 + 8 * 32 * C_RS <= S * STAGE && 2 * BN * 4 <= 4096, "epilogue scratch must fit the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        if (supir_note_hip_status(hipFuncSetAttribute((const void*)geglu_big_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK)
+        if (supir_note_hip_status(hipFuncSetAttribute((const void*)geglu_big_kernel<NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK)
+            return SUPIR_ERR_HIP;
+        if (supir_note_hip_status(hipFuncSetAttribute((const void*)geglu_big_kernel<NP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK)
             return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    SUPIR_LAUNCH(geglu_big_kernel<NP>, dim3(NP * tiles), dim3(512), smem, st, pp);
+    if (supir_debug_knob_value(0)) {
+        SUPIR_LAUNCH((geglu_big_kernel<NP, false>), dim3(NP * tiles), dim3(512), smem, st, pp);
+    } else {
+        SUPIR_LAUNCH((geglu_big_kernel<NP, true>), dim3(NP * tiles), dim3(512), smem, st, pp);
+    }
     return SUPIR_LAUNCH_STATUS();
 }
 

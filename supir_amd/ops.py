@@ -77,7 +77,8 @@ def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1, group=1):
         name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2"][tile - 64]
         return f"gemm_bf16_kernel<{name},conv,split9>+finalize"
     if tile is not None and tile >= 32:
-        nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv"}[tile]
+        nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv",
+              38: "128,80,1k,s3,4w"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}{g}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
@@ -686,9 +687,11 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
 
 _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
-               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2)}
+               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2), 38: (80, 1)}
 G16_TILES = {32, 33, 34, 35}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
-_G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3)}   # tile: (BM, BN, K groups, ring)
+# tile: (BM, BN, K groups, ring).  38 = 128 x 80 with FOUR waves and a 78 KB ring (two workgroups per CU): known to the mirror, enabled
+# by adding it to G16_TILES (tools/step_ab4.py); not in the default lists -- see DESIGN.md section 3 for what it measured
+_G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3), 38: (128, 80, 1, 3)}
 USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc/gemm16.hip) in the autotune lists
 USE_GEMM_BIG = _os.environ.get("SUPIR_GEMM_BIG", "1") != "0"   # tile 37 (csrc/gemm_big.hip) in the GEGLU autotune lists
 USE_CONV_SPLIT = _os.environ.get("SUPIR_CONV_SPLIT", "1") != "0"   # tap-split conv3x3 (codes 64 + tile) in the autotune lists of small-grid convs

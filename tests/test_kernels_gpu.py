@@ -476,16 +476,16 @@ G16_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (8192,
               (384, 320, 256)]
 
 
-_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80)}
+_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 38: (128, 80)}   # 38: four waves, one K group (round 4)
 
 
 @pytest.mark.parametrize("M,N,K", G16_SHAPES)
-@pytest.mark.parametrize("tile", [32, 33, 34, 35])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
 def test_gemm16_plain_and_epilogues(M, N, K, tile):
     """128 x 80 / 128 x 160 / 256 x 160 tiles (v_mfma_f32_16x16x32_bf16; two K groups per workgroup or eight waves on a 3-deep
     ring): plain, residual + alpha, row bias + SiLU, strided operands, run-to-run bitwise equality."""
     bm, bn = _G16_TILE[tile]
-    if N % bn or M % bm or (tile == 35 and K < 256):
+    if N % bn or M % bm or (tile == 35 and K < 256) or (tile == 38 and K < 128):
         pytest.skip("tile needs M % BM == 0, N % BN == 0 and at least ring-depth - 1 K steps per K group")
     a = rnd(M, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
@@ -514,7 +514,7 @@ def test_gemm16_plain_and_epilogues(M, N, K, tile):
 
 
 @pytest.mark.parametrize("B,T,N,K", [(2, 1024, 1280, 1280), (2, 4096, 640, 640), (1, 256, 160, 128)])
-@pytest.mark.parametrize("tile", [32, 33, 34, 35])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
 def test_gemm16_transposed(B, T, N, K, tile):
     if tile == 35 and K < 256:
         pytest.skip("3-deep rings need two K steps per K group")
@@ -527,7 +527,7 @@ def test_gemm16_transposed(B, T, N, K, tile):
 
 
 @pytest.mark.parametrize("M,C,N", [(2048, 1280, 2560), (8192, 640, 640), (256, 640, 1280)])
-@pytest.mark.parametrize("ptile,ctile", [(32, 32), (33, 33), (32, 0), (3, 32), (0, 33), (34, 35), (35, 34)])
+@pytest.mark.parametrize("ptile,ctile", [(32, 32), (33, 33), (32, 0), (3, 32), (0, 33), (34, 35), (35, 34), (38, 38), (38, 33)])
 def test_gemm16_layernorm_folding(M, C, N, ptile, ctile):
     """Row statistics emitted by / consumed from the 16x16x32 tiles, mixed with the 32x32x16 tiles on the other side."""
     from supir_amd.weights import fold_layernorm
@@ -651,7 +651,8 @@ def _unit_sums(y, B, rows_per_batch, bm):
     return torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
 
 
-@pytest.mark.parametrize("case", [(2, 32, 32, 1280, 1280, 35), (2, 64, 64, 640, 640, 33), (2, 128, 128, 320, 320, 34), (2, 32, 32, 640, 1280, 32)])
+@pytest.mark.parametrize("case", [(2, 32, 32, 1280, 1280, 35), (2, 64, 64, 640, 640, 33), (2, 128, 128, 320, 320, 34), (2, 32, 32, 640, 1280, 32),
+                                  (2, 32, 32, 1280, 1280, 38)])
 def test_groupnorm_statistics_from_the_conv_epilogue(case):
     """supir_set_next_gn_partials: a gemm16 conv launch also leaves (sum, sum of squares) per (batch, tile row, 10-channel unit) of the
     bf16 values it stored; supir_groupnorm_nhwc_parts normalises with them in one launch (openaimodel.py:295-308: conv -> GroupNorm32
@@ -725,12 +726,12 @@ G16_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", G16_CONV_CASES)
-@pytest.mark.parametrize("tile", [32, 33, 34, 35])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
 def test_gemm16_conv3x3(case, tile):
     """Implicit-GEMM 3x3 convolution on the 16x16x32 tiles: plain, and with bias + time-embedding row bias + SiLU + residual."""
     B, H, W, Cin, Cout, stride, pad, up, out_hw = case
     bm, bn = _G16_TILE[tile]
-    ks = 1 if tile == 34 else 2
+    ks = 1 if tile in (34, 38) else 2
     x = rnd(B, H, W, Cin).to(BF)
     w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
     bias = rnd(Cout, seed=2)
