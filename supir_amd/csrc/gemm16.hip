@@ -735,7 +735,11 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
         switch (tile) {
             case 32: return launch_gemm16<128, 80, 4, 1, 2, 2, false, true>(&a, st);
             case 33: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true>(&a, st);
-            case 34: return launch_gemm16<256, 160, 8, 1, 1, 3, false, true>(&a, st);
+            // 256 x 160: the eight waves as 4 x 2 (64 x 80 per wave: 18 fragment reads per K step instead of 24 for 8 x 1).  Same tile,
+            // same K order: outputs bitwise equal; +3..5 % on the large convolutions (profiles/r04/micro_256x160_waves_*.log).
+            // knob 1 = 2 forces 8 x 1 (A/B runs)
+            case 34: return supir_debug_knob_value(1) != 2 ? launch_gemm16<256, 160, 4, 2, 1, 3, false, true>(&a, st)
+                                                           : launch_gemm16<256, 160, 8, 1, 1, 3, false, true>(&a, st);
             case 38: return launch_gemm16<128, 80, 4, 1, 1, 3, false, true>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
@@ -745,7 +749,13 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
         case 38: return t ? launch_gemm16<128, 80, 4, 1, 1, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 1, 3, false>(&a, st);
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);
-        case 34: return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true>(&a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false>(&a, st);
+        case 34:
+            // knob 1 (tools only): the 256 x 160 tile with its eight waves as 4 x 2 (64 x 80 per wave: 18 fragment reads per K step
+            // instead of 24) -- not for GEGLU (value / gate pairs need an even number of column fragments per wave)
+            // default (knob 1 = 0): 4 x 2 for M >= 8192 (measured +2..4 % there, equal below); 1 forces 4 x 2, 2 forces 8 x 1
+            if (a.act != 2 && (supir_debug_knob_value(1) == 1 || (supir_debug_knob_value(1) == 0 && a.M >= 8192)))
+                return t ? launch_gemm16<256, 160, 4, 2, 1, 3, true>(&a, st) : launch_gemm16<256, 160, 4, 2, 1, 3, false>(&a, st);
+            return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true>(&a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false>(&a, st);
         default: return t ? launch_gemm16<128, 80, 4, 1, 2, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 3, false>(&a, st);
     }
 }
@@ -787,6 +797,7 @@ static int g16_qkv_check(const GemmArgs& a) {
 int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st) {
     const int rc = g16_qkv_check(a);
     if (rc != SUPIR_OK) return rc;
+    if (supir_debug_knob_value(1)) return launch_gemm16<256, 160, 4, 2, 1, 3, false, false, true>(&a, st);
     return launch_gemm16<256, 160, 8, 1, 1, 3, false, false, true>(&a, st);
 }
 

@@ -111,6 +111,8 @@ int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st);
 // gemm_big.hip: tile 37 = 256 x 320, activation operand global -> VGPR, GEGLU epilogue (16-row value / gate interleave)
 // measurement knobs (NOT part of the C ABI: undeclared in include/supir_hip.h, used by tools/ A/B scripts only).
 // knob 0: 1 = the exact-erf GELU in the 256 x 320 GEGLU tile's epilogue instead of the fitted one (csrc/gemm_big.hip)
+// knob 1: wave arrangement of the 256 x 160 tile (csrc/gemm16.hip): 0 = product policy, 1 = always 4 x 2, 2 = always 8 x 1
+// knob 2: GroupNorm apply with n row batches per workgroup instead of ~32 KB per workgroup (measured: no gain; csrc/norm.hip)
 int supir_debug_knob_value(int which);
 bool supir_gemm_big_supported(const GemmArgs& a);
 int supir_gemm_big_launch(const GemmArgs& a, hipStream_t st);

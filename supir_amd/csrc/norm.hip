@@ -344,19 +344,23 @@ static int gn_launch(const GnArgs* a_in, hipStream_t st) {
         const size_t smem_stats = (size_t)TY * a.C * 2 * sizeof(float);
         SUPIR_LAUNCH(gn_stats_kernel<NP>, dim3(a.nchunk, a.B, NP), dim3(256), smem_stats, st, pp);
     }
-    // apply: ~64 KB of bf16 per workgroup iteration, at least 2 waves of workgroups when there is enough work
-    long rows_target = (long)(32 * 1024) / (2L * a.C);
-    if (rows_target < 8) rows_target = 8;
-    int nca = (int)((a.HW + rows_target - 1) / rows_target);
-    if (nca > 2048) nca = 2048;
-    const int rpc = (a.HW + nca - 1) / nca;
-    nca = (a.HW + rpc - 1) / rpc;
     // cv x TY threads: every thread owns one 8-channel column; TY row slots so that the block has >= 256 threads where cv allows
     const int cv = a.C / 8;
     if (cv > 512) return SUPIR_ERR_SHAPE;
     int ty = (256 + cv - 1) / cv;
     if (ty > 512 / cv) ty = 512 / cv;
     if (ty < 1) ty = 1;
+    // apply: ~64 KB of bf16 per workgroup iteration, at least 2 waves of workgroups when there is enough work
+    long rows_target = (long)(32 * 1024) / (2L * a.C);
+    if (rows_target < 8) rows_target = 8;
+    // knob 2 (tools only): ONE row batch per workgroup (2 rows in flight per thread x TY row slots): a workgroup is a single
+    // load -> compute -> store round trip instead of 3-4 dependent ones, at the price of more workgroups re-reducing the statistics
+    if (supir_debug_knob_value(2)) rows_target = 2L * ty * supir_debug_knob_value(2);
+    int nca = (int)((a.HW + rows_target - 1) / rows_target);
+    if (nca > 2048 && !supir_debug_knob_value(2)) nca = 2048;
+    if (nca > 65535) nca = 65535;
+    const int rpc = (a.HW + nca - 1) / nca;
+    nca = (a.HW + rpc - 1) / rpc;
     for (int q = 1; q < NP; ++q)
         if ((pp.p[q].mod_g == nullptr) != (a.mod_g == nullptr)) return SUPIR_ERR_SHAPE;
     const char* gn_env = getenv("SUPIR_GN_APPLY");   // read per launch: tools flip it between the variants of an in-process A/B

@@ -22,6 +22,9 @@ from tests.helpers import build_unet, synth_tensor
 
 dev = "cuda"
 variants = sys.argv[1:] or ["base", "fastgelu", "t38", "t38k1280"]
+# further variants (round 4, second call): all on top of fastgelu
+#   w42     the 256 x 160 tile's eight waves as 4 x 2 (64 x 80 per wave) instead of 8 x 1 (32 x 160): debug knob 1
+#   gn1/gn2 GroupNorm apply with ONE / TWO row batches per workgroup (debug knob 2 = 1 / 2) instead of ~32 KB per workgroup
 wrap = build_unet(device=dev)
 B, lat = 2, 128
 x = synth_tensor("x", (B, 4, lat, lat)).to(dev)
@@ -49,6 +52,8 @@ def configure(v):
     ops._CHOICE.update(chosen)
     ops.G16_TILES = {32, 33, 34, 35}
     lib.supir_debug_knob(0, 1 if v == "base" else 0)
+    lib.supir_debug_knob(1, 1 if "w42" in v else 0)
+    lib.supir_debug_knob(2, 1 if "gn1" in v else 2 if "gn2" in v else 0)
     if v in ("t38", "t38k1280"):
         ops.G16_TILES = {32, 33, 34, 35, 38}
         n = 0
@@ -84,7 +89,8 @@ with torch.no_grad():
             outs[v] = o.clone()
             print(f"rep{rep} {v}: {ms:.3f} ms/step", flush=True)
     wrap.enable_graph(False)
-lib.supir_debug_knob(0, 0)
+for kn in range(3):
+    lib.supir_debug_knob(kn, 0)
 ref = outs[variants[0]]
 for v in variants[1:]:
     print(f"{v} vs {variants[0]}: rel-L2 {((outs[v] - ref).norm() / ref.norm()).item():.3e}")
