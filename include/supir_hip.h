@@ -155,7 +155,7 @@ int supir_conv3x3_bf16_ex(const void* X, const void* W, void* Y, int B, int H, i
 
 /* softmax(Q K^T * scale) V for head dim 64.  Q:[B][Tq][ldq], K:[B][Tk][ldk] with head h at columns h*64..h*64+63;
  * Vt:[B][H*64][ldvt] is V transposed per batch (SUPIR_OUT_BF16_T output of the to_v projection), ldvt >= roundup(Tk,64),
- * padding finite; O:[B][Tq][ldo].
+ * padding finite; O:[B][Tq][ldo] (ldo % 8 == 0 and a 16-byte aligned O take the row-contiguous 16-byte store path; ldo % 4 is accepted).
  * Replaces xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention at
  *   sgm/modules/attention.py:273-277, 357-359 and SUPIR/modules/SUPIR_v0.py:146. */
 int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,

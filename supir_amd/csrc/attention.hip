@@ -59,8 +59,10 @@ __device__ __forceinline__ float xhalf_max(float x) {
 
 // NP = 2 (supir_flash_attn_d64_grouped): two independent attention problems in one grid, problem q on XCDs [4 q, 4 q + 4): at 1024
 // tokens a problem is 320 workgroups on 256 CUs -- 1.25 rounds; two of them back to back fill 2.5 rounds instead of 2 x 2.
-template <int S, int NW, bool PRE, int NP = 1>
-__global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgsN<NP> pp) {
+// R4 (round 4, the default): no tile loads past the last tile, and the output staged through LDS for row-contiguous 16-byte stores;
+// R4 = false is the round-3 kernel, kept selectable for A/B runs (tools-only knob 3).
+template <int S, int NW, bool PRE, int NP = 1, bool R4 = true>
+__global__ __launch_bounds__(64 * NW, 3) void attn_d64_pipe_kernel(const AttnArgsN<NP> pp) {
     static_assert(S >= 3, "tile t+1 is read while tile t is live and tile t+2 is in flight");
     __shared__ __attribute__((aligned(16))) char smem[S * 16384];
     constexpr int NX = 8 / NP;
@@ -110,7 +112,11 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgsN<
     }
     const size_t k_tile_bytes = (size_t)64 * p.ldk * 2;
     auto stage_one = [&](int t, int soff, int i) {   // soff = ring slot of tile t, in bytes
-        const int tc = t < nt - 1 ? t : nt - 1;   // past the end: reload the last tile into a ring slot nobody reads any more
+        // past the end: nothing to load.  (Until round 4 the last tile was re-loaded into a ring slot nobody reads, to keep the number
+        // of loads in flight per iteration uniform -- but with S = 3 every tile start waits for vmcnt(0) anyway, so the reloads only
+        // cost 2 x 16 KB of L2 -> LDS traffic per workgroup and a drain at the end: 25 % of the loads of a 77-key launch.)
+        if (R4 && S == 3 && t >= nt) return;
+        const int tc = t < nt - 1 ? t : nt - 1;   // (S > 3, counted waits: reload the last tile into a ring slot nobody reads any more)
         char* sK = smem + soff;
         char* sV = sK + 8192;
         if (i < LPT) {
@@ -325,12 +331,32 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgsN<
     for (; t < n_plain; ++t) tile(t, attn_flag<false>{});
     for (; t < nt; ++t) tile(t, attn_flag<true>{});
     ATL(tl_loop1);
-    attn_wait_vmcnt<0>();   // the reloads issued by the last S-1 iterations still target this workgroup's LDS
+    attn_wait_vmcnt<0>();   // (S > 3 only: reloads issued by the last iterations still target this workgroup's LDS)
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q_ok) {
-        bf16_t* Op = p.O + ((size_t)b * p.Tq + q) * p.ldo + h * 64;
+    if constexpr (!R4) {
+        if (q_ok) {
+            bf16_t* Op = p.O + ((size_t)b * p.Tq + q) * p.ldo + h * 64;
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    u16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[df][rg * 4 + e] * inv);
+                    *(u16x4*)(Op + df * 32 + 8 * rg + 4 * half) = ov;
+                }
+        }
+    } else {
+        // O^T fragments -> this wave's 32 x 64 bf16 block, staged through LDS (row stride 144 B: conflict-free 8-byte writes and
+        // 16-byte reads), then stored as whole 128-byte rows: 8 lanes x 16 B cover one query's head slice, 4 store instructions per
+        // lane instead of 8 eight-byte stores scattered over 32 rows each (the store tail was issue-bound: 3.4 k cycles per wave at
+        // Tk = 77, half of the kernel's time there).  The ring is free: every wave has passed its last tile's reads (barrier).
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        constexpr int ORS = 144;
+        char* o_stage = smem + wave * (32 * ORS);
 #pragma unroll
         for (int df = 0; df < 2; ++df)
 #pragma unroll
@@ -338,8 +364,21 @@ __global__ __launch_bounds__(64 * NW) void attn_d64_pipe_kernel(const AttnArgsN<
                 u16x4 ov;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[df][rg * 4 + e] * inv);
-                *(u16x4*)(Op + df * 32 + 8 * rg + 4 * half) = ov;
+                *(u16x4*)(o_stage + l31 * ORS + (df * 32 + 8 * rg + 4 * half) * 2) = ov;
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private block: no barrier needed
+        {
+            const int q0 = qb * QB + wave * 32;
+            bf16_t* Ob = p.O + ((size_t)b * p.Tq + q0) * p.ldo + h * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                if (q0 + row < p.Tq) {
+                    const f32x4 piece = *(const f32x4*)(o_stage + row * ORS + ch * 16);
+                    *(f32x4*)(Ob + (size_t)row * p.ldo + ch * 8) = piece;
+                }
+            }
+        }
     }
 #ifdef SUPIR_ATTN_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -373,7 +412,13 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
     // profiles/r02/attn_pipelined_network_parity_and_step.log)
     AttnArgsN<1> pp;
     pp.p[0] = a;
-    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1>), dim3(((a.Tq + 127) / 128) * a.H * a.B), dim3(256), 0, st, pp);
+    const dim3 grid(((a.Tq + 127) / 128) * a.H * a.B);
+    // round-4 form needs 16-byte aligned output rows; anything else (and tools-only knob 3) runs the round-3 form
+    if (supir_debug_knob_value(3) || a.ldo % 8 != 0 || (((size_t)a.O) & 15) != 0) {
+        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, false>), grid, dim3(256), 0, st, pp);
+    } else {
+        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, true>), grid, dim3(256), 0, st, pp);
+    }
     return SUPIR_LAUNCH_STATUS();
 }
 
@@ -389,7 +434,7 @@ int supir_attn_launch_n(const AttnArgs* a, int n, hipStream_t st) {
     }
     if (a[0].B != a[1].B || a[0].H != a[1].H || a[0].Tq != a[1].Tq) return SUPIR_ERR_SHAPE;
     const int nwg = ((a[0].Tq + 127) / 128) * a[0].H * a[0].B;
-    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 2>), dim3(8 * ((nwg + 3) / 4)), dim3(256), 0, st, pp);
+    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 2, false>), dim3(8 * ((nwg + 3) / 4)), dim3(256), 0, st, pp);
     return SUPIR_LAUNCH_STATUS();
 }
 

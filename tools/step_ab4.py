@@ -54,6 +54,7 @@ def configure(v):
     lib.supir_debug_knob(0, 1 if v == "base" else 0)
     lib.supir_debug_knob(1, 1 if "w42" in v else 0)
     lib.supir_debug_knob(2, 1 if "gn1" in v else 2 if "gn2" in v else 0)
+    lib.supir_debug_knob(3, 1 if "attn3" in v else 0)      # attn3: the round-3 flash-attention kernel
     if v in ("t38", "t38k1280"):
         ops.G16_TILES = {32, 33, 34, 35, 38}
         n = 0
@@ -89,7 +90,7 @@ with torch.no_grad():
             outs[v] = o.clone()
             print(f"rep{rep} {v}: {ms:.3f} ms/step", flush=True)
     wrap.enable_graph(False)
-for kn in range(3):
+for kn in range(4):
     lib.supir_debug_knob(kn, 0)
 ref = outs[variants[0]]
 for v in variants[1:]:
