@@ -481,6 +481,23 @@ def main():
             torch.cuda.synchronize()
         ms_unet = e0.elapsed_time(e1) / 10
         extra["ms_per_unet_step"] = ms_unet
+        # the same call as a step of the sampler issues it since round 4: time / label embeddings gathered from the per-image table
+        # (ControlWrapper.prepare_schedule) instead of recomputed at the head of both chains
+        if hasattr(model.model, "prepare_schedule"):
+            with torch.no_grad():
+                model.model.prepare_schedule([500], cond["vector"])
+                for _ in range(3):
+                    model.model.select_step(0)
+                    model.model(xx, tt, cond, 1.0)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    model.model.select_step(0)
+                    model.model(xx, tt, cond, 1.0)
+                e1.record()
+                torch.cuda.synchronize()
+                model.model.end_schedule()
+            extra["ms_per_unet_step_inside_the_sampler"] = e0.elapsed_time(e1) / 10
         extra["unet_step_tflops"] = UNET_STEP_TFLOP.get(lat, 0) / (ms_unet * 1e-3) if lat in UNET_STEP_TFLOP else None
 
     roofline, breakdown = None, None

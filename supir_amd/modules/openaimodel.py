@@ -200,30 +200,71 @@ class UNetModel(nn.Module):
             self.out = nn.Sequential(GroupNorm32(ch), Passthrough(), Conv3x3(model_channels, out_channels))
         object.__setattr__(self, "_emb_w", Prep())
         object.__setattr__(self, "_label_cache", None)
+        object.__setattr__(self, "_schedule", None)
 
     # ------------------------------------------------------------------ embeddings
     def _res_blocks(self):
         return [m for m in self.modules() if isinstance(m, ResBlock)]
 
-    def _embed(self, timesteps, y):
-        """emb = time_embed(t_emb) + label_emb(y); then ONE GEMM projects SiLU(emb) for every ResBlock
-        (reference: per-block emb_layers Linear, openaimodel.py:287-293,343)."""
-        te = timestep_embedding(timesteps, self.model_channels).to(cdt())
-        l0, l2 = self.time_embed[0], self.time_embed[2]
-        emb = ops.gemm(ops.gemm(te, l0.w(), l0.b32(), act=1), l2.w(), l2.b32(), out_dtype=torch.float32)
-        emb = emb + self._label(y)
+    def _emb_project(self, emb):
+        """ONE GEMM projects SiLU(emb) [rows, 1280] for every ResBlock (reference: per-block emb_layers Linear,
+        openaimodel.py:287-293,343): returns (proj_all [rows, sum(Cout)], blocks, widths)."""
         blocks = self._res_blocks()
         srcs = [p for b in blocks for p in (b.emb_layers[1].weight, b.emb_layers[1].bias)]
         w_all, b_all, offs = self._emb_w.get(srcs, lambda: (
             torch.cat([Wt.linear_w(b.emb_layers[1].weight) for b in blocks], 0).contiguous(),
             torch.cat([Wt.f32(b.emb_layers[1].bias) for b in blocks], 0).contiguous(),
             [b.out_channels for b in blocks]))
-        proj_all = ops.gemm(torch.nn.functional.silu(emb).to(cdt()), w_all, b_all)
+        return ops.gemm(torch.nn.functional.silu(emb).to(cdt()), w_all, b_all), blocks, offs
+
+    def _time_emb(self, timesteps):
+        te = timestep_embedding(timesteps, self.model_channels).to(cdt())
+        l0, l2 = self.time_embed[0], self.time_embed[2]
+        return ops.gemm(ops.gemm(te, l0.w(), l0.b32(), act=1), l2.w(), l2.b32(), out_dtype=torch.float32)
+
+    def _embed(self, timesteps, y):
+        """emb = time_embed(t_emb) + label_emb(y), projected for every ResBlock.  With a prepared schedule (prepare_schedule: the
+        sampler knows all of an image's timesteps in advance) the whole thing is ONE row gather out of a per-image table."""
+        sch = self._schedule
+        if sch is not None and sch["active"] and sch["B"] == y.shape[0] and sch["cdt"] == cdt():
+            proj_all = sch["proj"].index_select(0, sch["row"])[0]              # [B, sum(Cout)]
+            raw = sch["raw"].index_select(0, sch["row"])[0]
+            blocks, offs = sch["blocks"], sch["offs"]
+        else:
+            emb = self._time_emb(timesteps) + self._label(y)
+            proj_all, blocks, offs = self._emb_project(emb)
+            raw = emb.to(cdt())
         proj, o = {}, 0
         for b, n in zip(blocks, offs):
             proj[id(b)] = proj_all[:, o:o + n]
             o += n
-        return EmbBundle(emb.to(cdt()), proj)
+        return EmbBundle(raw, proj)
+
+    def prepare_schedule(self, t_values, y, row):
+        """All of one image's timestep embeddings at once (the sigma schedule is known on the host before the loop starts):
+        time_embed for the n distinct timesteps, + label_emb(y), SiLU, the all-ResBlocks projection -- three GEMMs with M = n and
+        M = n B rows per image instead of three M = B GEMVs and a dozen elementwise launches at the head of EVERY step (they sit on
+        the critical path of both chains: nothing else can run until the first ResBlock has its row bias).  `row` = a device
+        int64 [1] owned by the caller that selects the step; tables live in persistent buffers refreshed in place (captured
+        graphs keep pointing at them).  Same arithmetic, same K order: bitwise the per-step values."""
+        n, B = len(t_values), y.shape[0]
+        t = torch.tensor(list(t_values), dtype=torch.int64, device=y.device)
+        emb = self._time_emb(t)[:, None, :] + self._label(y)[None, :, :]             # [n, B, 1280] fp32
+        proj_all, blocks, offs = self._emb_project(emb.reshape(n * B, -1))
+        sch = self._schedule
+        if sch is None or sch["proj"].shape != (n, B, proj_all.shape[-1]) or sch["cdt"] != cdt() or sch["proj"].device != y.device:
+            sch = dict(proj=torch.empty(n, B, proj_all.shape[-1], dtype=cdt(), device=y.device),
+                       raw=torch.empty(n, B, emb.shape[-1], dtype=cdt(), device=y.device), version=0)
+            sch["version"] = (self._schedule["version"] + 1) if self._schedule is not None else 1
+        sch["proj"].copy_(proj_all.view(n, B, -1))
+        sch["raw"].copy_(emb.to(cdt()))
+        sch.update(row=row, blocks=blocks, offs=offs, B=B, cdt=cdt(), active=True, t_values=tuple(int(v) for v in t_values))
+        object.__setattr__(self, "_schedule", sch)
+        return sch["version"]
+
+    def end_schedule(self):
+        if self._schedule is not None:
+            self._schedule["active"] = False
 
     def _label(self, y):
         """label_emb(y): constant over the sampling loop -> cached per y-shape on tensor identity/version and refreshed in

@@ -17,6 +17,9 @@ SIGMA_MAX = 14.6146
 # RestoreEDMSampler: run the elementwise halves of a step as two fused kernels (csrc/sampler.hip) with host-side scalars when the
 # caller exposes its denoiser / network (SUPIRModel.batchify_sample does); off -> the generic torch-op path for every caller
 FUSED_EDM_STEP = os.environ.get("SUPIR_FUSED_EDM_STEP", "1") == "1"
+# with the fused step: the network prepares the time / label embeddings of ALL steps of an image before the loop
+# (ControlWrapper.prepare_schedule) instead of recomputing them at the head of every step
+EMB_SCHEDULE = os.environ.get("SUPIR_EMB_SCHEDULE", "1") == "1"
 
 
 def append_dims(x, ndim):
@@ -264,7 +267,7 @@ class RestoreEDMSampler(BaseDiffusionSampler):
         return den, net
 
     def _fused_step(self, ctx, sigma_f, next_sigma_f, x, gamma, x_center, eps_noise, control_scale, use_linear_control_scale,
-                    control_scale_start, cond_cat):
+                    control_scale_start, cond_cat, sched_row=None):
         """sampler_step (sampling.py:548-570) with every sigma-derived factor evaluated on the host in fp32, in the reference's
         operation order, and the tensor work in supir_edm_step_pre / _post.  Same RNG consumption as the generic path."""
         from .. import ops
@@ -283,6 +286,8 @@ class RestoreEDMSampler(BaseDiffusionSampler):
         reps = 2 if twice else 1
         x = x if x.is_contiguous() else x.contiguous()
         x_hat, net_in = ops.edm_step_pre(x, None if eps is None else eps.float().contiguous(), self.s_noise, noise_mul, c_in, reps)
+        if sched_row is not None:
+            net.select_step(sched_row, idx)     # this call's timestep embeddings come out of the per-image table (ControlWrapper.prepare_schedule)
         out = net(net_in, den.idx_tensor(idx, net_in.shape[0], x.device), cond_cat, control_scale)
         cfg = 0.0
         if twice:
@@ -301,12 +306,26 @@ class RestoreEDMSampler(BaseDiffusionSampler):
         cond_cat = self.guider.prepare_cond(cond, uc)            # constant over the loop: concat once
         inject = self.__dict__.pop("injected_step_noises", None)  # parity runs: the churn noise of every step, given
         ctx = self._fused_ctx(denoiser, x) if type(self).sampler_step is RestoreEDMSampler.sampler_step else None
-        for i in range(num_sigmas - 1):
-            if ctx is not None:
+        sched = False
+        if ctx is not None and EMB_SCHEDULE and hasattr(ctx[1], "prepare_schedule") and "vector" in cond_cat:
+            # every step's timestep (table index) is known now: let the network prepare all its time / label embeddings at once
+            f32 = np.float32
+            t_all = [ctx[0].host_scalars(f32(sf[i]) * f32(self._gamma(sf[i], num_sigmas) + 1.0))[0] for i in range(num_sigmas - 1)]
+            ctx[1].prepare_schedule(t_all, cond_cat["vector"])
+            sched = True
+        try:
+            for i in range(num_sigmas - 1):
+                if ctx is None:
+                    break
                 x = self._fused_step(ctx, sf[i], sf[i + 1], x, self._gamma(sf[i], num_sigmas), x_center,
                                      None if inject is None else inject[i].to(x), control_scale, use_linear_control_scale,
-                                     control_scale_start, cond_cat)
-                continue
+                                     control_scale_start, cond_cat, sched_row=i if sched else None)
+        finally:
+            if sched:
+                ctx[1].end_schedule()
+        if ctx is not None:
+            return x
+        for i in range(num_sigmas - 1):
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, self._gamma(sf[i], num_sigmas),
                                   x_center, eps_noise=None if inject is None else inject[i].to(x), control_scale=control_scale, use_linear_control_scale=use_linear_control_scale,
                                   control_scale_start=control_scale_start, cond_cat=cond_cat, sigma_f=sf[i],

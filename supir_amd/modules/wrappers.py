@@ -73,6 +73,11 @@ class ControlWrapper(nn.Module):
         self._warm = False
         self._dtype_noted = None   # the dtype request _note_dtype last reported on
         self._last_cdt = None
+        # per-image timestep-embedding schedule (prepare_schedule / select_step): row selector shared by both networks
+        self._emb_row = None
+        self._emb_rows = None
+        self._sched = None
+        self._sched_armed = False
 
     @property
     def effective_dtype(self):
@@ -81,6 +86,52 @@ class ControlWrapper(nn.Module):
 
     def load_control_model(self, control_model):
         self.control_model = control_model
+
+    # ------------------------------------------------------------------ per-image embedding schedule
+    def prepare_schedule(self, t_values, vector):
+        """Called by a sampler that knows every timestep (table index) of the image it is about to sample: both networks build
+        their time + label embedding projections for ALL steps now (openaimodel.UNetModel.prepare_schedule: three GEMMs per
+        network per image) instead of three M = B GEMVs and ~12 elementwise launches at the head of every step.  A step then
+        announces itself with select_step(i) right before its forward call; a forward call that was not announced takes the normal
+        path, so callers that know nothing about schedules are unaffected.  `vector` must be the tensor the calls will pass as
+        c["vector"]."""
+        with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
+            if self._emb_row is None or self._emb_row.device != vector.device:
+                self._emb_row = torch.zeros(1, dtype=torch.int64, device=vector.device)
+                self._emb_rows = torch.arange(1024, dtype=torch.int64, device=vector.device)
+            assert len(t_values) <= self._emb_rows.numel()
+            v1 = self.control_model.prepare_schedule(t_values, vector, self._emb_row)
+            v2 = self.diffusion_model.prepare_schedule(t_values, vector, self._emb_row)
+            self.control_model.end_schedule()       # inactive until a step announces itself
+            self.diffusion_model.end_schedule()
+        self._sched = (len(t_values), v1, v2, self.effective_dtype, tuple(int(v) for v in t_values))
+        self._sched_armed = False
+
+    def select_step(self, i, expect_t=None):
+        """The NEXT forward call is step `i` of the prepared schedule; its `t` must be the schedule's i-th timestep (`expect_t`, when
+        given, is checked against it on the host)."""
+        if self._sched is None or not (0 <= i < self._sched[0]):
+            raise IndexError("select_step without a prepared schedule / out of range")
+        if expect_t is not None and int(expect_t) != self._sched[4][i]:
+            raise ValueError(f"step {i} of the prepared schedule is timestep {self._sched[4][i]}, the call is for {int(expect_t)}")
+        self._emb_row.copy_(self._emb_rows[i:i + 1])
+        self._sched_armed = True
+
+    def end_schedule(self):
+        self._sched, self._sched_armed = None, False
+        for m in (self.control_model, self.diffusion_model):
+            if m is not None and hasattr(m, "end_schedule"):
+                m.end_schedule()
+
+    def _use_schedule(self, kwargs):
+        """Consume the one-call announcement; switch both networks' tables on / off for this call."""
+        use = self._sched is not None and self._sched_armed and not kwargs and self._sched[3] == self.effective_dtype
+        self._sched_armed = False
+        for m in (self.control_model, self.diffusion_model):
+            sch = getattr(m, "_schedule", None)
+            if sch is not None:
+                sch["active"] = bool(use)
+        return use
 
     # ------------------------------------------------------------------ eager
     def _forward_eager(self, x, t, c, control_scale, **kwargs):
@@ -151,16 +202,18 @@ class ControlWrapper(nn.Module):
             self._graphs.clear()
             self._cs_miss.clear()
 
-    def _forward_graph(self, x, t, c, control_scale):
+    def _forward_graph(self, x, t, c, control_scale, sched=False):
         ctx, vec, ctl = c["crossattn"], c["vector"], c["control"]
-        key = (tuple(x.shape), float(control_scale), tuple(ctx.shape), tuple(vec.shape), Wt.cdt())
+        # a step of a prepared embedding schedule reads its embeddings out of the per-image tables (other launches than a plain
+        # call): its own graph, valid as long as the tables are the same buffers (version)
+        key = (tuple(x.shape), float(control_scale), tuple(ctx.shape), tuple(vec.shape), Wt.cdt()) + ((self._sched[1:3],) if sched else ())
         g = self._graphs.get(key)
         if g is None:
             # control_scale is a launch argument baked into the captured kernels.  With use_linear_control_scale
             # (sampling.py:557-559) it changes on every step: capturing a graph per value would cost three network calls per
             # step, so after two CONSECUTIVE misses for a shape such calls run eagerly.  A hit resets the streak, so a new
             # constant scale on a later image (1.0, then 0.9, then 0.8 ...) still gets its graph.
-            skey = (key[0], key[2], key[3], key[4])
+            skey = (key[0], key[2], key[3], key[4]) + key[5:]
             self._cs_miss[skey] = self._cs_miss.get(skey, 0) + 1
             if self._cs_miss[skey] > 2:
                 return self._forward_eager(x, t, c, control_scale)
@@ -193,7 +246,7 @@ class ControlWrapper(nn.Module):
             g = [graph, sx, st, sc, out]
             self._graphs[key] = g
         else:
-            self._cs_miss[(key[0], key[2], key[3], key[4])] = 0
+            self._cs_miss[(key[0], key[2], key[3], key[4]) + key[5:]] = 0
         graph, sx, st, sc, out = g[:5]
         rkey = (key[2], key[3], key[4])
         res = self._resident.get(rkey)
@@ -234,7 +287,8 @@ class ControlWrapper(nn.Module):
             self._cs_miss.clear()
             self._resident.clear()
             self._last_cdt = self.effective_dtype
+        sched = self._use_schedule(kwargs)
         with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
             if self._graph_on and not kwargs and x.is_cuda:
-                return self._forward_graph(x, t, c, control_scale)
+                return self._forward_graph(x, t, c, control_scale, sched)
             return self._forward_eager(x, t, c, control_scale, **kwargs)

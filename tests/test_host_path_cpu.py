@@ -114,6 +114,36 @@ def test_unfolded_transformer_path_matches_the_folded_one(wrap):
     assert rel_l2(a, b) <= TOL
 
 
+def test_embedding_schedule_serves_announced_calls_only(wrap):
+    """ControlWrapper.prepare_schedule / select_step (round 4): a sampler that knows all timesteps of an image lets both networks
+    build their time / label embedding projections for every step at once; an announced call reads its row out of that table and
+    must equal the plain call, an un-announced call takes the plain path, a mismatching announcement is an error."""
+    x, _, cond = _wrapper_inputs()
+    t = torch.tensor([500, 500], dtype=torch.int64)
+    with torch.no_grad():
+        plain = wrap(x, t, cond, 1.0).clone()
+        wrap.prepare_schedule([7, 500, 901], cond["vector"])
+        try:
+            assert wrap.diffusion_model._schedule["active"] is False
+            wrap.select_step(1, expect_t=500)
+            announced = wrap(x, t, cond, 1.0).clone()
+            assert wrap.diffusion_model._schedule["active"] is True and not wrap._sched_armed      # consumed by that one call
+            again = wrap(x, t, cond, 1.0).clone()                                                     # not announced: plain path
+            assert wrap.diffusion_model._schedule["active"] is False
+            wrap.select_step(2)
+            other = wrap(x, torch.tensor([901, 901]), cond, 1.0).clone()
+            with pytest.raises(ValueError):
+                wrap.select_step(0, expect_t=500)
+            with pytest.raises(IndexError):
+                wrap.select_step(3)
+        finally:
+            wrap.end_schedule()
+        ref_other = wrap(x, torch.tensor([901, 901]), cond, 1.0)
+    assert rel_l2(announced, plain) <= 1e-6 and torch.equal(again, plain) and rel_l2(other, ref_other) <= 1e-6
+    assert rel_l2(other, plain) > 1e-3          # another timestep really is another result
+    assert wrap._sched is None
+
+
 def test_sampler_2step_vs_reference_golden(wrap):
     from supir_amd.modules.sampling import DiscreteDenoiserWithControl, LinearCFG, RestoreEDMSampler
     _, _, cond = _wrapper_inputs()

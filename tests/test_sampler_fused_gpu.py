@@ -101,3 +101,51 @@ def test_sampler_fused_step_vs_generic_step_with_the_real_network(monkeypatch):
         print(f"[fused step] free-running {steps} steps, fused vs generic: rel-L2 {e:.3e}")
         assert e <= 1e-2, e
         assert torch.equal(outs[1], outs[3])      # both paths drew the same number of random values
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_embedding_schedule_is_bitwise_the_per_step_embeddings(monkeypatch, graph):
+    """Round 4: with the fused step the sampler hands all of an image's timesteps to the network up front
+    (ControlWrapper.prepare_schedule: time + label embeddings of every step from three GEMMs per network per image); each step then
+    gathers its row instead of recomputing ~15 launches at the head of both chains.  Same arithmetic, same K order: the sampled
+    latent must be BITWISE what the per-step path gives -- eagerly and under hipGraph replay, for two consecutive images with
+    different prompts (the tables are persistent buffers refreshed in place; the captured graph must see the new contents)."""
+    from supir_amd.modules import sampling
+    from supir_amd.modules.sampling import DiscreteDenoiserWithControl, LinearCFG, RestoreEDMSampler
+    mini = build_unet(depth=(1, 1, 2), device=DEV)
+    den = DiscreteDenoiserWithControl().to(DEV)
+    h = w = 32
+    lq, xc = T("lq_tiled", (1, 4, h, w)), T("fs.center", (1, 4, h, w))
+
+    def denoiser(i, s, cc, cs):
+        return den(mini, i, s, cc, cs)
+
+    denoiser.fused = (den, mini)
+    monkeypatch.setattr(sampling, "FUSED_EDM_STEP", True)
+    smp = RestoreEDMSampler(num_steps=5, s_churn=5, s_noise=1.01, restore_cfg=4.0, guider_config=LinearCFG(1.0, 4.0), device=DEV)
+    res = {}
+    for sched in (False, True):
+        monkeypatch.setattr(sampling, "EMB_SCHEDULE", sched)
+        mini.enable_graph(graph)
+        outs = []
+        try:
+            for img in range(2):
+                ctx, y = T(f"context{img}", (2, 77, 2048)), T(f"vector{img}", (2, 2816))
+                c = {"crossattn": ctx[:1], "vector": y[:1], "control": lq}
+                uc = {"crossattn": ctx[1:], "vector": y[1:], "control": lq}
+                torch.manual_seed(99 + img)
+                with torch.no_grad():
+                    outs.append(smp(denoiser, T("fs.x0", (1, 4, h, w)).clone(), cond=c, uc=uc, x_center=xc).float().clone())
+        finally:
+            mini.enable_graph(False)
+        res[sched] = outs
+        assert mini._sched is None                      # the schedule ends with the sampling loop
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[True][0], res[True][1])
+    # and a plain call after the loop is served by the normal path
+    x = T("fs.x0", (2, 4, h, w))
+    cond = {"crossattn": T("context0", (2, 77, 2048)), "vector": T("vector0", (2, 2816)), "control": torch.cat([lq, lq])}
+    t = torch.tensor([500, 37], dtype=torch.int64, device=DEV)
+    with torch.no_grad():
+        assert torch.equal(mini(x, t, cond, 1.0), mini(x, t, cond, 1.0))
