@@ -311,7 +311,7 @@ class RestoreEDMSampler(BaseDiffusionSampler):
             # every step's timestep (table index) is known now: let the network prepare all its time / label embeddings at once
             f32 = np.float32
             t_all = [ctx[0].host_scalars(f32(sf[i]) * f32(self._gamma(sf[i], num_sigmas) + 1.0))[0] for i in range(num_sigmas - 1)]
-            ctx[1].prepare_schedule(t_all, cond_cat["vector"])
+            ctx[1].prepare_schedule(t_all, cond_cat["vector"], control=cond_cat.get("control"))
             sched = True
         try:
             for i in range(num_sigmas - 1):

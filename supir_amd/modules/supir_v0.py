@@ -111,13 +111,38 @@ class GLVControl(UNetModel):
         self.input_upscale = input_upscale
         self.input_hint_block = TimestepEmbedSequential(Conv3x3(self.in_channels, self.model_channels))
 
+    def _guided_hint(self, x, out=None):
+        hint = self.input_hint_block[0]
+        return ops.conv3x3_smallcin(x.float(), hint.wf32(), hint.b32(), dtype=cdt(), out=out)
+
     def prologue(self, x, timesteps, xt, y=None):
         """Embeddings + the two <= 8-channel input convolutions: (emb, h0).  Kept apart from `body` because it mixes torch
         elementwise ops with kernel launches (it cannot be recorded by ops.paired_run)."""
         emb = self._embed(timesteps, y)
-        hint = self.input_hint_block[0]
-        guided_hint = ops.conv3x3_smallcin(x.float(), hint.wf32(), hint.b32(), dtype=cdt())
+        sch = self._schedule
+        if sch is not None and sch["active"] and sch.get("hint") is not None and sch["hint"].shape[0] == x.shape[0]:
+            guided_hint = sch["hint"]          # input_hint_block(LQ latent): the same every step of an image (prepare_schedule)
+        else:
+            guided_hint = self._guided_hint(x)
         return emb, self._conv_in(xt, add=guided_hint)          # input_blocks[0](xt) + guided_hint in one kernel
+
+    def prepare_schedule(self, t_values, y, row, control=None):
+        """UNetModel.prepare_schedule + the control branch's own step-invariant: guided_hint = input_hint_block(x) depends on the LQ
+        latent only (SUPIR_v0.py:504-505), which a sampler passes unchanged to every step of an image -- computed once per image
+        into a persistent buffer (refreshed in place: captured graphs point at it) instead of once per step at the head of the
+        control chain."""
+        ver = super().prepare_schedule(t_values, y, row)
+        sch = self._schedule
+        if control is not None:
+            old = sch.get("hint")
+            shape = (control.shape[0], control.shape[2], control.shape[3], self.model_channels)
+            if old is None or tuple(old.shape) != shape or old.dtype != cdt() or old.device != control.device:
+                old = torch.empty(shape, dtype=cdt(), device=control.device)
+                sch["version"] = ver = sch["version"] + 1
+            sch["hint"] = self._guided_hint(control, out=old)
+        else:
+            sch["hint"] = None
+        return ver
 
     def body(self, h, emb, context=None):
         """input_blocks[1:] + middle_block on h0: the 10 feature maps.  The same stack of layers, shape for shape, as

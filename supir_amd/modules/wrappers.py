@@ -88,19 +88,20 @@ class ControlWrapper(nn.Module):
         self.control_model = control_model
 
     # ------------------------------------------------------------------ per-image embedding schedule
-    def prepare_schedule(self, t_values, vector):
+    def prepare_schedule(self, t_values, vector, control=None):
         """Called by a sampler that knows every timestep (table index) of the image it is about to sample: both networks build
         their time + label embedding projections for ALL steps now (openaimodel.UNetModel.prepare_schedule: three GEMMs per
         network per image) instead of three M = B GEMVs and ~12 elementwise launches at the head of every step.  A step then
         announces itself with select_step(i) right before its forward call; a forward call that was not announced takes the normal
         path, so callers that know nothing about schedules are unaffected.  `vector` must be the tensor the calls will pass as
-        c["vector"]."""
+        c["vector"]; `control` (optional) the CFG-doubled LQ latent the calls will pass as c["control"]: the control branch's
+        input_hint_block convolution of it is step-invariant too and is then computed once per image as well."""
         with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
             if self._emb_row is None or self._emb_row.device != vector.device:
                 self._emb_row = torch.zeros(1, dtype=torch.int64, device=vector.device)
                 self._emb_rows = torch.arange(1024, dtype=torch.int64, device=vector.device)
             assert len(t_values) <= self._emb_rows.numel()
-            v1 = self.control_model.prepare_schedule(t_values, vector, self._emb_row)
+            v1 = self.control_model.prepare_schedule(t_values, vector, self._emb_row, control=control)
             v2 = self.diffusion_model.prepare_schedule(t_values, vector, self._emb_row)
             self.control_model.end_schedule()       # inactive until a step announces itself
             self.diffusion_model.end_schedule()

@@ -122,7 +122,7 @@ def test_embedding_schedule_serves_announced_calls_only(wrap):
     t = torch.tensor([500, 500], dtype=torch.int64)
     with torch.no_grad():
         plain = wrap(x, t, cond, 1.0).clone()
-        wrap.prepare_schedule([7, 500, 901], cond["vector"])
+        wrap.prepare_schedule([7, 500, 901], cond["vector"], control=cond["control"])
         try:
             assert wrap.diffusion_model._schedule["active"] is False
             wrap.select_step(1, expect_t=500)
