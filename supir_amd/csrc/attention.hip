@@ -413,8 +413,21 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
     AttnArgsN<1> pp;
     pp.p[0] = a;
     const dim3 grid(((a.Tq + 127) / 128) * a.H * a.B);
-    // round-4 form needs 16-byte aligned output rows; anything else (and tools-only knob 3) runs the round-3 form
-    if (supir_debug_knob_value(3) || a.ldo % 8 != 0 || (((size_t)a.O) & 15) != 0) {
+    const bool aligned = a.ldo % 8 == 0 && (((size_t)a.O) & 15) == 0;
+    const int knob = supir_debug_knob_value(3);   // tools only: 1 = round-3 kernel, 2 = always eight waves, 3 = always four waves (round-4 form)
+    // EIGHT waves = 256 query rows per workgroup (two waves per SIMD on one K / V^T ring: half the global -> LDS instructions and
+    // bytes per wave, the two waves of a SIMD fill each other's issue gaps) where the whole launch is ONE round of such workgroups
+    // (<= 256: one per CU): (B2, H20, 1024^2) = 160 workgroups: 21.1 -> 19.8 us.  With more than one round the coarser grid loses
+    // ((B2, H10, 4096^2) = 320 workgroups of which a CU holds one: 100 -> 128 us): four waves there.  Both forms are bitwise equal
+    // (profiles/r04/micro_flash_attention_*.log).
+    const int nwg8 = ((a.Tq + 255) / 256) * a.H * a.B;
+    const bool eight = aligned && (knob == 2 || (knob == 0 && nwg8 <= 256 && a.Tq >= 256 && a.Tk >= 256 && !a.causal));
+    if (eight) {
+        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 8, true, 1, true>), dim3(nwg8), dim3(512), 0, st, pp);
+        return SUPIR_LAUNCH_STATUS();
+    }
+    // the round-4 epilogue needs 16-byte aligned output rows; anything else (and knob 3 = 1) runs the round-3 form
+    if (knob == 1 || !aligned) {
         SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, false>), grid, dim3(256), 0, st, pp);
     } else {
         SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, true>), grid, dim3(256), 0, st, pp);

@@ -113,7 +113,7 @@ int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st);
 // knob 0: 1 = the exact-erf GELU in the 256 x 320 GEGLU tile's epilogue instead of the fitted one (csrc/gemm_big.hip)
 // knob 1: wave arrangement of the 256 x 160 tile (csrc/gemm16.hip): 0 = product policy, 1 = always 4 x 2, 2 = always 8 x 1
 // knob 2: GroupNorm apply with n row batches per workgroup instead of ~32 KB per workgroup (measured: no gain; csrc/norm.hip)
-// knob 3: 1 = the round-3 flash-attention kernel (tile reloads past the end, per-lane 8-byte output stores)
+// knob 3: flash attention d64: 0 = product policy, 1 = the round-3 kernel, 2 = always eight waves, 3 = always four waves (round-4 form)
 int supir_debug_knob_value(int which);
 bool supir_gemm_big_supported(const GemmArgs& a);
 int supir_gemm_big_launch(const GemmArgs& a, hipStream_t st);

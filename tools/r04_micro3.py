@@ -44,7 +44,7 @@ for (B, H, Tq, Tk) in [(2, 20, 1024, 1024), (2, 10, 4096, 4096), (2, 20, 1024, 7
     row = {"B": B, "H": H, "Tq": Tq, "Tk": Tk}
     outs = {}
     for rep in range(2):
-        for knob, name in ((1, "r03"), (0, "r04")):
+        for knob, name in ((1, "r03"), (3, "r04"), (2, "r04_8waves")):
             lib.supir_debug_knob(3, knob)
             row.setdefault(f"{name}_us", []).append(round(timeit(lambda: ops.flash_attn(q, k, vt, B, H, Tq, Tk)), 2))
             outs[name] = ops.flash_attn(q, k, vt, B, H, Tq, Tk).clone()
@@ -56,7 +56,8 @@ for (B, H, Tq, Tk) in [(2, 20, 1024, 1024), (2, 10, 4096, 4096), (2, 20, 1024, 7
     ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).permute(0, 2, 1, 3).reshape(B, Tq, C)
     row["rel_l2_vs_fp32"] = ((outs["r04"].float() - ref).norm() / ref.norm()).item()
     fl = 4.0 * B * H * Tq * Tk * 64
-    row["tflops"] = [round(fl / min(row[f"{n}_us"]) / 1e6, 1) for n in ("r03", "r04")]
+    row["eight_waves_equal"] = bool(torch.equal(outs["r04"], outs["r04_8waves"]))
+    row["tflops"] = [round(fl / min(row[f"{n}_us"]) / 1e6, 1) for n in ("r03", "r04", "r04_8waves")]
     res.append(row)
     print(row, flush=True)
 print(json.dumps(res))

@@ -54,7 +54,7 @@ def configure(v):
     lib.supir_debug_knob(0, 1 if v == "base" else 0)
     lib.supir_debug_knob(1, 1 if "w42" in v else 0)
     lib.supir_debug_knob(2, 1 if "gn1" in v else 2 if "gn2" in v else 0)
-    lib.supir_debug_knob(3, 1 if "attn3" in v else 0)      # attn3: the round-3 flash-attention kernel
+    lib.supir_debug_knob(3, 1 if "attn3" in v else 3 if "attn4w" in v else 0)   # attn3: round-3 kernel; attn4w: four waves everywhere
     if v in ("t38", "t38k1280"):
         ops.G16_TILES = {32, 33, 34, 35, 38}
         n = 0
