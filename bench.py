@@ -34,7 +34,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_model(device, rank, world):
+def build_model(device, rank, world, dist_on=False):
     from supir_amd.configs import supir_v0_config
     from supir_amd.plugin import instantiate_from_config
     from supir_amd.synth import synth_param
@@ -51,7 +51,7 @@ def build_model(device, rank, world):
     torch.cuda.synchronize()
     t_fill = time.time() - t0
     t_bcast = 0.0
-    if world > 1:
+    if world > 1 or dist_on:
         # ONE weight broadcast rank0 -> all over RCCL/xGMI, coalesced into 2^28-element buckets; nothing else is communicated
         from supir_amd.parallel import broadcast_module_
         t0 = time.time()
@@ -382,13 +382,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    if world > 1:   # before the first HIP call of the process: the HSA runtime reads it when it initialises
+    # `dist_on`: the multi-GPU code path.  Also taken with ONE rank when the process was started by torch.distributed.run
+    # (`--nproc-per-node 1`): the process group is then a one-rank RCCL group and supir_amd.parallel.FORCE_COLLECTIVES makes every
+    # collective of the N > 1 path (weight broadcast, autotune sync, barriers, the max-over-ranks all-reduce) actually run through
+    # RCCL -- the only way to execute that path on a one-GPU box (profiles/r04/bench_torchrun_nproc1.json)
+    launched = "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("SUPIR_BENCH_FORCE_DIST") == "1"
+    dist_on = world > 1 or launched
+    if dist_on:   # before the first HIP call of the process: the HSA runtime reads it when it initialises
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" == RCCL on ROCm
+        if world == 1:
+            from supir_amd import parallel as _par
+            _par.FORCE_COLLECTIVES = True
 
     from supir_amd import _lib
     _lib.load()  # fail loudly if the HIP extension is missing
@@ -403,7 +412,7 @@ def main():
         ops._CHOICE.clear()
         ops.load_tuning(args.tune_file)
 
-    model, t_fill, t_bcast = build_model(device, rank, world)
+    model, t_fill, t_bcast = build_model(device, rank, world, dist_on)
     if args.diff_dtype == "fp16":
         model.model.dtype = torch.float16
         assert model.model.effective_dtype == torch.float16, "fp16 requested but SUPIR_FP16_NATIVE=0"
@@ -421,14 +430,14 @@ def main():
     x, c, uc = make_inputs(ipg)
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         out = one_image(model, x, (c, uc), 1234 + rank, args.edm_steps)
     autotune_resynced = None
-    if world > 1 and args.warmup > 0:
+    if dist_on and args.warmup > 0:
         # every rank runs the kernels rank 0 picked (per-process autotune can otherwise differ at near-ties, i.e. replicas that
         # differ at the bf16 noise floor); a rank whose picks changed re-captures its graphs in one more untimed image
         from supir_amd import parallel
@@ -454,7 +463,7 @@ def main():
         out = one_image(model, x, (c, uc), 1234 + rank + 1000 * (i + 1), args.edm_steps)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -639,8 +648,11 @@ def main():
             "kernel_breakdown_unet_step": breakdown, "kernel_picks": picks,
         }
         line.update(extra)
+        if dist_on:
+            line["process_group"] = {"backend": dist.get_backend(), "world_size": world,
+                                     "collectives_forced_on_one_rank": bool(world == 1)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
