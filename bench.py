@@ -561,18 +561,18 @@ def main():
         # `traffic` = HBM / fabric-side bytes per launch of this kernel (FETCH_SIZE x 2 + WRITE_SIZE from the committed rocprofv3 --pmc
         # passes, profiles/pmc_traffic.json, averaged over its launches of the step by shape), to be read against
         # algorithmic_mb_per_launch; None when a shape of the kernel has no counter pass
-        tr_bytes, tr_ok = 0.0, bool(shapes)
+        tr_bytes, tr_alg, tr_n = 0.0, 0.0, 0
         for e in shapes:
             te = e.get("traffic")
-            if not te or "fetch_bytes" not in te:
-                tr_ok = False
-                break
-            tr_bytes += (te["fetch_bytes"] + te["write_bytes"]) * e["launches"]
-        traffic_per_launch = tr_bytes / v["launches"] if tr_ok else None
+            if te and "fetch_bytes" in te:      # shapes of this instantiation that have a counter pass (the rest are a few launches)
+                tr_bytes += (te["fetch_bytes"] + te["write_bytes"]) * e["launches"]
+                tr_alg += e["algorithmic_mb_per_launch"] * 1e6 * e["launches"]
+                tr_n += e["launches"]
+        traffic_per_launch = tr_bytes / tr_n if tr_n else None
         roofline.update(traffic=(round(traffic_per_launch) if traffic_per_launch is not None else None),
                         traffic_unit="bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
-                        traffic_over_algorithmic=(round(traffic_per_launch / (v["bytes"] / v["launches"]), 3)
-                                                  if traffic_per_launch is not None else None),
+                        traffic_over_algorithmic=(round(tr_bytes / tr_alg, 3) if tr_n else None),
+                        traffic_launches_covered=f"{tr_n} of {v['launches']}",
                         launches_per_unet_step=v["launches"],
                         avg_launch_us=round(v["us"] / v["launches"], 2),
                         algorithmic_gflop_per_launch=round(v["flops"] / v["launches"] / 1e9, 3),

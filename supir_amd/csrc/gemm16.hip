@@ -771,17 +771,24 @@ int supir_gemm16_launch_n(const GemmArgs* a, int n, hipStream_t st, int tile, bo
     if (n == 1) return supir_gemm16_launch(a[0], st, tile, conv);
     if (n != 2 || tile == 32 || tile == 38) return SUPIR_ERR_SHAPE;
     if (!supir_gemm16_supported(a[0], tile, conv) || !supir_gemm16_supported(a[1], tile, conv) || !g16_same_shape(a[0], a[1])) return SUPIR_ERR_SHAPE;
+    // the wave arrangement of the 256 x 160 tile follows the single-launch policy (4 x 2 for convolutions and M >= 8192): a grouped launch
+    // must stay bitwise the two single launches, GroupNorm partials and row statistics included (their cross-wave sums are ordered by it)
+    const int knob = supir_debug_knob_value(1);
     if (conv) {
         switch (tile) {
             case 33: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true, false, 2>(a, st);
-            case 34: return launch_gemm16<256, 160, 8, 1, 1, 3, false, true, false, 2>(a, st);
+            case 34: return knob != 2 ? launch_gemm16<256, 160, 4, 2, 1, 3, false, true, false, 2>(a, st)
+                                      : launch_gemm16<256, 160, 8, 1, 1, 3, false, true, false, 2>(a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 2>(a, st);
         }
     }
     const bool t = a[0].out_mode == 2;
+    const bool w42 = a[0].act != 2 && (knob == 1 || (knob == 0 && a[0].M >= 8192));
     switch (tile) {
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true, false, false, 2>(a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false, false, false, 2>(a, st);
-        case 34: return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true, false, false, 2>(a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false, false, false, 2>(a, st);
+        case 34:
+            if (w42) return t ? launch_gemm16<256, 160, 4, 2, 1, 3, true, false, false, 2>(a, st) : launch_gemm16<256, 160, 4, 2, 1, 3, false, false, false, 2>(a, st);
+            return t ? launch_gemm16<256, 160, 8, 1, 1, 3, true, false, false, 2>(a, st) : launch_gemm16<256, 160, 8, 1, 1, 3, false, false, false, 2>(a, st);
         default: return t ? launch_gemm16<128, 80, 4, 1, 2, 3, true, false, false, 2>(a, st) : launch_gemm16<128, 80, 4, 1, 2, 3, false, false, false, 2>(a, st);
     }
 }
