@@ -41,6 +41,8 @@ for c in cases:
         bm, bn = G16[tile]
         grid = (M // bm) * (N // bn) * 512
         targs = {32: "128, 80, 4, 1, 2, 2", 33: "128, 160, 2, 2, 2, 2", 34: "256, 160, 8, 1, 1, 3", 35: "128, 80, 4, 1, 2, 3"}
+        if tile == 34 and (kind == "conv3x3" or (kind == "gemm" and M >= 8192)):
+            targs[34] = "256, 160, 4, 2, 1, 3"     # round 4: the eight waves as 4 x 2 for convolutions and M >= 8192
         e = find("geglu_big_kernel", grid) if tile == 37 else \
             find(f"gemm16_kernel<{targs[tile]}, false, {'true' if kind == 'conv3x3' else 'false'}, false, 1>", grid)
         name = gemm_tile_name(M, N, 2 if kind == "gemm_geglu" else 0, conv=(kind == "conv3x3"), tile=tile)
