@@ -566,7 +566,8 @@ def main():
             te = e.get("traffic")
             if te and "fetch_bytes" in te:      # shapes of this instantiation that have a counter pass (the rest are a few launches)
                 tr_bytes += (te["fetch_bytes"] + te["write_bytes"]) * e["launches"]
-                tr_alg += e["algorithmic_mb_per_launch"] * 1e6 * e["launches"]
+                # the counter pass's own launch (with its residual operand) defines the algorithmic bytes the ratio is taken against
+                tr_alg += te.get("algorithmic_bytes", e["algorithmic_mb_per_launch"] * 1e6) * e["launches"]
                 tr_n += e["launches"]
         traffic_per_launch = tr_bytes / tr_n if tr_n else None
         roofline.update(traffic=(round(traffic_per_launch) if traffic_per_launch is not None else None),
