@@ -167,6 +167,21 @@ int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, 
 int supir_flash_attn_d64_ex(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int Tq, int Tk, int ldq,
                             int ldk, int ldvt, int ldo, float scale, int flags, void* stream);
 
+/* The to_q projection AND the attention of a cross-attention layer whose keys are the (few, cached) text tokens, in one launch:
+ *     q = X . Wq^T (+ bias)   [with the LayerNorm fold of supir_gemm_bf16_ln when ln_stats is given: X is then the LayerNorm INPUT,
+ *                              Wq the gamma-folded weight, bias the beta . Wq^T term, ln_colsum[n] = sum_k Wq[n][k]]
+ *     O = softmax(q K^T * scale) V      per head of 64 channels
+ * X:[B*T][ldx], Wq:[H*64][C], bias / ln_colsum:[H*64] fp32 (16-byte aligned), K:[B][Tk][ldk] and Vt:[B][H*64][ldvt] as in
+ * supir_flash_attn_d64, O:[B*T][ldo].  T % 128 == 0, C % 64 == 0, C >= 192, Tk <= 128, all leading dimensions multiples of 8, all
+ * pointers 16-byte aligned; anything else returns SUPIR_ERR_SHAPE and the caller issues the projection and the attention separately.
+ * ln_stats / ln_ld / ln_slots as in supir_gemm_bf16_ln (ln_slots <= 64; 0 = finalized (mean, rstd) pairs).
+ * q never exists in memory; it is rounded to bf16 once (after the fold, with the softmax scale and log2 e folded in), so results
+ * differ from the two-launch path by that one rounding.  hints (may be NULL): next_weight only (parity tests: tests/test_kernels_gpu.py::test_xattn_q_*).
+ * Replaces sgm/modules/attention.py:241-249 (to_q) + :273-277 / :357-359 for context = the text embeddings. */
+int supir_xattn_q_d64(const void* X, const void* Wq, const float* bias, const void* K, const void* Vt, void* O, int B, int H, int T, int Tk,
+                      int C, int ldx, int ldk, int ldvt, int ldo, const float* ln_stats, int ln_ld, int ln_slots, const float* ln_colsum,
+                      float ln_eps, float scale, const supir_launch_hints* hints, void* stream);
+
 /* softmax(Q K^T * scale) V for ONE head of dimension 512 without materialising the score matrix: the VAE mid-block attention
  * (sgm/modules/diffusionmodules/model.py:177-192 AttnBlock == :228-256 MemoryEfficientAttnBlock; SUPIR/utils/tilevae.py:276,335).
  * Q:[B][Tq][ldq], K:[B][Tk][ldk] (512 contiguous channels per token), Vt:[B][512][ldvt] = V transposed per batch

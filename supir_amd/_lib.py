@@ -86,6 +86,8 @@ SIGNATURES.update({
     "supir_gemm_bf16_ln_ex": SIGNATURES["supir_gemm_bf16_ln"][:-1] + [P, P],
     "supir_gemm_bf16_qkv_ex": SIGNATURES["supir_gemm_bf16_qkv"][:-1] + [P, P],
     "supir_conv3x3_bf16_ex": SIGNATURES["supir_conv3x3_bf16"][:-1] + [P, P],
+    # X, Wq, bias, K, Vt, O, B, H, T, Tk, C, ldx, ldk, ldvt, ldo, ln_stats, ln_ld, ln_slots, ln_colsum, ln_eps, scale, hints, stream
+    "supir_xattn_q_d64": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, I, P, F, F, P, P],
     "supir_gemm_grouped": [P, P, I, P],
     "supir_conv3x3_bf16_splitk": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "supir_splitk_finalize": [P, I, I, I, P, I, P, I, P],

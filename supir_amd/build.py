@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm16.hip", "gemm_big.hip", "attention.hip", "attention_d512.hip", "norm.hip", "edge.hip", "sampler.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm16.hip", "gemm_big.hip", "attention.hip", "xattn.hip", "attention_d512.hip", "norm.hip", "edge.hip", "sampler.hip", "api.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "supir_hip.h")]
 LIB = os.path.join(HERE, "libsupir_hip.so")
 LIB_F16 = os.path.join(HERE, "libsupir_hip_f16.so")
@@ -28,7 +28,7 @@ def _stale(lib=LIB):
 
 # per-source extra flags.  attention.hip: keep the MFMA accumulators in architectural VGPRs -- the default allocation put
 # O and S^T in AGPRs and spent 176 v_accvgpr moves per KV tile on the online-softmax rescale (37 % of the loop's instructions).
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "xattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def build(force=False, verbose=True):

@@ -239,6 +239,25 @@ int supir_flash_attn_d64(const void* Q, const void* K, const void* Vt, void* O, 
     return supir_attn_launch(a, (hipStream_t)stream);
 }
 
+int supir_xattn_q_d64(const void* X, const void* Wq, const float* bias, const void* K, const void* Vt, void* O, int B, int H, int T, int Tk,
+                      int C, int ldx, int ldk, int ldvt, int ldo, const float* ln_stats, int ln_ld, int ln_slots, const float* ln_colsum,
+                      float ln_eps, float scale, const supir_launch_hints* hints, void* stream) {
+    if (!X || !Wq || !K || !Vt || !O) return SUPIR_ERR_ARG;
+    if (ln_stats && !ln_colsum) return SUPIR_ERR_ARG;
+    if (hints && (hints->gn_partials_out || (hints->next_weight_bytes && !hints->next_weight))) return SUPIR_ERR_ARG;
+    XattnArgs a{};
+    a.X = (const bf16_t*)X; a.Wq = (const bf16_t*)Wq; a.bias = bias; a.K = (const bf16_t*)K; a.Vt = (const bf16_t*)Vt; a.O = (bf16_t*)O;
+    a.B = B; a.H = H; a.T = T; a.Tk = Tk; a.C = C; a.ldx = ldx; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.ln_stats = ln_stats; a.ln_ld = ln_ld; a.ln_slots = ln_slots; a.ln_colsum = ln_colsum; a.ln_eps = ln_eps;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    if (hints && hints->next_weight) {
+        const size_t lines = hints->next_weight_bytes / 128;
+        a.pf_ptr = (const char*)hints->next_weight;
+        a.pf_lines = lines > 0x7fffffffu ? 0x7fffffffu : (unsigned)lines;
+    }
+    return supir_xattn_q_launch(a, (hipStream_t)stream);
+}
+
 int supir_flash_attn_d512(const void* Q, const void* K, const void* Vt, void* O, int B, int Tq, int Tk, int ldq, int ldk, int ldvt,
                           int ldo, float scale, void* stream) {
     if (!Q || !K || !Vt || !O) return SUPIR_ERR_ARG;

@@ -66,6 +66,25 @@ struct AttnArgsN {
     AttnArgs p[NP];
 };
 
+// xattn.hip: to_q projection (with the LayerNorm fold of supir_gemm_bf16_ln) + attention over a short cached key axis, one launch
+struct XattnArgs {
+    const bf16_t* X;        // [B * T][ldx] tokens (the LayerNorm INPUT when ln_stats is set)
+    const bf16_t* Wq;       // [H * 64][C]  (gamma-folded when ln_stats is set)
+    const float* bias;      // [H * 64] or null (the folded beta . W^T term)
+    const bf16_t* K;        // [B][Tk][ldk], head h at columns h * 64
+    const bf16_t* Vt;       // [B * H][64][ldvt], zero beyond Tk
+    bf16_t* O;              // [B * T][ldo], head h at columns h * 64
+    int B, H, T, Tk, C;
+    int ldx, ldk, ldvt, ldo;
+    const float* ln_stats;  // as GemmArgs: [M][ln_ld][2] partial (sum, sum of squares) slots, or [M][2] (mean, rstd) when ln_slots == 0
+    int ln_ld, ln_slots;
+    const float* ln_colsum; // [H * 64]
+    float ln_eps;
+    float scale_log2e;
+    const char* pf_ptr;     // next-weight prefetch, as GemmArgs
+    unsigned pf_lines;
+};
+
 struct GnArgs {
     const bf16_t* x1;   // [B][HW][ld1], channels [0,C1)
     const bf16_t* x2;   // [B][HW][ld2], channels [C1,C)  (null when C1 == C)  -- the ZeroSFT / skip concat
@@ -120,6 +139,8 @@ int supir_gemm_big_launch(const GemmArgs& a, hipStream_t st);
 int supir_gemm_big_launch_n(const GemmArgs* a, int n, hipStream_t st);
 int supir_attn_launch(const AttnArgs& a, hipStream_t st);
 int supir_attn_launch_n(const AttnArgs* a, int n, hipStream_t st);
+bool supir_xattn_q_supported(const XattnArgs& a);
+int supir_xattn_q_launch(const XattnArgs& a, hipStream_t st);
 // attention_d512.hip: one head of dimension 512 (VAE mid block), 32-key tiles, 32 x 512 output tile per wave
 int supir_attn_d512_launch(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int B, int Tq, int Tk, int ldq, int ldk,
                            int ldvt, int ldo, float scale, hipStream_t st);

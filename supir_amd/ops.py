@@ -1089,6 +1089,47 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     return out
 
 
+USE_XATTN = _os.environ.get("SUPIR_FUSED_XATTN", "1") != "0"
+
+
+def xattn_q_supported(B, T, C, H, Tk):
+    """Shape predicate of supir_xattn_q_d64 (csrc/xattn.hip): whole 128-token row blocks, K steps of 64 channels, <= 2 key tiles."""
+    return USE_XATTN and T % 128 == 0 and C % 64 == 0 and C >= 192 and 0 < Tk <= 128 and H > 0
+
+
+def xattn_q(x, wq, bias, k, vt, B, H, T, Tk, *, ln=None, colsum=None, ln_eps=1e-5, out=None):
+    """to_q projection (optionally with the LayerNorm fold of gemm_ln) + attention over the Tk <= 128 cached text keys, one launch:
+    x [B,T,C] tokens, wq [H*64,C], k [B,Tk,H*64], vt [B,H*64,Tpad] -> [B,T,H*64].  Callers check xattn_q_supported first."""
+    DT = x.dtype
+    lib = _lib.load(DT)
+    _check_dev(x, wq, k, vt)
+    M, C, ldx = _rows_ld(x)
+    assert DT in HALF_TYPES and M == B * T and wq.shape == (H * 64, C) and wq.is_contiguous() and wq.dtype == DT
+    assert k.dtype == DT and vt.dtype == DT and k.stride(-1) == 1 and vt.is_contiguous()
+    ldk, ldvt = k.stride(-2), vt.shape[-1]
+    assert k.shape[0] == B and k.stride(0) == Tk * ldk
+    if out is None:
+        out = torch.empty(B, T, H * 64, dtype=DT, device=x.device)
+    assert out.dtype == DT
+    _, _, ldo = _rows_ld(out)
+    ln_p, ln_ld, ln_slots = 0, 0, 0
+    if ln is not None:
+        ln_p, ln_ld, ln_slots = ln.buf.data_ptr(), ln.ld, ln.slots
+        assert colsum is not None and colsum.numel() == H * 64
+
+    def launch(t, outp=None, hints=None):
+        return lib.supir_xattn_q_d64(x.data_ptr(), wq.data_ptr(), _p(bias), k.data_ptr(), vt.data_ptr(),
+                                     (out if outp is None else outp).data_ptr(), B, H, T, Tk, C, ldx, ldk, ldvt, ldo, ln_p, ln_ld, ln_slots,
+                                     _p(colsum), ln_eps, 0.125, None if hints is None else _ct.byref(hints), _stream())
+
+    N = H * 64
+    _issue(_Launch(None, lib, "supir_xattn_q_d64", launch, w=wq, out=out,
+                   trace=("xattn_q", 2.0 * M * N * C + 4.0 * M * N * Tk, 2.0 * (M * C + N * C + M * N + 2 * B * Tk * N),
+                          dict(B=B, H=H, T=T, Tk=Tk, C=C)),
+                   keep=(x, wq, bias, k, vt, out, ln.buf if ln is not None else None, colsum)))
+    return out
+
+
 # VAE mid-block attention (one head, dim 512): supir_flash_attn_d512 never forms the score matrix; the materialised form (GEMM -> fp32
 # scores [T, T] -> softmax_rows -> GEMM) moves ~3 GB per call at T = 16 384 but runs on the tuned GEMM tiles.  Measured on one box
 # (profiles/r02/attn_d512_timing.json): T = 4096: 391 us flash vs 93 us materialised (32 workgroups of one wave per SIMD cannot

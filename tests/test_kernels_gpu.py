@@ -834,3 +834,100 @@ def test_conv3x3_tap_split(B, H, W, Cin, Cout, act, base):
     assert ((out.float() - one.float()).norm() / one.float().norm()).item() <= 3e-3
     with pytest.raises(Exception):
         ops.conv3x3(x, w, bias, act=act, residual=out, tile=64 + base)      # no residual epilogue in the split form
+
+
+XATTN_CASES = [(2, 20, 1024, 77, 1280), (2, 10, 4096, 77, 640), (1, 5, 128, 64, 320), (1, 3, 256, 128, 192), (2, 2, 128, 1, 256),
+               (1, 4, 384, 33, 256), (1, 2, 128, 65, 192)]
+
+
+def _xattn_operands(B, H, T, Tk, C):
+    N = H * 64
+    x = (rnd(B, T, C) * 1.5 + 0.3).to(BF)
+    k = rnd(B, Tk, N, seed=1).to(BF)
+    k[:, Tk // 2] *= 3.0      # one spiked key: the second half tile has to rescale what the first accumulated (or the other way round)
+    v = rnd(B, Tk, N, seed=2).to(BF)
+    Tp = (Tk + 63) // 64 * 64
+    vt = torch.zeros(B, N, Tp, dtype=BF, device=DEV)
+    vt[:, :, :Tk] = v.permute(0, 2, 1)
+    w = rnd(N, C, scale=C ** -0.5, seed=6)
+    return x, k, v, vt, w
+
+
+def _attn_ref(q, k, v, B, H):
+    qf, kf, vf = (t.float().reshape(B, -1, H, 64).permute(0, 2, 1, 3) for t in (q, k, v))
+    return F.scaled_dot_product_attention(qf, kf, vf).permute(0, 2, 1, 3).reshape(B, -1, H * 64)
+
+
+@pytest.mark.parametrize("B,H,T,Tk,C", XATTN_CASES)
+def test_xattn_q_with_layernorm_fold(B, H, T, Tk, C):
+    """supir_xattn_q_d64 (to_q with the LayerNorm fold + text cross-attention in one launch) vs LayerNorm -> Linear -> attention in
+    fp32, and vs the two-launch HIP path it replaces (same operands; they differ by q's single bf16 rounding only)."""
+    from supir_amd.weights import fold_layernorm
+    N = H * 64
+    x, k, v, vt, w = _xattn_operands(B, H, T, Tk, C)
+    assert ops.xattn_q_supported(B, T, C, H, Tk)
+    # the row statistics as a producer GEMM leaves them (identity-free: a real producer launch)
+    wp = rnd(C, C, scale=C ** -0.5, seed=9).to(BF)
+    xs, st = ops.gemm_ln(x.view(B * T, C), wp, None, residual=x.view(B * T, C), emit_stats=True)
+    xs = xs.view(B, T, C)
+    gamma, beta = rnd(C, seed=4) * 0.2 + 1.0, rnd(C, seed=5) * 0.2
+    wf, cs, bf_ = fold_layernorm(w, None, gamma, beta)
+    out = ops.xattn_q(xs, wf, bf_, k, vt, B, H, T, Tk, ln=st, colsum=cs)
+    q_ref = F.layer_norm(xs.float(), (C,), gamma, beta, 1e-5) @ w.to(BF).float().T
+    ref = _attn_ref(q_ref, k, v, B, H)
+    check(out, ref, rel=8e-3, name="xattn-ln")
+    two = ops.flash_attn(ops.gemm_ln(xs, wf, bf_, ln=st, colsum=cs), k, vt, B, H, T, Tk)
+    check(out, two.float(), rel=8e-3, name="xattn-vs-two-launches")
+    # finalised statistics (slots == 0) take the other branch of the kernel
+    out_f = ops.xattn_q(xs, wf, bf_, k, vt, B, H, T, Tk, ln=ops.rowstats_finalize(st, C, 1e-5), colsum=cs)
+    check(out_f, out.float(), rel=2e-3, name="xattn-finalised-stats")
+
+
+@pytest.mark.parametrize("B,H,T,Tk,C", [(2, 20, 1024, 77, 1280), (1, 3, 256, 128, 192)])
+def test_xattn_q_plain_strided_and_prefetch(B, H, T, Tk, C):
+    """No LayerNorm / bias; x, k and the output as column slices of wider buffers; a next-weight request changes nothing."""
+    from supir_amd import _lib
+    N = H * 64
+    x, k, v, vt, w = _xattn_operands(B, H, T, Tk, C)
+    wb = w.to(BF)
+    xw = torch.zeros(B, T, C + 64, dtype=BF, device=DEV)
+    xw[:, :, :C] = x
+    kw = torch.zeros(B, Tk, 2 * N, dtype=BF, device=DEV)
+    kw[:, :, N:] = k
+    ow = torch.full((B, T, N + 128), 7.0, dtype=BF, device=DEV)
+    out = ops.xattn_q(xw[:, :, :C], wb, None, kw[:, :, N:], vt, B, H, T, Tk, out=ow[:, :, 64:64 + N])
+    ref = _attn_ref(x.float() @ wb.float().T, k, v, B, H)
+    check(out, ref, rel=8e-3, name="xattn-plain")
+    assert (ow[:, :, :64] == 7.0).all() and (ow[:, :, 64 + N:] == 7.0).all()
+    lib = _lib.load()
+    nxt = rnd(1280, 1280, seed=3).to(BF)
+    nxt_copy = nxt.clone()
+    hints = _lib.LaunchHints(next_weight=nxt.data_ptr(), next_weight_bytes=nxt.numel() * 2, gn_partials_out=None)
+    import ctypes
+    o2 = torch.empty(B, T, N, dtype=BF, device=DEV)
+    rc = lib.supir_xattn_q_d64(x.data_ptr(), wb.data_ptr(), None, k.data_ptr(), vt.data_ptr(), o2.data_ptr(), B, H, T, Tk, C, C, N,
+                               vt.shape[-1], N, None, 0, 0, None, 1e-5, 0.125, ctypes.byref(hints), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o2, out.contiguous()) and torch.equal(nxt, nxt_copy)
+
+
+def test_xattn_q_rejects_what_it_does_not_cover():
+    from supir_amd import _lib
+    lib = _lib.load()
+    B, H, T, Tk, C = 1, 2, 128, 77, 256
+    x, k, v, vt, w = _xattn_operands(B, H, T, Tk, C)
+    wb = w.to(BF)
+    o = torch.empty(B, T, H * 64, dtype=BF, device=DEV)
+
+    def call(T_=T, Tk_=Tk, C_=C, ldx=C, x_=x):
+        return lib.supir_xattn_q_d64(x_.data_ptr(), wb.data_ptr(), None, k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, T_, Tk_, C_, ldx,
+                                     H * 64, vt.shape[-1], H * 64, None, 0, 0, None, 1e-5, 0.125, None, None)
+    assert call() == 0
+    assert call(T_=96) == -2          # not whole 128-token row blocks
+    assert call(Tk_=129) == -2        # more than two key tiles
+    assert call(C_=128) == -2         # fewer K steps than the ring is deep
+    assert call(ldx=C + 4) == -2
+    assert lib.supir_xattn_q_d64(None, wb.data_ptr(), None, k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, T, Tk, C, C, H * 64,
+                                 vt.shape[-1], H * 64, None, 0, 0, None, 1e-5, 0.125, None, None) == -1
+    torch.cuda.synchronize()

@@ -200,6 +200,14 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     return _store(o, out, (B, Tq, inner), q.dtype)
 
 
+xattn_q_supported = real_ops.xattn_q_supported
+
+
+def xattn_q(x, wq, bias, k, vt, B, H, T, Tk, *, ln=None, colsum=None, ln_eps=1e-5, out=None):
+    q = gemm_ln(x, wq, bias, ln=ln, colsum=colsum, ln_eps=ln_eps)
+    return flash_attn(q.reshape(B, T, H * 64), k, vt, B, H, T, Tk, out=out)
+
+
 use_flash_d512 = real_ops.use_flash_d512
 
 
@@ -358,7 +366,7 @@ def bicubic_resize_f32(x, h0, w0, want_u8=True):
 
 
 _NAMES = ["gemm", "gemm_ln", "gemm_qkv", "gemm_qkv_supported", "choose", "gemm_t", "rowstats_finalize", "conv3x3", "flash_attn",
-          "use_flash_d512", "flash_attn_d512", "softmax_rows", "groupnorm_stats", "groupnorm", "layernorm", "conv3x3_smallcin",
+          "xattn_q", "xattn_q_supported", "use_flash_d512", "flash_attn_d512", "softmax_rows", "groupnorm_stats", "groupnorm", "layernorm", "conv3x3_smallcin",
           "conv3x3_smallcout", "pointwise_nchw", "edm_step_pre", "edm_step_post", "wavelet_decomposition", "WeightPrefetch",
           "set_prefetch", "paired_run", "start_trace", "stop_trace", "RowStats"]
 

@@ -51,6 +51,12 @@ def configure(v):
     ops._TUNE.update(tuned)
     ops._CHOICE.update(chosen)
     ops.G16_TILES = {32, 33, 34, 35}
+    # xattn / noxattn: the fused to_q + text cross-attention launch (csrc/xattn.hip) forced on / off for every block
+    ops.USE_XATTN = "noxattn" not in v
+    if v == "xattn":
+        for k in list(ops._CHOICE):
+            if k[0] == "xattn":
+                ops._CHOICE[k] = 1
     lib.supir_debug_knob(0, 1 if v == "base" else 0)
     lib.supir_debug_knob(1, 1 if "w42" in v else 0)
     lib.supir_debug_knob(2, 1 if "gn1" in v else 2 if "gn2" in v else 0)
