@@ -72,7 +72,10 @@ __device__ __forceinline__ float bfhi2f(uint32_t w) { return __uint_as_float(w &
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 #endif
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division: the division expands to ~10 VALU
+// instructions per element -- more than the rest of the GroupNorm + SiLU apply pass put together -- and the result is rounded to bf16
+// (2^-9) right after.  exp2(+inf) -> rcp(inf) = 0 -> -0 for very negative x, as before.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 // erf GELU (F.gelu default; reference: sgm/modules/attention.py:91).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,
 // below fp32 resolution of the 1 + erf term and far below the bf16 output): a dozen instructions instead of the libm erff call
 // in the epilogue of the widest GEMM of every transformer block.
@@ -87,7 +90,7 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(y, x);
 }
 // QuickGELU x * sigmoid(1.702 x): the activation of OpenAI CLIP text towers (transformers CLIPTextModel "quick_gelu")
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.4554669595930156f)); }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 // The same function as x * sigmoid(x * (c0 + c1 x^2 + c2 x^4)): a minimax fit of Phi(x) = (1 + erf(x / sqrt 2)) / 2 (scipy, [-8, 8]) with
 // max |gelu error| 2.5e-5 ABSOLUTE -- below half a bf16 ulp of the result for |result| >= 0.013 and 100x below the bf16 rounding of

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgsN<NP> pp) {
 // MOD = the ZeroSFT form (modulation maps, optional lerp): its extra row operands live in registers only in that instantiation -- the
 // plain form must stay small (<= 64 VGPRs: eight waves per SIMD), a streaming kernel lives on the loads the resident waves keep in
 // flight (a first version with one 150-register body ran the 16384 x 320 map in 46.8 us instead of 31).
-template <int NP, bool MOD>
+template <int NP, bool MOD, bool SILU>
 __global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int nchunk_apply, int rows_per_chunk_apply, int TY) {
     const GnArgs& p = pp.p[NP == 1 ? 0 : blockIdx.z];
     __shared__ float s_mean[32], s_rstd[32];
@@ -180,7 +180,6 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int
         sb[e] = (e < 4 ? be0[e] : be1[e - 4]) - s_mean[g] * a;
     }
     if (ty >= TY) return;   // (never: the block is exactly cv x TY threads)
-    const bool silu = p.act == 1;
     for (int row = row0 + ty; row < row1; row += U * TY) {
         u16x8 ov[U];
 #pragma unroll
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float y = bf2f(xv[u][e]) * sa[e] + sb[e];
-                if (silu) y = silu_f(y);
+                if constexpr (SILU) y = silu_f(y);
                 if constexpr (MOD) {
                     y = y * (bf2f(gv[u][e]) + 1.0f) + bf2f(bv[u][e]);
                     if (lerp) y = y * p.cscale + bf2f(rv[u][e]) * (1.0f - p.cscale);
@@ -368,8 +367,16 @@ static int gn_launch(const GnArgs* a_in, hipStream_t st) {
         SUPIR_LAUNCH(gn_apply_kernel_v1<NP>, dim3(nca, a.B, NP), dim3(256), (size_t)a.C * 2 * sizeof(float), st, pp, nca, rpc);
         return SUPIR_LAUNCH_STATUS();
     }
-    if (a.mod_g) SUPIR_LAUNCH((gn_apply_kernel<NP, true>), dim3(nca, a.B, NP), dim3(cv * ty), 0, st, pp, nca, rpc, ty);
-    else SUPIR_LAUNCH((gn_apply_kernel<NP, false>), dim3(nca, a.B, NP), dim3(cv * ty), 0, st, pp, nca, rpc, ty);
+    for (int q = 1; q < NP; ++q)
+        if (pp.p[q].act != a.act) return SUPIR_ERR_SHAPE;
+    const dim3 grid(nca, a.B, NP), block(cv * ty);
+    if (a.mod_g) {
+        if (a.act == 1) SUPIR_LAUNCH((gn_apply_kernel<NP, true, true>), grid, block, 0, st, pp, nca, rpc, ty);
+        else SUPIR_LAUNCH((gn_apply_kernel<NP, true, false>), grid, block, 0, st, pp, nca, rpc, ty);
+    } else {
+        if (a.act == 1) SUPIR_LAUNCH((gn_apply_kernel<NP, false, true>), grid, block, 0, st, pp, nca, rpc, ty);
+        else SUPIR_LAUNCH((gn_apply_kernel<NP, false, false>), grid, block, 0, st, pp, nca, rpc, ty);
+    }
     return SUPIR_LAUNCH_STATUS();
 }
 
