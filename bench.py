@@ -107,6 +107,8 @@ def kernel_profile(model, latent, device):
             shape = f"B{r['B']} H{r['H']} Tq{r['Tq']} Tk{r['Tk']}"
         elif k == "groupnorm":
             shape = f"B{r['B']} HW{r['HW']} C{r['C']}"
+        elif k == "xattn_q":
+            shape = f"B{r['B']} H{r['H']} T{r['T']} Tk{r['Tk']} C{r['C']}"
         if r["kernel"] == "groupnorm" and r.get("parts"):
             k = "groupnorm(statistics from the producer)"   # one launch; the others are a statistics + an apply launch
         if r.get("group", 1) == 2:

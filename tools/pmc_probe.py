@@ -49,6 +49,15 @@ for (B, H, Tq, Tk) in [(2, 20, 1024, 1024), (2, 10, 4096, 4096)]:
     for _ in range(3):
         ops.flash_attn(q, k, vt, B, H, Tq, Tk)
     note("attn", f"B{B} H{H} Tq{Tq} Tk{Tk}", 4.0 * B * H * Tq * Tk * 64, 2.0 * B * C * (2 * Tq + 2 * Tk), -1)
+# fused to_q + text cross-attention (csrc/xattn.hip, round 4): x, the head's weight rows and the 77 cached keys in, the attention output out
+for (B, H, T, Tk, C) in [(2, 20, 1024, 77, 1280), (2, 10, 4096, 77, 640)]:
+    N = H * 64
+    x = torch.randn(B, T, C, device=dev).to(BF); wq = (torch.randn(N, C, device=dev) * C ** -0.5).to(BF)
+    k = torch.randn(B, Tk, N, device=dev).to(BF)
+    vt = torch.zeros(B, N, 128, device=dev, dtype=BF); vt[:, :, :Tk] = torch.randn(B, N, Tk, device=dev).to(BF)
+    for _ in range(3):
+        ops.xattn_q(x, wq, None, k, vt, B, H, T, Tk)
+    note("xattn_q", f"B{B} H{H} T{T} Tk{Tk} C{C}", 2.0 * B * T * N * C + 4.0 * B * T * N * Tk, 2.0 * (B * T * C + N * C + 2 * B * Tk * N + B * T * N), -1)
 for (B, HW, C) in [(2, 1024, 1280), (2, 4096, 640), (2, 16384, 320)]:
     x = torch.randn(B, HW, C, device=dev).to(BF)
     g, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)

@@ -17,7 +17,7 @@ for f in files:
     with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
             name = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", ""))
-            if not (name.startswith("gemm") or name.startswith("geglu") or name.startswith("attn") or name.startswith("gn_")):
+            if not (name.startswith("gemm") or name.startswith("geglu") or name.startswith("attn") or name.startswith("xattn") or name.startswith("gn_")):
                 continue
             rows[f"{name} grid={r['Grid_Size']}"].append(r)
     for base, rs in rows.items():

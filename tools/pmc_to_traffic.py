@@ -50,6 +50,10 @@ for c in cases:
         B, H, Tq = (int(t.lstrip("BHTq")) for t in shape.split()[:3])
         e = find("attn_d64_pipe_kernel", ((Tq + 127) // 128) * H * B * 256)
         name = "attn"
+    elif kind == "xattn_q":
+        B, H, T = (int(t.lstrip("BHT")) for t in shape.split()[:3])
+        e = find("xattn_q_kernel", (T // 128) * H * B * 256)
+        name = "xattn_q"
     else:
         continue
     if e is None:

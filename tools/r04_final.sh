@@ -25,7 +25,7 @@ done
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summarize.py $O/pmc_summary.json $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/pmc_SQ_WAVE_CYCLES.csv > $O/pmc_summary.txt 2>&1
 rm -rf $O/raw_*
-for f in $O/pmc_*.csv; do (head -1 $f; grep -E "gemm16_kernel|gemm_bf16_kernel|geglu_big|attn_d64|gn_" $f) > $f.tmp && mv $f.tmp $f; done
+for f in $O/pmc_*.csv; do (head -1 $f; grep -E "gemm16_kernel|gemm_bf16_kernel|geglu_big|attn_d64|xattn_q|gn_" $f) > $f.tmp && mv $f.tmp $f; done
 MASTER_ADDR=127.0.0.1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --extra-batch 0 --no-kernel-profile > $O/bench_torchrun_nproc1.json 2> $O/bench_torchrun_nproc1.err
 echo "torchrun rc=$?"; tail -c 200 $O/bench_torchrun_nproc1.err
 python - <<'PY'
