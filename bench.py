@@ -476,10 +476,11 @@ def main():
     if rank == 0:
         lat = P // 8
         from supir_amd.synth import synth_tensor as st
-        xx = st("bench.x", (2, 4, lat, lat)).to(device)
+        nb = 2 * int(c["vector"].shape[0])   # CFG-doubled batch of one call: 2 x images per call
+        xx = st("bench.x", (nb, 4, lat, lat)).to(device)
         cond = {"crossattn": torch.cat([uc["crossattn"], c["crossattn"]]), "vector": torch.cat([uc["vector"], c["vector"]]),
-                "control": st("bench.lq", (2, 4, lat, lat)).to(device)}
-        tt = torch.full((2,), 500, dtype=torch.int64, device=device)
+                "control": st("bench.lq", (nb, 4, lat, lat)).to(device)}
+        tt = torch.full((nb,), 500, dtype=torch.int64, device=device)
         with torch.no_grad():
             for _ in range(3):
                 model.model(xx, tt, cond, 1.0)
@@ -509,7 +510,7 @@ def main():
                 torch.cuda.synchronize()
                 model.model.end_schedule()
             extra["ms_per_unet_step_inside_the_sampler"] = e0.elapsed_time(e1) / 10
-        extra["unet_step_tflops"] = UNET_STEP_TFLOP.get(lat, 0) / (ms_unet * 1e-3) if lat in UNET_STEP_TFLOP else None
+        extra["unet_step_tflops"] = UNET_STEP_TFLOP.get(lat, 0) * (nb // 2) / (ms_unet * 1e-3) if lat in UNET_STEP_TFLOP else None
 
     roofline, breakdown = None, None
     if rank == 0 and not args.no_kernel_profile:

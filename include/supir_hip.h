@@ -86,7 +86,8 @@ typedef struct supir_launch_hints {
  * 256x128/8 waves, 256x256/8 waves, 256x128/4 waves); bits 3-4 optionally force the LDS ring depth (profiling sweeps);
  * 32..35: the exact-fit tiles of csrc/gemm16.hip (128x80, 128x160, 256x160, 128x80 with 3-deep rings); 37: the 256x320 GEGLU tile of
  * csrc/gemm_big.hip (act = GEGLU, W rows interleaved [16 value | 16 gate], M % 256 == 0, N % 320 == 0); 38: 128x80 with FOUR waves
- * and 78 KB of LDS (two workgroups per CU; round 4).  Forced tiles that do not fit the shape return SUPIR_ERR_SHAPE. */
+ * and 78 KB of LDS (two workgroups per CU; round 4); 39 / 40: 256x128 and 256x256 of csrc/gemm16.hip (M % 256 == 0, N % 128 / 256 == 0,
+ * ordinary epilogue only: the VAE's 128 / 256 / 512-channel layers).  Forced tiles that do not fit the shape return SUPIR_ERR_SHAPE. */
 int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream);

@@ -17,6 +17,11 @@
 //   33   128 x 160  2x2 per group     2       2   144 KB   N = 2560, M = 8192 x N = 640
 //   34   256 x 160  8x1               1       3   156 KB   N = 10240 (GEGLU epilogue: value / gate interleaved per 16 rows of W)
 //   35   128 x  80  4x1 per group     2       3   156 KB   tile 32 with a 3-deep ring (two K steps of loads in flight per group)
+//   39   256 x 128  4x2               1       3   144 KB   128-channel outputs at M >= 64 K rows (VAE convolutions, sgm/modules/
+//                                                          diffusionmodules/model.py:55-148: Cout = 128 at 512^2 / 1024^2)
+//   40   256 x 256  4x2               1       2   128 KB   256 / 512-channel outputs of the VAE (32 B/clk of fill per CU: the one tile
+//                                                          of the family under the 38 B/clk the loops sustain); one 32-wide K slice of
+//                                                          fragments in registers at a time (128 accumulator registers)
 //
 //  * 512 threads.  KS = 2: two K groups of four waves, group g takes K steps g, g+2, ... from its own LDS ring, so every SIMD
 //    holds two waves (one per group) whose load issue / LDS reads / MFMAs interleave; the partial accumulators are
@@ -315,7 +320,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* sT = ring + buf * STAGE_BYTES;
-        bf16x8 af[2][MI], bfr[2][NI];
+        // both 32-wide K slices of fragments are read ahead of the MFMAs -- except where the accumulators already take half the
+        // register file (256 x 256: MI * NI = 32 fragments = 128 registers; 96 more for two slices spilled): one slice at a time
+        // there, the second one read behind the first slice's MFMAs (the SIMD's other wave covers the wait)
+        constexpr bool ONE_SLICE = MI * NI >= 32;
+        constexpr int FS = ONE_SLICE ? 1 : 2;
+        bf16x8 af[FS][MI], bfr[FS][NI];
         auto read_frags = [&](int kk, int slot) {
             const int coff = ((4 * kk + quad) ^ sw) * 16;
 #pragma unroll
@@ -326,7 +336,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         read_frags(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 0) read_frags(1, 1);
+            const int sl = ONE_SLICE ? 0 : kk;
+            if (!ONE_SLICE && kk == 0) read_frags(1, 1);
             if constexpr (STAGE) {
 #pragma unroll
                 for (int q = (kk * LOADS) / 2; q < ((kk + 1) * LOADS) / 2; ++q) stage_one(sbuf, q);
@@ -336,11 +347,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     if constexpr (TR)
-                        acc[i][j] = SUPIR_MFMA_16x16x32(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SUPIR_MFMA_16x16x32(af[sl][i], bfr[sl][j], acc[i][j], 0, 0, 0);
                     else
-                        acc[i][j] = SUPIR_MFMA_16x16x32(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SUPIR_MFMA_16x16x32(bfr[sl][j], af[sl][i], acc[i][j], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
+            if (ONE_SLICE && kk == 0) read_frags(1, 0);
         }
         if constexpr (STAGE) stage_advance();
         buf = buf + 1 == S ? 0 : buf + 1;
@@ -712,11 +724,15 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    if ((tile < 32 || tile > 35) && tile != 38) return false;
-    const int bm = tile == 34 ? 256 : 128, bn = (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
-    const int ks = (tile == 34 || tile == 38) ? 1 : 2, s = (tile == 34 || tile == 35 || tile == 38) ? 3 : 2;
+    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40)) return false;
+    const bool wide = tile == 34 || tile == 39 || tile == 40;
+    const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : tile == 40 ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
+    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
+    // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU, no GroupNorm partials:
+    // their channel counts -- 128 / 256 / 512 -- have 4 / 8 / 16 channels per group, not the 10-channel units of the partials)
+    if ((tile == 39 || tile == 40) && (a.out_mode != 0 || a.act == 2 || a.gn_part_out)) return false;
     if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % 10)) return false;
     if (conv) {
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
@@ -741,11 +757,15 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
             case 34: return supir_debug_knob_value(1) != 2 ? launch_gemm16<256, 160, 4, 2, 1, 3, false, true>(&a, st)
                                                            : launch_gemm16<256, 160, 8, 1, 1, 3, false, true>(&a, st);
             case 38: return launch_gemm16<128, 80, 4, 1, 1, 3, false, true>(&a, st);
+            case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false, true>(&a, st);
+            case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false, true>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
     const bool t = a.out_mode == 2;
     switch (tile) {
+        case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false>(&a, st);
+        case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false>(&a, st);
         case 38: return t ? launch_gemm16<128, 80, 4, 1, 1, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 1, 3, false>(&a, st);
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);

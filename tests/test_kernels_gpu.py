@@ -758,6 +758,77 @@ def test_gemm16_conv3x3(case, tile):
     check(out, 0.5 * F.silu(ref + rb.float()[:, None, None, :]) + res.float(), name="conv16 epilogue")
 
 
+G16_VAE_CONV_CASES = [
+    # B, H, W, Cin, Cout, stride, pad(top,left), upsample, out_hw      (sgm/modules/diffusionmodules/model.py:55-148, 571-743)
+    (1, 64, 64, 128, 128, 1, (1, 1), False, None),          # ResnetBlock at the full-resolution level (1024^2 in production)
+    (1, 32, 32, 256, 256, 1, (1, 1), False, None),
+    (1, 32, 32, 128, 256, 1, (1, 1), False, None),          # channel change
+    (1, 16, 16, 512, 512, 1, (1, 1), True, None),           # Upsample: nearest 2x folded into the gather
+    (1, 64, 64, 128, 128, 2, (0, 0), False, (32, 32)),      # Downsample: stride 2, pad (0,1,0,1)
+    (2, 16, 16, 512, 256, 1, (1, 1), False, None),
+]
+
+
+@pytest.mark.parametrize("case", G16_VAE_CONV_CASES)
+@pytest.mark.parametrize("tile", [39, 40])
+def test_gemm16_vae_tiles_conv3x3(case, tile):
+    """Tiles 39 (256 x 128) / 40 (256 x 256, one K slice of fragments in registers at a time) of csrc/gemm16.hip on the VAE's
+    convolution shapes: against torch fp32, against the gemm.hip tile that ran them before, repeatable, epilogue terms."""
+    B, H, W, Cin, Cout, stride, pad, up, out_hw = case
+    bn = 128 if tile == 39 else 256
+    x = rnd(B, H, W, Cin).to(BF)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
+    bias = rnd(Cout, seed=2)
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    xr = x.float().permute(0, 3, 1, 2)
+    if up:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    if out_hw is not None:
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), w.float(), bias, stride=stride, padding=0)
+    else:
+        ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=1)
+    OH, OW = ref.shape[2:]
+    if (B * OH * OW) % 256 or Cout % bn:
+        pytest.skip("not an exact fit for this tile")
+    ref = ref.permute(0, 2, 3, 1)
+    out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile)
+    check(out, ref, name=f"conv16 {case} tile{tile}")
+    assert torch.equal(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile))
+    check(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=4).float(), rel=3e-3, name="vs gemm.hip tile 4")
+    res = rnd(B, OH, OW, Cout, seed=5).to(BF)
+    out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, residual=res, act=1, alpha=0.5, tile=tile)
+    check(out, 0.5 * F.silu(ref) + res.float(), name="conv16 epilogue")
+    # the request for GroupNorm partials is answered with "cannot" (None), not with a refused launch
+    o2, part = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile, gn_part=True)
+    assert part is None and torch.equal(o2, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile))
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (1024, 256, 128), (512, 128, 256), (16384, 512, 512)])
+@pytest.mark.parametrize("tile", [39, 40])
+def test_gemm16_vae_tiles_plain(M, N, K, tile):
+    """The same tiles as plain GEMMs (the VAE's 1x1 convolutions: nin_shortcut model.py:124, attention q / k / v / proj_out :164-175)."""
+    bn = 128 if tile == 39 else 256
+    if N % bn or (tile == 39 and K < 128):
+        pytest.skip("not an exact fit for this tile")
+    a = rnd(M, K).to(BF)
+    w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N, seed=2)
+    base = a.float() @ w.float().T + bias
+    out = ops.gemm(a, w, bias, tile=tile)
+    check(out, base, name=f"gemm16{(M, N, K)} tile{tile}")
+    assert torch.equal(out, ops.gemm(a, w, bias, tile=tile))
+    res = rnd(M, N, seed=3).to(BF)
+    check(ops.gemm(a, w, bias, residual=res, alpha=0.5, tile=tile), 0.5 * base + res.float(), name="res+alpha")
+    acc = res.clone()
+    ops.gemm(a, w, bias, residual=acc, out=acc, tile=tile)                          # in-place residual (x += f(x))
+    check(acc, base + res.float(), name="in-place residual")
+    from supir_amd._lib import SupirHipError
+    with pytest.raises(SupirHipError):
+        ops.gemm_t(a.view(1, M, K), w, None, 1, M, M, tile=tile)                   # no transposed form
+    # autotuned call: N % 80 != 0, so 39 / 40 are among the candidates; whichever tile wins the result is right
+    check(ops.gemm(a, w, bias), base, name="auto")
+
+
 @pytest.mark.parametrize("B,T,C", [(2, 1024, 1280), (2, 4096, 640), (1, 256, 320)])
 def test_gemm_qkv_fused(B, T, C):
     """supir_gemm_bf16_qkv: q | k written normally, v transposed per batch, one launch; with and without the LayerNorm fold,
