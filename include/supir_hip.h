@@ -65,9 +65,11 @@ const char* supir_hip_error_string(int code);
  *   next_weight / next_weight_bytes: this launch, after its last store, touches the first `next_weight_bytes` (whole 128-byte lines) of
  *     `next_weight` -- the bf16 weight matrix of a LATER launch -- so that it is found in the Infinity Cache / L2 instead of HBM.
  *     Read-only, results unaffected.  (The host mirror knows the launch order of a network call: supir_amd/ops.py WeightPrefetch.)
- *   gn_partials_out: tiles 32..35 only, bf16 row-major output, rows_per_batch % BM == 0, N % 10 == 0 (else SUPIR_ERR_SHAPE): the launch
- *     also writes, per batch b, tile row c (BM = 128 or 256 tokens) and 10-channel unit u, the (sum, sum of squares) of the bf16 values
- *     it stored: gn_partials_out[((b * (rows_per_batch / BM) + c) * (N / 10) + u) * 2 + {0,1}] -- the input of supir_groupnorm_nhwc_parts.
+ *   gn_partials_out: tiles 32..35 / 38..40 only, bf16 row-major output, rows_per_batch % BM == 0, N % GU == 0 (else SUPIR_ERR_SHAPE): the
+ *     launch also writes, per batch b, tile row c (BM = 128 or 256 tokens) and GU-channel unit u, the (sum, sum of squares) of the bf16
+ *     values it stored: gn_partials_out[((b * (rows_per_batch / BM) + c) * (N / GU) + u) * 2 + {0,1}].  GU = 10 on the 80 / 160-column
+ *     tiles 32..35 / 38 (the input of supir_groupnorm_nhwc_parts), GU = 4 on the 128 / 256-column tiles 39 / 40 (the VAE's 4 / 8 / 16-channel
+ *     groups; reduced by supir_groupnorm_parts_finalize into the given_mean_var input of supir_groupnorm_nhwc).
  * No reference counterpart (the reference's cuBLAS / cuDNN calls meet every weight cold each step and its GroupNorm always runs its
  * own statistics pass, sgm/modules/diffusionmodules/util.py:258-276). */
 typedef struct supir_launch_hints {
@@ -226,6 +228,14 @@ int supir_groupnorm_nhwc_parts(const void* x1, const void* x2, const void* x1raw
                                int ld1, int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
                                const void* mod_b, int ldm, float control_scale, void* out, int ldo, const float* part1, int nchunk1,
                                const float* part2, int nchunk2, void* stream);
+
+/* Producer partials in `unit`-channel units (part[((b * nchunk + c) * (C / unit) + u) * 2 + {0,1}], (C / 32) % unit == 0) -> per batch
+ * and group (mean, biased variance), fp32 [B][32][2] = the given_mean_var input of supir_groupnorm_nhwc.  HW = pixels per batch element.
+ * Used where a producer leaves thousands of tile rows behind (VAE feature maps at 1024^2: 4096 rows of 256 pixels): one small launch
+ * instead of every workgroup of the normalisation re-reducing all of them.  fp64 accumulation, fixed order.  Replaces the statistics
+ * pass of Normalize (sgm/modules/diffusionmodules/model.py:48-51) over the outputs of ResnetBlock / Upsample / Downsample convolutions
+ * (model.py:55-148). */
+int supir_groupnorm_parts_finalize(const float* part, int B, int nchunk, int C, int unit, int HW, float* mean_var_out, void* stream);
 
 /* Statistics half of GroupNorm alone: sums_out[b][g] = (sum, sum of squares) over group g of batch b, fp32 [B][32][2].
  * With given_mean_var ([B][32][2] = mean, biased variance) supir_groupnorm_nhwc skips its own statistics pass and

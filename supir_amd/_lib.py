@@ -31,6 +31,7 @@ SIGNATURES = {
     "supir_softmax_rows": [P, P, I, I, I, L, L, F, P],
     "supir_groupnorm_nhwc": [P, P, P, P, I, I, I, I, I, I, P, P, F, I, P, P, I, F, P, I, P, c_size_t, P, P],
     "supir_groupnorm_stats": [P, P, I, I, I, I, I, I, P, P, c_size_t, P],
+    "supir_groupnorm_parts_finalize": [P, I, I, I, I, I, P, P],
     "supir_layernorm": [P, P, P, P, I, I, I, I, F, P],
     "supir_conv3x3_smallcin": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "supir_conv3x3_smallcout": [P, P, P, P, I, I, I, I, I, I, P],

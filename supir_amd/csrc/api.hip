@@ -282,6 +282,11 @@ int supir_groupnorm_stats(const void* x1, const void* x2, int B, int HW, int C, 
     return supir_groupnorm_stats_launch(a, sums_out, (hipStream_t)stream);
 }
 
+int supir_groupnorm_parts_finalize(const float* part, int B, int nchunk, int C, int unit, int HW, float* mean_var_out, void* stream) {
+    if (!part || !mean_var_out) return SUPIR_ERR_ARG;
+    return supir_groupnorm_parts_finalize_launch(part, B, nchunk, C, unit, HW, mean_var_out, (hipStream_t)stream);
+}
+
 int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, const void* x2raw, int B, int HW, int C, int C1, int ld1,
                          int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
                          const void* mod_b, int ldm, float control_scale, void* out, int ldo, float* workspace,

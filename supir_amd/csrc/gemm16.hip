@@ -655,13 +655,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             }
         }
         if (p.gn_part_out) {
-            // one (sum, sum of squares) per 10-channel unit of this tile: every wave that covered the unit's columns (all wave rows,
-            // both K groups), in a fixed order (reproducible); tile rows never straddle a batch (dispatcher)
+            // one (sum, sum of squares) per GU-channel unit of this tile: every wave that covered the unit's columns (all wave rows,
+            // both K groups), in a fixed order (reproducible); tile rows never straddle a batch (dispatcher).  GU = 10 for the
+            // 80 / 160-column tiles (the UNet's groups are 10 / 20 / 40 / 60 channels wide), 4 for the 128 / 256-column tiles 39 / 40
+            // (the VAE's groups: 4 / 8 / 16 channels, sgm/modules/diffusionmodules/model.py:48-51)
+            constexpr int GU = (BN % 10 == 0) ? 10 : 4;
             __syncthreads();
-            if ((int)threadIdx.x < BN / 10) {
+            if ((int)threadIdx.x < BN / GU) {
                 const float* red = (const float*)(smem + OFF_GN);
                 float sm = 0.f, sq = 0.f;
-                for (int c = (int)threadIdx.x * 10; c < (int)threadIdx.x * 10 + 10; ++c) {
+                for (int c = (int)threadIdx.x * GU; c < (int)threadIdx.x * GU + GU; ++c) {
                     const int wn_c = c / WTN, cl = c - wn_c * WTN;
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx)
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                         }
                 }
                 const int b = m0 / p.rows_per_batch, chunk = (m0 - b * p.rows_per_batch) / BM, nchunk = p.rows_per_batch / BM;
-                float* dst = p.gn_part_out + (((size_t)b * nchunk + chunk) * (p.N / 10) + n0 / 10 + threadIdx.x) * 2;
+                float* dst = p.gn_part_out + (((size_t)b * nchunk + chunk) * (p.N / GU) + n0 / GU + threadIdx.x) * 2;
                 dst[0] = sm;
                 dst[1] = sq;
             }
@@ -730,10 +733,10 @@ bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
     const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
-    // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU, no GroupNorm partials:
-    // their channel counts -- 128 / 256 / 512 -- have 4 / 8 / 16 channels per group, not the 10-channel units of the partials)
-    if ((tile == 39 || tile == 40) && (a.out_mode != 0 || a.act == 2 || a.gn_part_out)) return false;
-    if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % 10)) return false;
+    // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU); their GroupNorm
+    // partials come in 4-channel units (channel counts 128 / 256 / 512: 4 / 8 / 16 channels per group)
+    if ((tile == 39 || tile == 40) && (a.out_mode != 0 || a.act == 2)) return false;
+    if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % (bn % 10 == 0 ? 10 : 4))) return false;
     if (conv) {
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }

@@ -116,6 +116,7 @@ struct GnArgsN {
 int supir_gemm_select_tile(int M, int N, int act, int force_tile);
 int supir_splitk_finalize_launch(const float* part, int ksplit, int M, int N, int ld_part, const float* bias, int act, bf16_t* out, int ldo,
                                  hipStream_t st);
+int supir_groupnorm_parts_finalize_launch(const float* part, int B, int nchunk, int C, int unit, int HW, float* mean_var, hipStream_t st);
 int supir_rowstats_finalize_launch(const float* part, float* out, int M, int ld, int slots, int dim, float eps, hipStream_t st);
 int supir_gemm_launch(const GemmArgs& a, bool conv, hipStream_t st, int force_tile);
 // nx = XCDs this problem's tiles are spread over (8; 4 for each problem of a two-problem grouped launch)

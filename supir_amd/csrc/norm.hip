@@ -414,6 +414,49 @@ int supir_groupnorm_stats_launch(GnArgs a, float* sums_out, hipStream_t st) {
     return SUPIR_LAUNCH_STATUS();
 }
 
+// Producer partials in `unit`-channel units ([B][nchunk][C / unit][2], GemmArgs::gn_part_out) -> per-(batch, group) (mean, biased
+// variance) [B][32][2]: the `given` input of the apply pass.  For maps whose producers leave THOUSANDS of tile rows behind (the VAE at
+// 1024^2: 4096 rows of 256 pixels) -- there the apply kernel's own prologue, which has every workgroup re-reduce all partials, would read
+// more than the tensor itself.  One workgroup per (group, batch); fp64 accumulation in a fixed order (reproducible).
+__global__ __launch_bounds__(256) void gn_parts_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_var, int nchunk,
+                                                                int U, int upg, double inv_n) {
+    __shared__ double s_s[256], s_q[256];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int k = tid; k < nchunk; k += 256) {
+        const float* e = part + (((size_t)b * nchunk + k) * U + (size_t)g * upg) * 2;
+        for (int u = 0; u < upg; ++u) {
+            s += (double)e[2 * u];
+            q += (double)e[2 * u + 1];
+        }
+    }
+    s_s[tid] = s;
+    s_q[tid] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) {
+            s_s[tid] += s_s[tid + w];
+            s_q[tid] += s_q[tid + w];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double mean = s_s[0] * inv_n;
+        double var = s_q[0] * inv_n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mean_var[((size_t)b * 32 + g) * 2] = (float)mean;
+        mean_var[((size_t)b * 32 + g) * 2 + 1] = (float)var;
+    }
+}
+
+int supir_groupnorm_parts_finalize_launch(const float* part, int B, int nchunk, int C, int unit, int HW, float* mean_var, hipStream_t st) {
+    if (B <= 0 || nchunk <= 0 || HW <= 0 || C <= 0 || C % 32 || unit <= 0 || (C / 32) % unit) return SUPIR_ERR_SHAPE;
+    const int cpg = C / 32;
+    SUPIR_LAUNCH(gn_parts_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, mean_var, nchunk, C / unit, cpg / unit,
+                 1.0 / ((double)HW * (double)cpg));
+    return SUPIR_LAUNCH_STATUS();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm over the channel dim of token-major bf16 [rows][ld]; one wave per row, row kept in registers.
 template <int NV>

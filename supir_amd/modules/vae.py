@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .base import cdt, Conv3x3, Linear, Normalize, Prep, to_nchw, to_nhwc
+from .base import attach_gn_part, cdt, Conv3x3, gn_part_of, Linear, Normalize, Prep, to_nchw, to_nhwc
 from .. import weights as Wt
 
 
@@ -29,14 +29,17 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = Linear(in_channels, out_channels, conv1x1=True)
 
     def forward(self, x, temb=None):
+        """model.py:126-148.  Every convolution epilogue also leaves the GroupNorm statistics of what it stored (ops.GnPart, where
+        the tile that runs can emit them): norm2 and the NEXT module's first norm then skip their pass over the tensor."""
         xh = to_nhwc(x)
-        h = ops.groupnorm(xh, self.norm1.g32(), self.norm1.b32(), self.norm1.eps, silu=True)
-        h = ops.conv3x3(h, self.conv1.w(), self.conv1.b32())
-        h = ops.groupnorm(h, self.norm2.g32(), self.norm2.b32(), self.norm2.eps, silu=True, out=h)
+        h = ops.groupnorm(xh, self.norm1.g32(), self.norm1.b32(), self.norm1.eps, silu=True, part=gn_part_of(x))
+        h, p1 = ops.conv3x3(h, self.conv1.w(), self.conv1.b32(), gn_part=True)
+        h = ops.groupnorm(h, self.norm2.g32(), self.norm2.b32(), self.norm2.eps, silu=True, out=h, part=p1)
         sk = xh
         if self.in_channels != self.out_channels:
             sk = ops.gemm(xh, self.nin_shortcut.w(), self.nin_shortcut.b32())
-        return to_nchw(ops.conv3x3(h, self.conv2.w(), self.conv2.b32(), residual=sk))
+        out, po = ops.conv3x3(h, self.conv2.w(), self.conv2.b32(), residual=sk, gn_part=True)
+        return attach_gn_part(to_nchw(out), po)
 
 
 class AttnBlock(nn.Module):
@@ -84,10 +87,10 @@ class AttnBlock(nn.Module):
         xh = to_nhwc(x)
         B, H, W, C = xh.shape
         T = H * W
-        n = ops.groupnorm(xh, self.norm.g32(), self.norm.b32(), self.norm.eps).view(B, T, C)
+        n = ops.groupnorm(xh, self.norm.g32(), self.norm.b32(), self.norm.eps, part=gn_part_of(x)).view(B, T, C)
         o = self.attend(n)
-        out = ops.gemm(o, self.proj_out.w(), self.proj_out.b32(), residual=xh.view(B, T, C))
-        return to_nchw(out.view(B, H, W, C))
+        out, po = ops.gemm(o, self.proj_out.w(), self.proj_out.b32(), residual=xh.view(B, T, C), rows_per_batch=T, gn_part=True)
+        return attach_gn_part(to_nchw(out.view(B, H, W, C)), po)
 
 
 MemoryEfficientAttnBlock = AttnBlock
@@ -108,7 +111,8 @@ class Upsample(nn.Module):
         self.conv = Conv3x3(in_channels, in_channels)
 
     def forward(self, x):
-        return to_nchw(ops.conv3x3(to_nhwc(x), self.conv.w(), self.conv.b32(), upsample=True))
+        out, po = ops.conv3x3(to_nhwc(x), self.conv.w(), self.conv.b32(), upsample=True, gn_part=True)
+        return attach_gn_part(to_nchw(out), po)
 
 
 class Downsample(nn.Module):
@@ -122,7 +126,8 @@ class Downsample(nn.Module):
     def forward(self, x):
         xh = to_nhwc(x)
         H, W = xh.shape[1:3]
-        return to_nchw(ops.conv3x3(xh, self.conv.w(), self.conv.b32(), stride=2, pad=(0, 0), out_hw=(H // 2, W // 2)))
+        out, po = ops.conv3x3(xh, self.conv.w(), self.conv.b32(), stride=2, pad=(0, 0), out_hw=(H // 2, W // 2), gn_part=True)
+        return attach_gn_part(to_nchw(out), po)
 
 
 class _Level(nn.Module):
@@ -168,7 +173,7 @@ class Encoder(nn.Module):
             if i_level != self.num_resolutions - 1:
                 h = self.down[i_level].downsample(h)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
-        hn = ops.groupnorm(to_nhwc(h), self.norm_out.g32(), self.norm_out.b32(), self.norm_out.eps, silu=True)
+        hn = ops.groupnorm(to_nhwc(h), self.norm_out.g32(), self.norm_out.b32(), self.norm_out.eps, silu=True, part=gn_part_of(h))
         return ops.conv3x3_smallcout(hn, self.conv_out.w9(), self.conv_out.b32())
 
 
@@ -210,7 +215,7 @@ class Decoder(nn.Module):
                 h = blk(h)
             if i_level != 0:
                 h = self.up[i_level].upsample(h)
-        hn = ops.groupnorm(to_nhwc(h), self.norm_out.g32(), self.norm_out.b32(), self.norm_out.eps, silu=True)
+        hn = ops.groupnorm(to_nhwc(h), self.norm_out.g32(), self.norm_out.b32(), self.norm_out.eps, silu=True, part=gn_part_of(h))
         return ops.conv3x3_smallcout(hn, self.conv_out.w9(), self.conv_out.b32())
 
 

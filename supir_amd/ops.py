@@ -328,11 +328,12 @@ def _pf_group(ws):
 # --------------------------------------------------------------------------------------------- GroupNorm statistics from producers
 class GnPart:
     """What a producer GEMM / conv epilogue left behind for a GroupNorm over its output (supir_launch_hints.gn_partials_out): fp32
-    [B, nchunk, C // 10, 2] = (sum, sum of squares) per batch, tile row and 10-channel unit of the bf16 values it stored."""
-    __slots__ = ("buf", "nchunk", "C")
+    [B, nchunk, C // unit, 2] = (sum, sum of squares) per batch, tile row and `unit`-channel unit of the bf16 values it stored.
+    unit = 10 from the 80 / 160-column tiles (UNet / control net), 4 from the 128 / 256-column tiles 39 / 40 (VAE)."""
+    __slots__ = ("buf", "nchunk", "C", "unit")
 
-    def __init__(self, buf, nchunk, C):
-        self.buf, self.nchunk, self.C = buf, nchunk, C
+    def __init__(self, buf, nchunk, C, unit=10):
+        self.buf, self.nchunk, self.C, self.unit = buf, nchunk, C, unit
 
 
 USE_GN_PARTS = _os.environ.get("SUPIR_GN_PARTS", "1") != "0"   # producers emit GroupNorm statistics where the kernels support it
@@ -342,16 +343,19 @@ def _gn_part_alloc(tile, nbatch, rows_per_batch, N, device):
     """The buffer a launch on `tile` fills with GroupNorm partials of its output, if that tile can emit them; returns the GnPart
     or None.  (The request itself travels with the launch: supir_launch_hints.gn_partials_out for a single launch, the
     problem's gn_partials_out field for a grouped one.)"""
-    if not USE_GN_PARTS or tile not in _G16 or tile in _G16_PLAIN_ONLY:
+    if not USE_GN_PARTS or tile not in _G16:
         return None
     bm = _G16[tile][0]
-    if rows_per_batch <= 0 or rows_per_batch % bm or N % 10:
+    unit = 4 if tile in _G16_PLAIN_ONLY else 10     # csrc/gemm16.hip: GU by the tile's column count
+    if rows_per_batch <= 0 or rows_per_batch % bm or N % unit:
         return None
+    if unit == 4 and ((N // 32) % 4 or N % 32 or _DEFER is not None):
+        return None                                   # VAE form: whole groups of 4-channel units; never inside paired_run
     nchunk = rows_per_batch // bm
     # recorded launches (paired_run) may be re-timed on other tiles of the family before they are issued: room for the finest tile rows
     alloc = max(nchunk, rows_per_batch // 128) if _DEFER is not None else nchunk
-    buf = torch.empty(nbatch, alloc, N // 10, 2, dtype=torch.float32, device=device)
-    return GnPart(buf, nchunk, N)
+    buf = torch.empty(nbatch, alloc, N // unit, 2, dtype=torch.float32, device=device)
+    return GnPart(buf, nchunk, N, unit)
 
 
 # --------------------------------------------------------------------------------------------- deferred issue / paired launches
@@ -1240,7 +1244,17 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
         _, Cm, ldm = _rows_ld(mod_g)
         _, Cm2, ldm2 = _rows_ld(mod_b)
         assert Cm == C and Cm2 == C and ldm == ldm2
-    use_parts = (part is not None and given is None and (x2 is None or part2 is not None) and (C // 32) % 10 == 0 and C1 % 10 == 0
+    if (part is not None and part.unit != 10 and given is None and x2 is None and part.C == C and part.buf.shape[0] == B
+            and (C // 32) % part.unit == 0 and _DEFER is None):
+        # VAE form (4-channel units from tiles 39 / 40, thousands of tile rows): one small launch reduces them to (mean, variance) per
+        # group, the apply pass takes those as `given` -- no pass over the tensor for its statistics
+        given = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
+        ev = _ev()
+        _lib.check(lib.supir_groupnorm_parts_finalize(part.buf.data_ptr(), B, part.nchunk, C, part.unit, HW, given.data_ptr(), _stream()),
+                   "supir_groupnorm_parts_finalize", lib)
+        _rec("groupnorm_parts_finalize", 0, 8.0 * B * part.nchunk * (C // part.unit), ev, B=B, C=C, nchunk=part.nchunk)
+    use_parts = (part is not None and part.unit == 10 and given is None and (x2 is None or part2 is not None) and (C // 32) % 10 == 0
+                 and C1 % 10 == 0 and (part2 is None or part2.unit == 10)
                  and part.C == C1 and part.buf.shape[0] == B and (part2 is None or (part2.C == C - C1 and part2.buf.shape[0] == B)))
     act = 1 if silu else 0
     # own statistics: partial-sum workspace.  Recorded launches may run two to a grid (paired_run): each gets its own.

@@ -798,9 +798,26 @@ def test_gemm16_vae_tiles_conv3x3(case, tile):
     res = rnd(B, OH, OW, Cout, seed=5).to(BF)
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, residual=res, act=1, alpha=0.5, tile=tile)
     check(out, 0.5 * F.silu(ref) + res.float(), name="conv16 epilogue")
-    # the request for GroupNorm partials is answered with "cannot" (None), not with a refused launch
-    o2, part = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile, gn_part=True)
-    assert part is None and torch.equal(o2, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile))
+    # GroupNorm statistics from the epilogue, in 4-channel units (the VAE's groups are 4 / 8 / 16 channels wide): the partials
+    # themselves, the request leaving the output untouched, supir_groupnorm_parts_finalize -> `given` -> one apply launch against torch
+    # and against the two-launch path, repeatability, in place (ResnetBlock.norm2, model.py:136-139)
+    y = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, residual=res, tile=tile)
+    y2, part = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, residual=res, tile=tile, gn_part=True)
+    assert part is not None and part.unit == 4 and part.C == Cout and torch.equal(y, y2)
+    yf = y.double().view(B, OH * OW // 256, 256, Cout // 4, 4)
+    ref_part = torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
+    assert part.buf.shape == ref_part.shape
+    assert torch.allclose(part.buf.double(), ref_part, rtol=2e-5, atol=2e-3), (part.buf.double() - ref_part).abs().max()
+    g, b_ = rnd(Cout, seed=6) * 0.2 + 1.0, rnd(Cout, seed=7) * 0.2
+    o_parts = ops.groupnorm(y, g, b_, 1e-6, silu=True, part=part)
+    o_two = ops.groupnorm(y, g, b_, 1e-6, silu=True)
+    gn = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, g, b_, 1e-6)).permute(0, 2, 3, 1)
+    check(o_parts, gn, name="gn from 4-channel conv partials")
+    check(o_parts, o_two.float(), rel=1e-3, name="gn partials vs two-launch")
+    assert torch.equal(o_parts, ops.groupnorm(y, g, b_, 1e-6, silu=True, part=part))
+    yc = y.clone()
+    ops.groupnorm(yc, g, b_, 1e-6, silu=True, out=yc, part=part)
+    assert torch.equal(yc, o_parts)
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (1024, 256, 128), (512, 128, 256), (16384, 512, 512)])
@@ -822,6 +839,15 @@ def test_gemm16_vae_tiles_plain(M, N, K, tile):
     acc = res.clone()
     ops.gemm(a, w, bias, residual=acc, out=acc, tile=tile)                          # in-place residual (x += f(x))
     check(acc, base + res.float(), name="in-place residual")
+    if N % 128 == 0 and M % 512 == 0:   # partials from a plain GEMM (AttnBlock.proj_out + residual, model.py:192), two batch elements
+        y, part = ops.gemm(a, w, bias, residual=res, rows_per_batch=M // 2, tile=tile, gn_part=True)
+        assert part is not None and part.unit == 4 and part.nchunk == M // 2 // 256
+        yf = y.double().view(2, M // 2 // 256, 256, N // 4, 4)
+        assert torch.allclose(part.buf.double(), torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1), rtol=2e-5, atol=2e-3)
+        g, b_ = rnd(N, seed=6) * 0.2 + 1.0, rnd(N, seed=7) * 0.2
+        yv = y.view(2, M // 2, N)
+        check(ops.groupnorm(yv, g, b_, 1e-6, part=part), F.group_norm(yv.float().permute(0, 2, 1), 32, g, b_, 1e-6).permute(0, 2, 1),
+              name="gn from 4-channel gemm partials")
     from supir_amd._lib import SupirHipError
     with pytest.raises(SupirHipError):
         ops.gemm_t(a.view(1, M, K), w, None, 1, M, M, tile=tile)                   # no transposed form

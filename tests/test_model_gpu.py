@@ -204,6 +204,47 @@ def test_vae_vs_reference_golden(g):
     assert rel_l2(z, g["vae_z"]) <= 2e-2
 
 
+def test_vae_groupnorm_statistics_from_the_conv_epilogues():
+    """The VAE with its convolutions on tiles 39 / 40 of csrc/gemm16.hip and every Normalize (model.py:48-51) taking its statistics from
+    the producing epilogue (4-channel unit partials -> supir_groupnorm_parts_finalize -> `given`) against the same network with the
+    statistics passes (SUPIR_GN_PARTS off): decoder image and encoder moments at 256 px, where every feature map is a whole number of
+    256-pixel tile rows.  Also counts that the producer path is really taken."""
+    from supir_amd import ops
+    vae = build_vae(DEV)
+    z = T("z_gn", (1, 4, 32, 32))
+    img = T("img_gn", (1, 3, 256, 256), scale=0.5)
+    saved_tune, saved_flag = dict(ops._TUNE), ops.USE_GN_PARTS
+
+    def run():
+        with torch.no_grad():
+            return vae.decoder(vae.post_quant_conv(z)).float(), vae.quant_conv(vae.encoder(img)).float()
+
+    try:
+        ops.USE_GN_PARTS = False
+        ref_x, ref_m = run()
+        # force the new tiles wherever they fit (the autotuner would pick gemm.hip tiles for some of these small maps)
+        run()
+        for k in [k for k in ops._TUNE if k[0] == "conv" and len(k) == 8]:
+            _, Bc, H, W, Cin, Cout, stride, up = k
+            M = Bc * (4 * H * W if up else H * W // (stride * stride))
+            if Cin % 64 == 0 and M % 256 == 0 and Cout % 128 == 0 and Cout % 80:
+                ops._TUNE[k] = 40 if Cout % 256 == 0 else 39
+        ops.USE_GN_PARTS = True
+        tr = ops.start_trace()
+        x, m = run()
+        ops.stop_trace()
+    finally:
+        ops._TUNE.clear()
+        ops._TUNE.update(saved_tune)
+        ops.USE_GN_PARTS = saved_flag
+    n_fin = sum(1 for r in tr if r["kernel"] == "groupnorm_parts_finalize")
+    n_gn = sum(1 for r in tr if r["kernel"] == "groupnorm")
+    e_x, e_m = rel_l2(x, ref_x), rel_l2(m, ref_m)
+    print(f"vae with producer statistics: {n_fin} of {n_gn} GroupNorms; decoder {e_x:.3e}, encoder moments {e_m:.3e} vs statistics passes")
+    assert n_fin >= 0.8 * n_gn, (n_fin, n_gn)
+    assert e_x <= 1e-2 and e_m <= 1e-2
+
+
 def test_full_depth_wrapper_vs_oracle_on_device():
     """Full SDXL-sized model ([1,2,10] transformer depth, 3.9 G parameters) at latent 32x32: HIP path vs the oracle run in
     fp32 on the same device (the oracle is only the checker here), with the ATen-autocast bf16 floor measured beside it."""
