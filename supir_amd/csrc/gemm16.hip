@@ -816,17 +816,33 @@ int supir_gemm16_launch_n(const GemmArgs* a, int n, hipStream_t st, int tile, bo
     }
 }
 
-// fused q|k|v projection on tile 34 (256 x 160): columns [0, n_split) -> C (normal epilogue), [n_split, N) -> C2 transposed
-static int g16_qkv_check(const GemmArgs& a) {
-    if (a.M % 256 || a.N % 160 || a.n_split % 160 || a.n_split <= 0 || a.n_split >= a.N || a.K % 64 || (a.K >> 6) < 2) return SUPIR_ERR_SHAPE;
+// fused q|k|v projection: columns [0, n_split) -> C (normal epilogue), [n_split, N) -> C2 transposed.  Two tile widths, 256 x 160 (tile 34's
+// loop, eight waves as 8 x 1) and 256 x 128 (tile 39's, 4 x 2): the launch takes the one with fewer rounds-of-256-workgroups x columns.
+// (2048, 3840, 1280) -- the 1280-wide SpatialTransformers at 32^2 -- is 192 tiles of 256 x 160 (64 CUs idle) or 240 of 256 x 128, each
+// 0.8 x the work: one round either way.  Same K order per output element: bitwise-equal results.
+static int g16_qkv_check(const GemmArgs& a, int bn) {
+    if (a.M % 256 || a.N % bn || a.n_split % bn || a.n_split <= 0 || a.n_split >= a.N || a.K % 64 || (a.K >> 6) < 2) return SUPIR_ERR_SHAPE;
     if (a.lda % 8 || a.ldc % 8 || (((size_t)a.C) & 15) || a.ldc2 % 4 || a.rows_per_batch % 4 || a.ln_slots > 32) return SUPIR_ERR_SHAPE;
     if (a.act != 0 || a.out_mode != 0 || a.res || a.rowbias || a.rowstats_out || !a.C2) return SUPIR_ERR_ARG;
     return SUPIR_OK;
 }
 
+// knob 4 (tools only): 1 forces 160 columns, 2 forces 128 where both fit
+static int g16_qkv_bn(const GemmArgs& a) {
+    const bool ok160 = a.N % 160 == 0 && a.n_split % 160 == 0, ok128 = a.N % 128 == 0 && a.n_split % 128 == 0;
+    if (!ok128 || !ok160) return ok128 ? 128 : 160;
+    const int knob = supir_debug_knob_value(4);
+    if (knob == 1 || knob == 2) return knob == 1 ? 160 : 128;
+    const long tm = a.M / 256;
+    const long c160 = ((tm * (a.N / 160) + 255) / 256) * 160, c128 = ((tm * (a.N / 128) + 255) / 256) * 128;
+    return c128 < c160 ? 128 : 160;
+}
+
 int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st) {
-    const int rc = g16_qkv_check(a);
+    const int bn = g16_qkv_bn(a);
+    const int rc = g16_qkv_check(a, bn);
     if (rc != SUPIR_OK) return rc;
+    if (bn == 128) return launch_gemm16<256, 128, 4, 2, 1, 3, false, false, true>(&a, st);
     if (supir_debug_knob_value(1)) return launch_gemm16<256, 160, 4, 2, 1, 3, false, false, true>(&a, st);
     return launch_gemm16<256, 160, 8, 1, 1, 3, false, false, true>(&a, st);
 }
@@ -835,7 +851,7 @@ int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st) {
     if (n == 1) return supir_gemm16_qkv_launch(a[0], st);
     if (n != 2) return SUPIR_ERR_SHAPE;
     for (int q = 0; q < 2; ++q) {
-        const int rc = g16_qkv_check(a[q]);
+        const int rc = g16_qkv_check(a[q], 160);
         if (rc != SUPIR_OK) return rc;
     }
     if (!g16_same_shape(a[0], a[1])) return SUPIR_ERR_SHAPE;

@@ -854,8 +854,9 @@ USE_QKV = _os.environ.get("SUPIR_FUSED_QKV", "1") != "0"
 
 
 def gemm_qkv_supported(M, N, n_split, K, T):
-    """Shape predicate of supir_gemm_bf16_qkv (256 x 160 tile of csrc/gemm16.hip)."""
-    return (USE_QKV and USE_GEMM16 and 34 in G16_TILES and M % 256 == 0 and N % 160 == 0 and n_split % 160 == 0 and 0 < n_split < N
+    """Shape predicate of supir_gemm_bf16_qkv (256 x 160 or 256 x 128 tile of csrc/gemm16.hip)."""
+    fits = (N % 160 == 0 and n_split % 160 == 0) or (N % 128 == 0 and n_split % 128 == 0)
+    return (USE_QKV and USE_GEMM16 and 34 in G16_TILES and M % 256 == 0 and fits and 0 < n_split < N
             and K % 64 == 0 and K >= 128 and T % 4 == 0)
 
 

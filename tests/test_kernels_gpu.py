@@ -882,6 +882,19 @@ def test_gemm_qkv_fused(B, T, C):
     check(vt, refn[:, 2 * inner:].view(B, T, inner).permute(0, 2, 1), rel=6e-3, name="qkv ln: v^T")
     sep = ops.gemm_ln(x, wf[:2 * inner].contiguous(), bf_[:2 * inner].contiguous(), ln=st, colsum=cs[:2 * inner].contiguous())
     check(qk.view(M, 2 * inner), sep.float(), rel=3e-3, name="qkv vs separate")
+    # the two tile widths of the fused launch (256 x 160 / 256 x 128; the launch takes the one with fewer workgroup rounds x columns)
+    # accumulate every output element over K in the same order: forced either way (tools-only knob 4) the results are bitwise equal
+    if (3 * inner) % 160 == 0 and (3 * inner) % 128 == 0:
+        from supir_amd import _lib
+        lib, got = _lib.load(BF), []
+        try:
+            for width in (1, 2):
+                lib.supir_debug_knob(4, width)
+                got.append(ops.gemm_qkv(x, wf, bf_, B, T, 2 * inner, ln=st, colsum=cs))
+        finally:
+            lib.supir_debug_knob(4, 0)
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+        assert torch.equal(got[0][0], qk) and torch.equal(got[0][1], vt)
 
 
 @pytest.mark.parametrize("tile", [-1, 3, 32])

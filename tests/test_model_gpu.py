@@ -206,43 +206,76 @@ def test_vae_vs_reference_golden(g):
 
 def test_vae_groupnorm_statistics_from_the_conv_epilogues():
     """The VAE with its convolutions on tiles 39 / 40 of csrc/gemm16.hip and every Normalize (model.py:48-51) taking its statistics from
-    the producing epilogue (4-channel unit partials -> supir_groupnorm_parts_finalize -> `given`) against the same network with the
-    statistics passes (SUPIR_GN_PARTS off): decoder image and encoder moments at 256 px, where every feature map is a whole number of
-    256-pixel tile rows.  Also counts that the producer path is really taken."""
-    from supir_amd import ops
+    the producing epilogue (4-channel unit partials -> supir_groupnorm_parts_finalize -> `given`), at 256 px (every feature map a whole
+    number of 256-pixel tile rows).  Checked: the producer path is really taken; every producer statistic against fp64 torch over the
+    tensor (rstd to 1e-6 -- the statistics pass it replaces is no closer); and end to end.  The random-weight VAE amplifies a 3e-8
+    perturbation of one statistic to ~1e-2 at the output (profiles/r04/diag_vae_groupnorm_statistics_1024px.log), so the end-to-end bar
+    is relative: the producer path must sit as close to a run with fp64-exact statistics as the statistics-pass path does."""
+    from supir_amd import _lib, ops
     vae = build_vae(DEV)
     z = T("z_gn", (1, 4, 32, 32))
     img = T("img_gn", (1, 3, 256, 256), scale=0.5)
-    saved_tune, saved_flag = dict(ops._TUNE), ops.USE_GN_PARTS
+    saved_tune, saved_flag, real_gn = dict(ops._TUNE), ops.USE_GN_PARTS, ops.groupnorm
+    mode, errs = ["plain"], []
+
+    def truth(x):
+        Bx, C = x.shape[0], x.shape[-1]
+        gx = x.double().reshape(Bx, -1, 32, C // 32)
+        mean = gx.mean(dim=(1, 3))
+        return mean, ((gx * gx).mean(dim=(1, 3)) - mean * mean).clamp_min(0)
+
+    def gn(x, gamma, beta, eps, **kw):
+        part = kw.get("part")
+        if mode[0] == "truth":
+            kw = {k: v for k, v in kw.items() if k != "part"}
+            m, v = truth(x)
+            return real_gn(x, gamma, beta, eps, given=torch.stack([m, v], -1).float().contiguous(), **kw)
+        if mode[0] == "check" and part is not None and part.unit == 4:
+            Bx, C = x.shape[0], x.shape[-1]
+            HW = x.numel() // (Bx * C)
+            giv = torch.empty(Bx, 32, 2, dtype=torch.float32, device=x.device)
+            lib = _lib.load(x.dtype)
+            _lib.check(lib.supir_groupnorm_parts_finalize(part.buf.data_ptr(), Bx, part.nchunk, C, part.unit, HW, giv.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), "finalize", lib)
+            m, v = truth(x)
+            r, r3 = 1.0 / torch.sqrt(v + eps), 1.0 / torch.sqrt(giv[..., 1].double() + eps)
+            errs.append((((r3 - r).abs() / r).max().item(), ((giv[..., 0].double() - m).abs() / v.sqrt()).max().item()))
+        return real_gn(x, gamma, beta, eps, **kw)
 
     def run():
         with torch.no_grad():
             return vae.decoder(vae.post_quant_conv(z)).float(), vae.quant_conv(vae.encoder(img)).float()
 
     try:
+        ops.groupnorm = gn
         ops.USE_GN_PARTS = False
-        ref_x, ref_m = run()
-        # force the new tiles wherever they fit (the autotuner would pick gemm.hip tiles for some of these small maps)
-        run()
+        off_x, off_m = run()
+        # force the new tiles wherever they fit (the autotuner picks gemm.hip tiles for some of these small maps)
         for k in [k for k in ops._TUNE if k[0] == "conv" and len(k) == 8]:
             _, Bc, H, W, Cin, Cout, stride, up = k
             M = Bc * (4 * H * W if up else H * W // (stride * stride))
             if Cin % 64 == 0 and M % 256 == 0 and Cout % 128 == 0 and Cout % 80:
                 ops._TUNE[k] = 40 if Cout % 256 == 0 else 39
         ops.USE_GN_PARTS = True
+        mode[0] = "check"
         tr = ops.start_trace()
-        x, m = run()
+        on_x, on_m = run()
         ops.stop_trace()
+        mode[0] = "truth"
+        tr_x, tr_m = run()
     finally:
+        ops.groupnorm = real_gn
         ops._TUNE.clear()
         ops._TUNE.update(saved_tune)
         ops.USE_GN_PARTS = saved_flag
     n_fin = sum(1 for r in tr if r["kernel"] == "groupnorm_parts_finalize")
     n_gn = sum(1 for r in tr if r["kernel"] == "groupnorm")
-    e_x, e_m = rel_l2(x, ref_x), rel_l2(m, ref_m)
-    print(f"vae with producer statistics: {n_fin} of {n_gn} GroupNorms; decoder {e_x:.3e}, encoder moments {e_m:.3e} vs statistics passes")
-    assert n_fin >= 0.8 * n_gn, (n_fin, n_gn)
-    assert e_x <= 1e-2 and e_m <= 1e-2
+    e_on, e_off = max(rel_l2(on_x, tr_x), rel_l2(on_m, tr_m)), max(rel_l2(off_x, tr_x), rel_l2(off_m, tr_m))
+    print(f"vae with producer statistics: {n_fin} of {n_gn} GroupNorms; worst rstd error {max(e[0] for e in errs):.2e}, worst mean error "
+          f"{max(e[1] for e in errs):.2e} std; vs a run on fp64 statistics: producer path {e_on:.3e}, statistics passes {e_off:.3e}")
+    assert n_fin >= 0.8 * n_gn and len(errs) == n_fin, (n_fin, n_gn, len(errs))
+    assert max(e[0] for e in errs) <= 1e-6 and max(e[1] for e in errs) <= 1e-6
+    assert e_on <= 2.0 * e_off + 2e-3 and e_on <= 5e-2
 
 
 def test_full_depth_wrapper_vs_oracle_on_device():

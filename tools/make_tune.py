@@ -12,8 +12,13 @@ from supir_amd import ops  # noqa: E402
 from tests.helpers import build_unet, build_vae, synth_tensor  # noqa: E402
 
 dev = "cuda"
-out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "tune_gfx950.json")
-wrap = build_unet(device=dev)
+# --vae-only: re-time the VAE's shapes alone (from an empty state, so new tile candidates get their chance) and overlay the picks on
+# the packaged file -- every other pick stays what it was
+VAE_ONLY = "--vae-only" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--vae-only"]
+packaged = os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "tune_gfx950.json")
+out_path = argv[0] if argv else packaged
+wrap = None if VAE_ONLY else build_unet(device=dev)
 
 
 def net_call(B, lat, dtype=torch.bfloat16, reps=2):
@@ -32,12 +37,13 @@ def net_call(B, lat, dtype=torch.bfloat16, reps=2):
 
 
 with torch.no_grad():
-    net_call(2, 128)                      # config 2 (the bench): one 1024^2 image, CFG-doubled
-    net_call(8, 128)                      # 4 images per call / tile_batch 4 of the tiled sampler (config 3)
-    net_call(2, 64)                       # config 1 (512^2)
-    net_call(2, 128, torch.float16)       # config 5 (diff_dtype fp16)
-    net_call(2, 32)                       # the reduced-size shapes the test suite uses
-    net_call(2, 16)
+    if not VAE_ONLY:
+        net_call(2, 128)                      # config 2 (the bench): one 1024^2 image, CFG-doubled
+        net_call(8, 128)                      # 4 images per call / tile_batch 4 of the tiled sampler (config 3)
+        net_call(2, 64)                       # config 1 (512^2)
+        net_call(2, 128, torch.float16)       # config 5 (diff_dtype fp16)
+        net_call(2, 32)                       # the reduced-size shapes the test suite uses
+        net_call(2, 16)
     vae = build_vae(dev)
     for px in (1024, 512):
         img = synth_tensor("img", (1, 3, px, px), scale=0.5).to(dev)
@@ -47,5 +53,16 @@ with torch.no_grad():
         vae.quant_conv(vae.encoder(img))
         torch.cuda.synchronize()
         print(f"  VAE {px}px: {len(ops._TUNE)} tile picks", flush=True)
+if VAE_ONLY:
+    fresh_t, fresh_c = dict(ops._TUNE), dict(ops._CHOICE)
+    ops._TUNE.clear()
+    ops._CHOICE.clear()
+    ops.load_tuning(packaged)
+    changed = {k: (ops._TUNE.get(k), v) for k, v in fresh_t.items() if ops._TUNE.get(k) != v}
+    print(f"  overlay on {packaged}: {len(fresh_t)} VAE picks, {len(changed)} differ from the packaged ones", flush=True)
+    for k, (old, new) in sorted(changed.items(), key=repr):
+        print("   ", k, old, "->", new, flush=True)
+    ops._TUNE.update(fresh_t)
+    ops._CHOICE.update(fresh_c)
 ops.save_tuning(out_path)
 print("wrote", out_path, len(ops._TUNE), "tile picks,", len(ops._CHOICE), "choices")

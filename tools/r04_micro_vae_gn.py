@@ -54,6 +54,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from tests.helpers import build_vae   # noqa: E402
 from supir_amd.synth import synth_tensor   # noqa: E402
 
+# the packaged picks predate tiles 39 / 40: let the VAE's shapes be timed again on this box
+for k in [k for k in ops._TUNE if k[0] in ("conv", "gemm") and (k[5] if k[0] == "conv" else k[2]) in (128, 256, 512)]:
+    del ops._TUNE[k]
 vae = build_vae(dev)
 img = synth_tensor("bench.vae", (1, 3, 1024, 1024), scale=0.5).clamp(-1, 1).to(dev)
 

@@ -60,6 +60,7 @@ def configure(v):
     lib.supir_debug_knob(0, 1 if v == "base" else 0)
     lib.supir_debug_knob(1, 1 if "w42" in v else 0)
     lib.supir_debug_knob(2, 1 if "gn1" in v else 2 if "gn2" in v else 0)
+    lib.supir_debug_knob(4, 1 if "qkv160" in v else 0)   # qkv160: the fused q|k|v launch on its 256 x 160 tile wherever that fits (the round-3 form)
     lib.supir_debug_knob(3, 1 if "attn3" in v else 3 if "attn4w" in v else 0)   # attn3: round-3 kernel; attn4w: four waves everywhere
     if v in ("t38", "t38k1280"):
         ops.G16_TILES = {32, 33, 34, 35, 38}
@@ -96,7 +97,7 @@ with torch.no_grad():
             outs[v] = o.clone()
             print(f"rep{rep} {v}: {ms:.3f} ms/step", flush=True)
     wrap.enable_graph(False)
-for kn in range(4):
+for kn in range(5):
     lib.supir_debug_knob(kn, 0)
 ref = outs[variants[0]]
 for v in variants[1:]:
