@@ -193,6 +193,20 @@ int supir_xattn_q_d64(const void* X, const void* Wq, const float* bias, const vo
 int supir_flash_attn_d512(const void* Q, const void* K, const void* Vt, void* O, int B, int Tq, int Tk, int ldq, int ldk, int ldvt,
                           int ldo, float scale, void* stream);
 
+/* The same attention with the KEYS split over `splits` sets of workgroups and a fixed-order merge (reproducible; the result differs from
+ * supir_flash_attn_d512's by fp32 rounding of the merge only).  A launch of supir_flash_attn_d512 has B * ceil(Tq / 128) workgroups --
+ * 128 for the mid block of a 1024^2 image (16 384 tokens), 32 for a 512^2 image or a tiled-VAE tile (SUPIR/utils/tilevae.py:276,335) --
+ * on a 256-CU part; split s attends to its own range of 32-key tiles with its own exact row maxima and leaves a normalised fp32
+ * partial output plus (maximum, sum) per query row in `workspace`, a second kernel merges them.
+ *   splits <= 0: chosen by the library (as many as bring the grid to <= 256 workgroups, >= 256 keys each, <= 16; 1 from 192 workgroups up);
+ *   splits >= 1: that many (clamped to 16 and to the number of key tiles).
+ * supir_flash_attn_d512_workspace(B, Tq, Tk, splits) = bytes the call needs for the same arguments (0 when it resolves to one split: the
+ * call is then supir_flash_attn_d512 and `workspace` may be NULL).  workspace: device memory, 16-byte aligned, contents undefined
+ * before and after.  A workspace smaller than required, or NULL when one is required, returns SUPIR_ERR_ARG. */
+size_t supir_flash_attn_d512_workspace(int B, int Tq, int Tk, int splits);
+int supir_flash_attn_d512_split(const void* Q, const void* K, const void* Vt, void* O, int B, int Tq, int Tk, int ldq, int ldk, int ldvt,
+                                int ldo, float scale, int splits, void* workspace, size_t workspace_bytes, void* stream);
+
 /* P[r][:] = softmax(S[r][:] * scale): fp32 scores -> bf16 probabilities (VAE mid-block single-head attention,
  * sgm/modules/diffusionmodules/model.py:177-192, 228-256; the score matrix itself comes from supir_gemm_bf16).
  * Columns [T, Tpad) (K padding of the following P.V GEMM) are written as zeros. */

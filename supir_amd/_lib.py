@@ -93,8 +93,13 @@ SIGNATURES.update({
     "supir_conv3x3_bf16_splitk": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "supir_splitk_finalize": [P, I, I, I, P, I, P, I, P],
     "supir_flash_attn_d64_grouped": [P, I, I, I, I, F, P],
+    # Q, K, Vt, O, B, Tq, Tk, ldq, ldk, ldvt, ldo, scale, splits, workspace, workspace_bytes, stream
+    "supir_flash_attn_d512_split": [P, P, P, P, I, I, I, I, I, I, I, F, I, P, c_size_t, P],
     "supir_groupnorm_grouped": [P, I, I, I, I, F, I, P],
 })
+
+# entry points that return a byte count (size_t) instead of a status
+SIZE_SIGNATURES = {"supir_flash_attn_d512_workspace": [I, I, I, I]}
 
 _lib = None       # the bf16 library (the product default)
 _lib_f16 = None   # the fp16 build, loaded on first use
@@ -127,6 +132,10 @@ def load(dtype=None):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int
+    for name, argtypes in SIZE_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_size_t
     lib.supir_last_hip_error.restype = c_int
     lib.supir_last_hip_error.argtypes = []
     lib.supir_hip_error_string.restype = c_char_p

@@ -262,7 +262,17 @@ int supir_flash_attn_d512(const void* Q, const void* K, const void* Vt, void* O,
                           int ldo, float scale, void* stream) {
     if (!Q || !K || !Vt || !O) return SUPIR_ERR_ARG;
     return supir_attn_d512_launch((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, B, Tq, Tk, ldq, ldk, ldvt, ldo,
-                                  scale, (hipStream_t)stream);
+                                  scale, 1, nullptr, 0, (hipStream_t)stream);
+}
+
+size_t supir_flash_attn_d512_workspace(int B, int Tq, int Tk, int splits) { return supir_attn_d512_workspace_bytes(B, Tq, Tk, splits); }
+
+int supir_flash_attn_d512_split(const void* Q, const void* K, const void* Vt, void* O, int B, int Tq, int Tk, int ldq, int ldk, int ldvt,
+                                int ldo, float scale, int splits, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!Q || !K || !Vt || !O) return SUPIR_ERR_ARG;
+    if (!workspace && supir_attn_d512_workspace_bytes(B, Tq, Tk, splits) != 0) return SUPIR_ERR_ARG;
+    return supir_attn_d512_launch((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, B, Tq, Tk, ldq, ldk, ldvt, ldo,
+                                  scale, splits, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int supir_softmax_rows(const float* S, void* P, int rows, int T, int Tpad, long ld_s, long ld_p, float scale,

@@ -43,12 +43,17 @@ struct Attn512Args {
     int B, Tq, Tk;
     int ldq, ldk, ldvt, ldo;
     float scale_log2e;
+    // key-split form (SPLIT): workgroup (b, qb, sp) attends to key tiles [sp * tps, min(nt, (sp + 1) * tps)) only and leaves its
+    // normalised fp32 output and (row maximum, row sum) in the workspace; attn_d512_combine_kernel merges the splits
+    int nsplit, tps;
+    float* part;   // [nsplit][B][Tq][512] fp32
+    float* ml;     // [nsplit][B][Tq][2]  (m in raw score units, l)
 };
 
 constexpr int KT = 32;              // keys per tile
 constexpr int STAGE_BYTES = 65536;  // K tile (32 KB) + V^T tile (32 KB)
 
-template <int NW>
+template <int NW, bool SPLIT>
 __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages
     constexpr int QB = 32 * NW;
@@ -56,7 +61,11 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     const int half = lane >> 5, l31 = lane & 31;
 
     const int nqb = (p.Tq + QB - 1) / QB;
-    const int b = blockIdx.x / nqb, qb = blockIdx.x - b * nqb;
+    // SPLIT: the splits of one query block are neighbouring block ids (different XCDs); the query blocks that share a key range follow
+    // each other at stride nsplit, i.e. on the same XCD whenever nsplit divides 8
+    const int sp = SPLIT ? (int)(blockIdx.x % (unsigned)p.nsplit) : 0;
+    const int bq = SPLIT ? (int)(blockIdx.x / (unsigned)p.nsplit) : (int)blockIdx.x;
+    const int b = bq / nqb, qb = bq - b * nqb;
     const char* Kb = (const char*)(p.K + (size_t)b * p.Tk * p.ldk);
     const char* Vb = (const char*)(p.Vt + (size_t)b * 512 * p.ldvt);
 
@@ -66,6 +75,9 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     const bf16_t* Qp = p.Q + ((size_t)b * p.Tq + qc) * p.ldq + 8 * half;
     const float c = p.scale_log2e;
     const int nt = (p.Tk + KT - 1) / KT;
+    // this workgroup's key tiles [t_lo, t_hi) (never empty: the launcher sizes nsplit so that (nsplit - 1) * tps < nt)
+    const int t_lo = SPLIT ? sp * p.tps : 0;
+    const int t_hi = SPLIT ? (t_lo + p.tps < nt ? t_lo + p.tps : nt) : nt;
 
     // ---- loader: one wave-instruction moves 1 KB.  K: instruction r = key row r of the tile (64 chunks of 16 B); the lane
     // that fills LDS chunk position `lane` fetches logical chunk lane ^ (r & 15).  V^T: instruction i = channel rows
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
 #pragma unroll
     for (int t0 = 0; t0 < 3; ++t0)
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) stage_k(t0, t0 * K_SLOT, i);
+        for (int i = 0; i < LPT; ++i) stage_k(t_lo + t0, t0 * K_SLOT, i);
 
     const int klast = p.Tk - 1;
     // S^T = K.Q^T + c0 (c0 = -m of this lane's query, or 0) for the tile in stage `sb`, keys past the end -> -inf.  Eight groups of four k steps: the fragments of
@@ -167,15 +179,16 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     // LDS once more, from L2 -- and the main pass runs with a fixed m: no rescale, P <= 1, l >= 1, no overflow cases.
     {
         float mx = -INFINITY;
-        for (int t = 0; t < nt; ++t) {
+        for (int t = t_lo; t < t_hi; ++t) {
+            const int u = t - t_lo;   // position in the ring
             // loads complete in issue order: all but the two newest tiles' have landed, i.e. Q and tile t.  The first version
             // of this kernel issued a tile's loads DURING the previous tile and then waited for vmcnt(0): the full L2 latency
             // sat on the critical path of every tile (measured 10.6 k cycles per tile against 3 k of MFMA work).
             d512_wait_vmcnt<2 * LPT>();
             __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done with tile t-1, whose slot takes tile t+3
             asm volatile("" ::: "memory");
-            const int nslot = ((t + 3) & 3) * K_SLOT;
-            const f32x16 s = scores(smem + (t & 3) * K_SLOT, nm, t, [&](int g) {
+            const int nslot = ((u + 3) & 3) * K_SLOT;
+            const f32x16 s = scores(smem + (u & 3) * K_SLOT, nm, t, [&](int g) {
                 if (g < 4) {   // past the end the loader re-reads the last tile into a slot nobody reads: the count stays uniform
 #pragma unroll
                     for (int i = g * LPT / 4; i < (g + 1) * LPT / 4; ++i) stage_k(t + 3, nslot, i);
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
         }
-        nm = -d512_xhalf_max(mx);   // finite: key 0 is visible to every query
+        nm = -d512_xhalf_max(mx);   // finite: the first key of the range is visible to every query
     }
     d512_wait_vmcnt<0>();           // the ring's trailing (unused) loads still target this workgroup's LDS
     __builtin_amdgcn_s_barrier();   // every wave is done with the last K tile before stage 0 is refilled
@@ -193,16 +206,17 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     // ================= pass 2: P = exp2((S^T - m) c), O^T += V^T.P =================
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-        stage_k(0, 0, i);
-        stage_v(0, 0, i);
+        stage_k(t_lo, 0, i);
+        stage_v(t_lo, 0, i);
     }
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int u = t - t_lo;
         d512_wait_vmcnt<0>();              // this wave's share of tile t has landed ...
         __builtin_amdgcn_s_barrier();      // ... and so has everybody else's; all waves are done with tile t-1
         asm volatile("" ::: "memory");
-        const char* sb = smem + (t & 1) * STAGE_BYTES;
-        const int noff = ((t + 1) & 1) * STAGE_BYTES;
-        const bool more = t + 1 < nt;
+        const char* sb = smem + (u & 1) * STAGE_BYTES;
+        const int noff = ((u + 1) & 1) * STAGE_BYTES;
+        const bool more = t + 1 < t_hi;
         // tile t+1: all 2 * LPT loads on the first four score groups, so that they have the rest of this tile to land
         const f32x16 s = scores(sb, nm, t, [&](int g) {
             if (more && g < 4) {
@@ -247,6 +261,26 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    if constexpr (SPLIT) {
+        if (q_ok) {
+            const size_t row = ((size_t)sp * p.B + b) * p.Tq + q;
+            float* Pp = p.part + row * 512;
+#pragma unroll
+            for (int db = 0; db < 16; ++db)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = o[db][rg * 4 + e] * inv;
+                    *(f32x4*)(Pp + db * 32 + 8 * rg + 4 * half) = ov;
+                }
+            if (half == 0) {
+                p.ml[row * 2] = -nm;
+                p.ml[row * 2 + 1] = l_tot;
+            }
+        }
+        return;
+    }
     if (q_ok) {
         bf16_t* Op = p.O + ((size_t)b * p.Tq + q) * p.ldo;
 #pragma unroll
@@ -261,24 +295,99 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
     }
 }
 
+
+// Merge of the key splits (fixed order, reproducible): out = sum_h w_h O_h,  w_h = l_h 2^((m_h - m) c) / sum_h' l_h' 2^((m_h' - m) c),
+// m = max_h m_h.  One thread per (query row, 4 channels); a row's 1 KB of bf16 output is one contiguous store per 128 threads.
+__global__ __launch_bounds__(256) void attn_d512_combine_kernel(const float* __restrict__ part, const float* __restrict__ ml,
+                                                                bf16_t* __restrict__ O, long rows, int ldo, int nsplit, float c) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = gid >> 7;
+    const int cg = (int)(gid & 127);
+    if (row >= rows) return;
+    float m = -INFINITY;
+    for (int h = 0; h < nsplit; ++h) m = fmaxf(m, ml[((size_t)h * rows + row) * 2]);
+    float den = 0.f;
+    for (int h = 0; h < nsplit; ++h) {
+        const float* st = ml + ((size_t)h * rows + row) * 2;
+        den += st[1] * __builtin_amdgcn_exp2f((st[0] - m) * c);
+    }
+    const float inv = 1.0f / den;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < nsplit; ++h) {
+        const float* st = ml + ((size_t)h * rows + row) * 2;
+        const float w = st[1] * __builtin_amdgcn_exp2f((st[0] - m) * c) * inv;
+        const f32x4 v = *(const f32x4*)(part + ((size_t)h * rows + row) * 512 + cg * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w * v[e];
+    }
+    u16x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = f2bf(acc[e]);
+    *(u16x4*)(O + (size_t)row * ldo + cg * 4) = ov;
+}
+
 }  // namespace
 
+constexpr int D512_NW = 4;   // 128 queries per workgroup: half the K / V^T stream (and LDS-DMA issue) per FLOP of the 2-wave form
+
+// Key splits.  A launch has B * ceil(Tq / 128) workgroups of one wave per SIMD: 128 at T = 16 384 (the mid block of a 1024^2 image), 32 at
+// T = 4096 -- half / an eighth of the 256 CUs.  With the keys split over `ns` workgroup sets the same work fills the chip; the merge is
+// 2 x ns x 2 KB per query row of extra traffic (T = 16 384, ns = 2: 134 MB against ~1 ms of attention).  requested <= 0: as many splits as
+// bring the grid to <= 256 workgroups, at least 8 key tiles (256 keys) each, at most 16; none from 192 workgroups up.
+static int d512_splits(int B, int Tq, int Tk, int requested) {
+    const int nt = (Tk + KT - 1) / KT;
+    const long nwg1 = (long)B * ((Tq + 32 * D512_NW - 1) / (32 * D512_NW));
+    long ns = requested;
+    if (requested <= 0) {
+        ns = nwg1 >= 192 ? 1 : 256 / nwg1;
+        if (ns > nt / 8) ns = nt / 8;
+    }
+    if (ns > 16) ns = 16;
+    if (ns > nt) ns = nt;
+    if (ns < 1) ns = 1;
+    const int tps = (nt + (int)ns - 1) / (int)ns;
+    return (nt + tps - 1) / tps;   // no empty split
+}
+
+size_t supir_attn_d512_workspace_bytes(int B, int Tq, int Tk, int splits) {
+    if (B <= 0 || Tq <= 0 || Tk <= 0) return 0;
+    const int ns = d512_splits(B, Tq, Tk, splits);
+    return ns <= 1 ? 0 : (size_t)ns * B * Tq * (512 + 2) * sizeof(float);
+}
+
 int supir_attn_d512_launch(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int B, int Tq, int Tk, int ldq, int ldk,
-                           int ldvt, int ldo, float scale, hipStream_t st) {
+                           int ldvt, int ldo, float scale, int splits, void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (B <= 0 || Tq <= 0 || Tk <= 0 || !(scale > 0.f)) return SUPIR_ERR_ARG;   // the row maxima are taken on the unscaled scores
     if ((ldq | ldk | ldvt) % 8 != 0 || ldo % 4 != 0 || ldq < 512 || ldk < 512 || ldo < 512) return SUPIR_ERR_SHAPE;
     if (ldvt < ((Tk + KT - 1) / KT) * KT) return SUPIR_ERR_SHAPE;
-    Attn512Args a{Q, K, Vt, O, B, Tq, Tk, ldq, ldk, ldvt, ldo, scale * 1.4426950408889634f};
-    constexpr int NW = 4;   // 128 queries per workgroup: half the K / V^T stream (and LDS-DMA issue) per FLOP of the 2-wave form
-    const long nwg = (long)B * ((Tq + 32 * NW - 1) / (32 * NW));
+    constexpr int NW = D512_NW;
+    const int ns = workspace ? d512_splits(B, Tq, Tk, splits) : 1;   // no workspace: the single-pass form
+    if (ns > 1 && (workspace_bytes < supir_attn_d512_workspace_bytes(B, Tq, Tk, splits) || (((size_t)workspace) & 15))) return SUPIR_ERR_ARG;
+    Attn512Args a{Q, K, Vt, O, B, Tq, Tk, ldq, ldk, ldvt, ldo, scale * 1.4426950408889634f, ns, 0, nullptr, nullptr};
+    const long nwg = (long)B * ((Tq + 32 * NW - 1) / (32 * NW)) * ns;
     if (nwg > 0x7fffffffL) return SUPIR_ERR_SHAPE;
     static bool attr_set = false;
     if (!attr_set) {
-        if (supir_note_hip_status(hipFuncSetAttribute((const void*)attn_d512_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (supir_note_hip_status(hipFuncSetAttribute((const void*)attn_d512_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      2 * STAGE_BYTES)) != SUPIR_OK ||
+            supir_note_hip_status(hipFuncSetAttribute((const void*)attn_d512_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       2 * STAGE_BYTES)) != SUPIR_OK)
             return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    SUPIR_LAUNCH((attn_d512_kernel<NW>), dim3((unsigned)nwg), dim3(64 * NW), 2 * STAGE_BYTES, st, a);
+    if (ns == 1) {
+        SUPIR_LAUNCH((attn_d512_kernel<NW, false>), dim3((unsigned)nwg), dim3(64 * NW), 2 * STAGE_BYTES, st, a);
+        return SUPIR_LAUNCH_STATUS();
+    }
+    const int nt = (Tk + KT - 1) / KT;
+    const long rows = (long)B * Tq;
+    a.tps = (nt + ns - 1) / ns;
+    a.part = (float*)workspace;
+    a.ml = a.part + (size_t)ns * rows * 512;
+    SUPIR_LAUNCH((attn_d512_kernel<NW, true>), dim3((unsigned)nwg), dim3(64 * NW), 2 * STAGE_BYTES, st, a);
+    if (const int rc = SUPIR_LAUNCH_STATUS()) return rc;
+    const long nblk = (rows * 128 + 255) / 256;
+    if (nblk > 0x7fffffffL) return SUPIR_ERR_SHAPE;
+    SUPIR_LAUNCH(attn_d512_combine_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a.part, a.ml, O, rows, ldo, ns, a.scale_log2e);
     return SUPIR_LAUNCH_STATUS();
 }

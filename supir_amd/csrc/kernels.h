@@ -143,8 +143,10 @@ int supir_attn_launch_n(const AttnArgs* a, int n, hipStream_t st);
 bool supir_xattn_q_supported(const XattnArgs& a);
 int supir_xattn_q_launch(const XattnArgs& a, hipStream_t st);
 // attention_d512.hip: one head of dimension 512 (VAE mid block), 32-key tiles, 32 x 512 output tile per wave
+// (splits / workspace: the key-split form, see attention_d512.hip; workspace == nullptr -> one pass over all keys per workgroup)
 int supir_attn_d512_launch(const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int B, int Tq, int Tk, int ldq, int ldk,
-                           int ldvt, int ldo, float scale, hipStream_t st);
+                           int ldvt, int ldo, float scale, int splits, void* workspace, size_t workspace_bytes, hipStream_t st);
+size_t supir_attn_d512_workspace_bytes(int B, int Tq, int Tk, int splits);
 int supir_softmax_rows_launch(const float* S, bf16_t* P, int rows, int T, int Tpad, long lds_, long ldp, float scale,
                               hipStream_t st);
 int supir_groupnorm_launch(GnArgs a, hipStream_t st);

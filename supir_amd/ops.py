@@ -1160,9 +1160,11 @@ def use_flash_d512(T):
     return bool(USE_FLASH_D512)
 
 
-def flash_attn_d512(q, k, vt, Tk, out=None):
+def flash_attn_d512(q, k, vt, Tk, out=None, splits=0):
     """Single-head, head-dim-512 attention without a score matrix (VAE mid block): q [B,Tq,512], k [B,Tk,512], vt [B,512,Tpad]
-    (V transposed per batch, Tpad >= roundup(Tk, 32), zero padded) -> [B,Tq,512].  scale = 512^-0.5."""
+    (V transposed per batch, Tpad >= roundup(Tk, 32), zero padded) -> [B,Tq,512].  scale = 512^-0.5.
+    splits: key splits of supir_flash_attn_d512_split (0 = the library's choice: enough to fill the 256 CUs -- 2 at 16 384 tokens, 8 at
+    4096; 1 = one pass over all keys per workgroup)."""
     DT = q.dtype
     lib = _lib.load(DT)
     _check_dev(q, k, vt)
@@ -1174,12 +1176,15 @@ def flash_attn_d512(q, k, vt, Tk, out=None):
         out = torch.empty(B, Tq, 512, dtype=DT, device=q.device)
     assert out.dtype == DT and out.stride(-1) == 1 and out.stride(0) == Tq * out.stride(1)
     _no_defer("flash_attn_d512")
+    nbytes = lib.supir_flash_attn_d512_workspace(B, Tq, Tk, splits)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device) if nbytes else None
     ev = _ev()
-    rc = lib.supir_flash_attn_d512(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, Tq, Tk, q.stride(1), k.stride(1),
-                                   vt.shape[-1], out.stride(1), 512 ** -0.5, _stream())
-    _lib.check(rc, "supir_flash_attn_d512", lib)
+    rc = lib.supir_flash_attn_d512_split(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, Tq, Tk, q.stride(1), k.stride(1),
+                                         vt.shape[-1], out.stride(1), 512 ** -0.5, splits, _p(ws), nbytes, _stream())
+    _lib.check(rc, "supir_flash_attn_d512_split", lib)
     # algorithmic FLOPs (Q.K^T and P.V once each; the kernel's own first pass over K is overhead, not work)
-    _rec("attn_d512", 4.0 * B * Tq * Tk * 512, 2.0 * B * 512 * (2 * Tq + 2 * Tk), ev, B=B, H=1, Tq=Tq, Tk=Tk)
+    _rec("attn_d512", 4.0 * B * Tq * Tk * 512, 2.0 * B * 512 * (2 * Tq + 2 * Tk), ev, B=B, H=1, Tq=Tq, Tk=Tk,
+         splits=nbytes // (B * Tq * 514 * 4) if nbytes else 1)
     return out
 
 

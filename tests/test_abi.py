@@ -12,7 +12,7 @@ def _header_functions():
     src = open(os.path.join(ROOT, "include", "supir_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     fns = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(supir_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(supir_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         fns[m.group(1)] = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
     return fns
@@ -46,10 +46,10 @@ def test_f16_library_exports_the_same_surface():
 
 def test_ctypes_signatures_match_header():
     fns = _header_functions()
-    for name, argtypes in _lib.SIGNATURES.items():
+    for name, argtypes in list(_lib.SIGNATURES.items()) + list(_lib.SIZE_SIGNATURES.items()):
         assert name in fns, name
         assert len(argtypes) == fns[name], (name, len(argtypes), fns[name])
-    assert set(fns) - set(_lib.SIGNATURES) == {"supir_abi_version", "supir_target_arch", "supir_elem_type",
+    assert set(fns) - set(_lib.SIGNATURES) - set(_lib.SIZE_SIGNATURES) == {"supir_abi_version", "supir_target_arch", "supir_elem_type",
                                                  "supir_last_hip_error", "supir_hip_error_string"}
 
 
@@ -95,6 +95,19 @@ def test_round2_entry_points_validate_arguments_without_a_gpu():
     assert lib.supir_flash_attn_d512(fake, fake, fake, fake, 1, 64, 64, 256, 512, 64, 512, 0.044, None) == -2
     assert lib.supir_flash_attn_d512(fake, fake, fake, fake, 1, 64, 64, 512, 516, 64, 512, 0.044, None) == -2
     assert lib.supir_flash_attn_d512(fake, fake, fake, fake, 1, 64, 100, 512, 512, 96, 512, 0.044, None) == -2
+    # key-split form: the workspace the library asks for (auto: 2 splits at T = 16 384, 8 at 4096, none for 256 query blocks or < 16 key
+    # tiles; explicit counts clamp to 16 and to the key tiles, and never leave a split empty), and its argument checks
+    ws = lib.supir_flash_attn_d512_workspace
+    assert ws(1, 16384, 16384, 0) == 2 * 16384 * 514 * 4 and ws(1, 4096, 4096, 0) == 8 * 4096 * 514 * 4
+    assert ws(2, 16384, 16384, 0) == 0 and ws(1, 200, 200, 0) == 0 and ws(1, 16384, 16384, 1) == 0 and ws(0, 64, 64, 0) == 0
+    assert ws(1, 128, 16384, 64) == 16 * 128 * 514 * 4 and ws(1, 128, 96, 8) == 3 * 128 * 514 * 4
+    assert ws(1, 128, 9 * 32, 4) == 3 * 128 * 514 * 4          # 9 tiles / 4 -> 3 per split -> 3 splits, none empty
+    split = lib.supir_flash_attn_d512_split
+    assert split(None, None, None, None, 1, 64, 64, 512, 512, 64, 512, 0.044, 0, None, 0, None) == -1
+    assert split(fake, fake, fake, fake, 1, 4096, 4096, 512, 512, 4096, 512, 0.044, 0, None, 0, None) == -1          # needs a workspace
+    assert split(fake, fake, fake, fake, 1, 4096, 4096, 512, 512, 4096, 512, 0.044, 0, fake, 1024, None) == -1       # too small
+    assert split(fake, fake, fake, fake, 1, 4096, 4096, 512, 512, 4096, 512, 0.044, 0, fake + 4, 1 << 30, None) == -1   # misaligned
+    assert split(fake, fake, fake, fake, 1, 4096, 4096, 256, 512, 4096, 512, 0.044, 0, fake, 1 << 30, None) == -2     # ldq < 512
     # tile 32 (128 x 80) on an inexact shape is refused, not silently run on another tile
     assert lib.supir_gemm_bf16(fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 32, None) == -2
     assert lib.supir_gemm_bf16(fake, fake, fake, 128, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 36, None) == -1   # no such tile

@@ -54,6 +54,40 @@ def test_flash_attn_d512_vs_sdpa(B, T):
     _check(out, _ref(q, k, v), 4e-3, f"d512 B{B} T{T}")
 
 
+# key-split form (supir_flash_attn_d512_split): explicit split counts incl. ones that do not divide the key tiles (4096 keys = 128 tiles
+# over 3), more splits than sensible (16 over 32 tiles), ragged last tiles (7396, 200, 33, 63 keys) and a split holding ONE key (33 keys
+# = 2 tiles over 2 splits).  Against fp32 SDPA at the kernel's bar, against the single-pass launch (both round the same fp32 value to
+# bf16 after different fp32 summation orders), and bitwise reproducible.
+@pytest.mark.parametrize("B,T,splits", [(1, 16384, 2), (1, 4096, 8), (1, 4096, 3), (2, 7396, 2), (2, 1024, 16), (1, 200, 4), (3, 33, 2),
+                                        (1, 63, 2), (1, 512, 0)])
+def test_flash_attn_d512_key_splits(B, T, splits):
+    from supir_amd import _lib
+    q, k, v = rnd(B, T, 512, scale=3.0).to(BF), rnd(B, T, 512, seed=1).to(BF), rnd(B, T, 512, seed=2).to(BF)
+    vt = _vt(v, (T + 63) // 64 * 64)
+    want = _lib.load().supir_flash_attn_d512_workspace(B, T, T, splits)
+    assert want > 0, "case does not exercise the split form"
+    ops.start_trace()
+    out = ops.flash_attn_d512(q, k, vt, T, splits=splits)
+    rec = [r for r in ops.stop_trace() if r["kernel"] == "attn_d512"]
+    assert len(rec) == 1 and rec[0]["splits"] == want // (B * T * 514 * 4) and rec[0]["splits"] > 1
+    single = ops.flash_attn_d512(q, k, vt, T, splits=1)
+    _check(out, _ref(q, k, v), 4e-3, f"d512 split B{B} T{T} x{splits}")
+    e = ((out.float() - single.float()).norm() / single.float().norm()).item()
+    assert e <= 3e-3, f"split vs single pass: {e:.3e}"
+    assert torch.equal(out, ops.flash_attn_d512(q, k, vt, T, splits=splits))
+
+
+def test_flash_attn_d512_split_extreme_logits_across_splits():
+    """The dominating key sits in the LAST split and one query is near one-hot: the other splits' partial outputs must vanish in the
+    merge (weights 2^((m_h - m) c) ~ 0), not pollute it."""
+    B, T = 1, 1024
+    q, k, v = rnd(B, T, 512).to(BF), rnd(B, T, 512, seed=1).to(BF), rnd(B, T, 512, seed=2).to(BF)
+    k[:, 1000] = q[:, 7] * 8.0
+    q[:, 9] *= 10.0
+    out = ops.flash_attn_d512(q, k, _vt(v, 1024), T, splits=4)
+    _check(out, _ref(q, k, v), 4e-3, "d512 split extreme")
+
+
 def test_flash_attn_d512_cross_lengths_and_strides():
     """Tq != Tk, operands that are column slices of wider buffers (row stride > 512), V^T padded wider than needed."""
     B, Tq, Tk = 2, 300, 1000
@@ -115,20 +149,23 @@ def test_flash_attn_d512_timing_report():
         return e0.elapsed_time(e1) / n * 1e3
 
     res = {}
-    for T in (16384, 4096):
-        q, k, v = rnd(1, T, 512).to(BF), rnd(1, T, 512, seed=1).to(BF), rnd(1, T, 512, seed=2).to(BF)
+    for B, T in ((1, 16384), (1, 4096), (4, 4096)):
+        q, k, v = rnd(B, T, 512).to(BF), rnd(B, T, 512, seed=1).to(BF), rnd(B, T, 512, seed=2).to(BF)
         vt = _vt(v, T)
-        t_flash = timed(lambda: ops.flash_attn_d512(q, k, vt, T))
+        t_single = timed(lambda: ops.flash_attn_d512(q, k, vt, T, splits=1))
+        t_flash = timed(lambda: ops.flash_attn_d512(q, k, vt, T))          # the library's split choice
 
         def materialised():
-            s = ops.gemm(q[0], k[0], out_dtype=torch.float32)
-            p = ops.softmax_rows(s, 512 ** -0.5, valid=T)
-            return ops.gemm(p, vt[0])
+            for b in range(B):
+                s = ops.gemm(q[b], k[b], out_dtype=torch.float32)
+                p = ops.softmax_rows(s, 512 ** -0.5, valid=T)
+                ops.gemm(p, vt[b])
 
         t_mat = timed(materialised)
-        fl = 4.0 * T * T * 512
-        print(f"[d512] T={T}: flash {t_flash:.0f} us = {fl / t_flash / 1e6:.0f} TFLOP/s; materialised scores {t_mat:.0f} us")
-        res[f"T{T}"] = {"flash_us": t_flash, "flash_tflops": fl / t_flash / 1e6, "materialised_us": t_mat}
+        fl = 4.0 * B * T * T * 512
+        print(f"[d512] B={B} T={T}: flash {t_flash:.0f} us = {fl / t_flash / 1e6:.0f} TFLOP/s (one pass per workgroup: {t_single:.0f} us); "
+              f"materialised scores {t_mat:.0f} us")
+        res[f"B{B}_T{T}"] = {"flash_us": t_flash, "flash_tflops": fl / t_flash / 1e6, "flash_single_pass_us": t_single, "materialised_us": t_mat}
     try:
         import json
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

@@ -211,7 +211,7 @@ def xattn_q(x, wq, bias, k, vt, B, H, T, Tk, *, ln=None, colsum=None, ln_eps=1e-
 use_flash_d512 = real_ops.use_flash_d512
 
 
-def flash_attn_d512(q, k, vt, Tk, out=None):
+def flash_attn_d512(q, k, vt, Tk, out=None, splits=0):   # key splits change the summation order only
     B, Tq, C = q.shape
     v = vt[:, :, :Tk].float().transpose(1, 2)
     o = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v[:, None], scale=C ** -0.5)[:, 0]
