@@ -328,7 +328,8 @@ def vae_colorfix_profile(model, P, device):
 _ROCPROF_NAMES = {"gemm16_kernel<128,80,2k,s3>": "gemm16_kernel<128, 80, 4, 1, 2, 3, false, false, false, 1>",
                   "gemm16_kernel<128,80,2k,s2>": "gemm16_kernel<128, 80, 4, 1, 2, 2, false, false, false, 1>",
                   "geglu_big_kernel<256,320,4x2>": "geglu_big_kernel<1, true>", "attn": "attn_d64_pipe_kernel<3, 4, true, 1, true>",
-                  "gemm16_kernel<256,160,1k,s3,qkv>": "gemm16_kernel<256, 160, 8, 1, 1, 3, false, false, true, 1>"}
+                  "gemm16_kernel<256,160,1k,s3,qkv>": "gemm16_kernel<256, 160, 8, 1, 1, 3, false, false, true, 1>",
+                  "gemm16_kernel<256,128,1k,s3,qkv>": "gemm16_kernel<256, 128, 4, 2, 1, 3, false, false, true, 1>"}
 
 
 def _replay_average_us(kernel):

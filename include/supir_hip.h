@@ -198,7 +198,8 @@ int supir_flash_attn_d512(const void* Q, const void* K, const void* Vt, void* O,
  * 128 for the mid block of a 1024^2 image (16 384 tokens), 32 for a 512^2 image or a tiled-VAE tile (SUPIR/utils/tilevae.py:276,335) --
  * on a 256-CU part; split s attends to its own range of 32-key tiles with its own exact row maxima and leaves a normalised fp32
  * partial output plus (maximum, sum) per query row in `workspace`, a second kernel merges them.
- *   splits <= 0: chosen by the library (as many as bring the grid to <= 256 workgroups, >= 256 keys each, <= 16; 1 from 192 workgroups up);
+ *   splits <= 0: chosen by the library (the count <= 16 with >= 128 keys per split that minimises rounds-of-256-workgroups x keys per
+ *                split + the merge; 1 below 512 keys);
  *   splits >= 1: that many (clamped to 16 and to the number of key tiles).
  * supir_flash_attn_d512_workspace(B, Tq, Tk, splits) = bytes the call needs for the same arguments (0 when it resolves to one split: the
  * call is then supir_flash_attn_d512 and `workspace` may be NULL).  workspace: device memory, 16-byte aligned, contents undefined

@@ -330,17 +330,33 @@ __global__ __launch_bounds__(256) void attn_d512_combine_kernel(const float* __r
 
 constexpr int D512_NW = 4;   // 128 queries per workgroup: half the K / V^T stream (and LDS-DMA issue) per FLOP of the 2-wave form
 
-// Key splits.  A launch has B * ceil(Tq / 128) workgroups of one wave per SIMD: 128 at T = 16 384 (the mid block of a 1024^2 image), 32 at
-// T = 4096 -- half / an eighth of the 256 CUs.  With the keys split over `ns` workgroup sets the same work fills the chip; the merge is
-// 2 x ns x 2 KB per query row of extra traffic (T = 16 384, ns = 2: 134 MB against ~1 ms of attention).  requested <= 0: as many splits as
-// bring the grid to <= 256 workgroups, at least 8 key tiles (256 keys) each, at most 16; none from 192 workgroups up.
+// Key splits.  A launch has B * ceil(Tq / 128) workgroups of one wave per SIMD, one per CU (128 KB of LDS): 128 at T = 16 384 (the mid
+// block of a 1024^2 image), 32 at T = 4096 -- half / an eighth of the 256 CUs -- and 328 (1.28 rounds = 2) for eight stacked 5184-token
+// tiled-VAE tiles.  With the keys split over `ns` workgroup sets the same work is cut finer; the merge costs 2 x ns x 2 KB per query row
+// of extra traffic.  requested <= 0: the count that minimises  rounds-of-256-workgroups x key tiles per split + the merge  (in units of
+// one 32-key tile of one workgroup, ~3 us: the merge is ~0.6 of that per split and 4096 rows, a split launch 2 more), among the counts
+// with >= 4 tiles per split, <= 16, for >= 16 key tiles; a split must win by 3 %.  Measured (profiles/r04/micro_attn_d512_key_split_sweep.log):
+// (1, 16 384): 1 518 us unsplit, 912 / 906 / 950 / 1 073 with 2 / 4 / 8 / 16; (1, 4096): 399, 209 / 122 / 90 / 125; (4, 4096): 412, 261 / 310 / 375.
 static int d512_splits(int B, int Tq, int Tk, int requested) {
     const int nt = (Tk + KT - 1) / KT;
     const long nwg1 = (long)B * ((Tq + 32 * D512_NW - 1) / (32 * D512_NW));
     long ns = requested;
     if (requested <= 0) {
-        ns = nwg1 >= 192 ? 1 : 256 / nwg1;
-        if (ns > nt / 8) ns = nt / 8;
+        ns = 1;
+        if (nt >= 16) {
+            const double merge = 0.6 * (double)B * Tq / 4096.0;
+            double best = (double)((nwg1 + 255) / 256) * nt;
+            for (int c = 2; c <= 16; ++c) {
+                const int tps = (nt + c - 1) / c;
+                if (tps < 4) break;
+                if ((nt + tps - 1) / tps != c) continue;   // same split as a smaller count
+                const double cost = (double)((nwg1 * c + 255) / 256) * tps + merge * c + 2.0;
+                if (cost < 0.97 * best) {
+                    best = cost;
+                    ns = c;
+                }
+            }
+        }
     }
     if (ns > 16) ns = 16;
     if (ns > nt) ns = nt;

@@ -4,8 +4,9 @@ Upsample/Downsample :55-88, Encoder :482-596, Decoder :599-743), sgm/models/auto
 AutoencoderKLInferenceWrapper) and sgm/modules/distributions/distributions.py:24-72.
 
 Activations are NHWC bf16 between the fp32 NCHW image / latent boundaries.  The mid-block single-head attention
-(head dim 512, up to 16384 tokens at 1024 px) materialises its fp32 score matrix (1 GB at 1024 px: trivial next to
-288 GB of HBM) and runs as GEMM -> row softmax -> GEMM on the MFMA GEMM kernel.
+(head dim 512, up to 16384 tokens at 1024 px) is one flash-attention launch with the keys split over workgroup sets
+(csrc/attention_d512.hip) from 1024 tokens up; smaller maps materialise their fp32 score matrix and run as GEMM -> row softmax ->
+GEMM on the MFMA GEMM kernel.
 """
 import torch
 import torch.nn as nn
@@ -56,9 +57,9 @@ class AttnBlock(nn.Module):
 
     def attend(self, n):
         """n: normalised tokens [B, T, C] bf16 -> proj_out-less attention output [B, T, C].  Any T.
-        C == 512 (every SDXL / SUPIR VAE) and ops.use_flash_d512(T) (T >= 16 384 tokens = a 1024^2 px image and larger, where it
-        measures faster): q, k and v^T projections + ONE flash-attention launch (csrc/attention_d512.hip), no score matrix.
-        Otherwise (512^2 px images, tiled-VAE tiles) the materialised form: the key axis is padded to a multiple of 64
+        C == 512 (every SDXL / SUPIR VAE) and ops.use_flash_d512(T) (T >= 1024 tokens: 256^2 px images, tiled-VAE tiles and everything
+        larger, where it measures faster): q, k and v^T projections + ONE flash-attention launch with key splits + its merge
+        (csrc/attention_d512.hip), no score matrix.  Otherwise (small maps) the materialised form: the key axis is padded to a multiple of 64
         with zero K rows / zero V^T columns, a GEMM writes fp32 scores [T, Tp], softmax_rows masks the padding, a GEMM applies P."""
         B, T, C = n.shape
         Tp = (T + 63) // 64 * 64

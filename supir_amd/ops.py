@@ -78,7 +78,7 @@ def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1, group=1):
         return f"gemm_bf16_kernel<{name},conv,split9>+finalize"
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv",
-              38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2"}[tile]
+              38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2", 41: "256,128,1k,s3,qkv"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}{g}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
@@ -860,6 +860,17 @@ def gemm_qkv_supported(M, N, n_split, K, T):
             and K % 64 == 0 and K >= 128 and T % 4 == 0)
 
 
+def qkv_tile_width(M, N, n_split):
+    """The tile width the fused q|k|v launch takes (csrc/gemm16.hip g16_qkv_bn, same rule): 128 or 160 columns -- the one with fewer
+    rounds of 256 workgroups x columns among those that divide N and n_split.  For trace records / kernel names only."""
+    ok160, ok128 = N % 160 == 0 and n_split % 160 == 0, N % 128 == 0 and n_split % 128 == 0
+    if not (ok128 and ok160):
+        return 128 if ok128 else 160
+    tm = M // 256
+    c160, c128 = -(-tm * (N // 160) // 256) * 160, -(-tm * (N // 128) // 256) * 128
+    return 128 if c128 < c160 else 160
+
+
 def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, out_qk=None, out_vt=None):
     """Fused q | k | v projection: a [B*T, K] -> (qk [B, T, n_split] bf16, v^T [B, N - n_split, T] bf16) in one launch; optional
     LayerNorm fold as in gemm_ln.  Callers check gemm_qkv_supported first."""
@@ -892,7 +903,8 @@ def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, ou
     tkey = ("qkv", M, N, K) + _k(DT)
     _issue(_Launch("qkv", lib, "supir_gemm_bf16_qkv", launch, key=tkey + (n_split, T, ln_eps, ln is not None), tkey=tkey, tile=36,
                    single_tile=36, make=make, w=w, out=out_qk,
-                   trace=("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), dict(M=M, N=N, K=K, act=0, tile=36)),
+                   trace=("gemm", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N),
+                          dict(M=M, N=N, K=K, act=0, tile=36 if qkv_tile_width(M, N, n_split) == 160 else 41)),
                    keep=(a, w, bias, out_qk, out_vt, ln.buf if ln is not None else None, colsum)))
     return out_qk, out_vt
 
@@ -1143,14 +1155,15 @@ def xattn_q(x, wq, bias, k, vt, B, H, T, Tk, *, ln=None, colsum=None, ln_eps=1e-
 
 
 # VAE mid-block attention (one head, dim 512): supir_flash_attn_d512 never forms the score matrix; the materialised form (GEMM -> fp32
-# scores [T, T] -> softmax_rows -> GEMM) moves ~3 GB per call at T = 16 384 but runs on the tuned GEMM tiles.  Measured on one box
-# (profiles/r02/attn_d512_timing.json): T = 4096: 391 us flash vs 93 us materialised (32 workgroups of one wave per SIMD cannot
-# fill 256 CUs); T = 16 384 (a 1024^2 image, the bench): 1.49 ms vs 1.69 ms.  The materialised form grows as T^2 from a small
-# constant, the flash kernel linearly in its workgroup count until the chip is full, so the flash kernel takes over from
-# FLASH_D512_MIN_TOKENS = 16 384 tokens per batch element upwards (env SUPIR_FLASH_D512_MIN_TOKENS); SUPIR_FLASH_D512 = 1 / 0 forces
-# it on / off for every size.
+# scores [T, T] -> softmax_rows -> GEMM) moves ~3 GB per call at T = 16 384 but runs on the tuned GEMM tiles.  Until round 4 the flash
+# kernel had B * T / 128 workgroups of one wave per SIMD and lost below 16 384 tokens (T = 4096: 391 us vs 93 us materialised,
+# profiles/r02/attn_d512_timing.json).  With the keys split over workgroup sets (supir_flash_attn_d512_split, the library picks the count)
+# it fills the chip at every size -- measured on one box (profiles/r04/micro_attn_d512_key_split_sweep.log), flash / materialised in us:
+# (B 1, T 16 384) 820 / 1 668, (1, 4096) 96 / 100, (4, 4096) 243 / 382, (16, 4096) 876 / 1 800, (1, 5184) 125 / 158, (8, 5184) 985 / 1 437,
+# (1, 1024) 44 / 50, (16, 1024) 94 / 795 -- so it takes over from FLASH_D512_MIN_TOKENS = 1024 tokens per batch element upwards (env
+# SUPIR_FLASH_D512_MIN_TOKENS); SUPIR_FLASH_D512 = 1 / 0 forces it on / off for every size.
 USE_FLASH_D512 = {"1": True, "0": False}.get(_os.environ.get("SUPIR_FLASH_D512", "auto"), "auto")
-FLASH_D512_MIN_TOKENS = int(_os.environ.get("SUPIR_FLASH_D512_MIN_TOKENS", "16384"))
+FLASH_D512_MIN_TOKENS = int(_os.environ.get("SUPIR_FLASH_D512_MIN_TOKENS", "1024"))
 
 
 def use_flash_d512(T):

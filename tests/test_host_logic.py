@@ -539,8 +539,8 @@ def test_flash_d512_policy(monkeypatch):
     SUPIR_FLASH_D512 = 1 / 0 force it for every size."""
     from supir_amd import ops
     monkeypatch.setattr(ops, "USE_FLASH_D512", "auto")
-    assert ops.FLASH_D512_MIN_TOKENS == 16384          # the default: where the flash kernel measured faster (1024^2 px images)
-    assert ops.use_flash_d512(16384) and ops.use_flash_d512(65536) and not ops.use_flash_d512(16383) and not ops.use_flash_d512(4096)
+    assert ops.FLASH_D512_MIN_TOKENS == 1024           # the default: where the key-split flash kernel measures faster (256^2 px and up)
+    assert ops.use_flash_d512(16384) and ops.use_flash_d512(4096) and ops.use_flash_d512(1024) and not ops.use_flash_d512(1023)
     monkeypatch.setattr(ops, "FLASH_D512_MIN_TOKENS", 46341)                   # e.g. only where the score matrix would reach 8 GiB
     assert not ops.use_flash_d512(16384) and not ops.use_flash_d512(46340) and ops.use_flash_d512(46341)
     monkeypatch.setattr(ops, "USE_FLASH_D512", True)

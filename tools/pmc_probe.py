@@ -37,6 +37,12 @@ for (M, N, K, tile) in [(2048, 1280, 1280, 35), (2048, 1280, 5120, 35), (2048, 2
     for _ in range(3):
         ops.gemm(a, w, None, residual=res, tile=tile)
     note("gemm", f"M{M} N{N} K{K}", 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N), tile)
+# fused q|k|v projection of the 1280-wide blocks: 240 tiles of 256 x 128 (round 4)
+M, N, K = 2048, 3840, 1280
+a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
+for _ in range(3):
+    ops.gemm_qkv(a, w, None, 2, 1024, 2560)
+note("gemm_qkv", f"M{M} N{N} K{K}", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), 41)
 for (B, H, W, Cin, Cout, tile) in [(2, 32, 32, 1280, 1280, 35), (2, 64, 64, 640, 640, 33), (2, 128, 128, 320, 320, 34)]:
     x = torch.randn(B, H, W, Cin, device=dev).to(BF); w = (torch.randn(Cout, 3, 3, Cin, device=dev) * (9 * Cin) ** -0.5).to(BF)
     for _ in range(3):
