@@ -46,6 +46,10 @@ for c in cases:
         e = find("geglu_big_kernel", grid) if tile == 37 else \
             find(f"gemm16_kernel<{targs[tile]}, false, {'true' if kind == 'conv3x3' else 'false'}, false, 1>", grid)
         name = gemm_tile_name(M, N, 2 if kind == "gemm_geglu" else 0, conv=(kind == "conv3x3"), tile=tile)
+    elif kind == "gemm_qkv":      # fused q|k|v projection on 256 x 128 tiles (round 4)
+        M, N = (int(t[1:]) for t in shape.split()[:2])
+        e = find("gemm16_kernel<256, 128, 4, 2, 1, 3, false, false, true, 1>", (M // 256) * (N // 128) * 512)
+        name = gemm_tile_name(M, N, 0, tile=tile)
     elif kind == "attn":
         B, H, Tq = (int(t.lstrip("BHTq")) for t in shape.split()[:3])
         e = find("attn_d64_pipe_kernel", ((Tq + 127) // 128) * H * B * 256)
