@@ -61,7 +61,12 @@ __device__ __forceinline__ float xhalf_max(float x) {
 // tokens a problem is 320 workgroups on 256 CUs -- 1.25 rounds; two of them back to back fill 2.5 rounds instead of 2 x 2.
 // R4 (round 4, the default): no tile loads past the last tile, and the output staged through LDS for row-contiguous 16-byte stores;
 // R4 = false is the round-3 kernel, kept selectable for A/B runs (tools-only knob 3).
-template <int S, int NW, bool PRE, int NP = 1, bool R4 = true>
+// DS (round 4, second half): the row sum l as v_dot2c of the PACKED bf16 probabilities -- one instruction per two terms instead of an fp32
+// add per term (the exponential slots are VALU-issue bound: 4 exp + 4 add + 2 cvt_pk per MFMA) -- which also makes l the sum of the
+// probabilities P.V really multiplies with.  DS = false: the fp32 sum of the unrounded exponentials (rounds 1-3; tools-only knob 3 = 4,
+// round-4 forms only).  Measured (profiles/r04/micro_flash_attention_row_sum_dot2_vs_fp32.log): 21.9 -> 20.8 us at (B2, H20, 1024^2),
+// 104.6 -> 103.4 at (B2, H10, 4096^2), error vs fp32 SDPA equal or slightly lower (2.866e-3 vs 2.872e-3; 3.87e-3 vs 4.00e-3 at 3 x the logits).
+template <int S, int NW, bool PRE, int NP = 1, bool R4 = true, bool DS = true>
 __global__ __launch_bounds__(64 * NW, 3) void attn_d64_pipe_kernel(const AttnArgsN<NP> pp) {
     static_assert(S >= 3, "tile t+1 is read while tile t is live and tile t+2 is in flight");
     __shared__ __attribute__((aligned(16))) char smem[S * 16384];
@@ -193,13 +198,30 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_d64_pipe_kernel(const AttnArg
     // meant to run under).  Plain (unpacked) fp32 VALU on purpose: v_pk_* beside MFMAs issues slower than two scalar ops
     // (tools/probes/issue_probe.hip).
     auto exp4 = [&](const f32x16& s, bf16x8 (&pf)[2], int j) {
+        if constexpr (DS) {
+            float pv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 4 * j + e;
-            float pv = PRE ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * c);
-            asm volatile("" : "+v"(pv));
-            l_run += pv;
-            pf[r >> 3][r & 7] = (bf16_t)pv;
+            for (int e = 0; e < 4; ++e) {
+                pv[e] = PRE ? __builtin_amdgcn_exp2f(s[4 * j + e]) : __builtin_amdgcn_exp2f(s[4 * j + e] * c);
+                asm volatile("" : "+v"(pv[e]));
+            }
+            u32x4 w = __builtin_bit_cast(u32x4, pf[j >> 1]);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const uint32_t pk = f2bf_pk(pv[2 * h2], pv[2 * h2 + 1]);
+                l_run = pair_sum_acc(pk, l_run);
+                w[2 * (j & 1) + h2] = pk;
+            }
+            pf[j >> 1] = __builtin_bit_cast(bf16x8, w);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * j + e;
+                float pv = PRE ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * c);
+                asm volatile("" : "+v"(pv));
+                l_run += pv;
+                pf[r >> 3][r & 7] = (bf16_t)pv;
+            }
         }
     };
 
@@ -414,7 +436,9 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
     pp.p[0] = a;
     const dim3 grid(((a.Tq + 127) / 128) * a.H * a.B);
     const bool aligned = a.ldo % 8 == 0 && (((size_t)a.O) & 15) == 0;
-    const int knob = supir_debug_knob_value(3);   // tools only: 1 = round-3 kernel, 2 = always eight waves, 3 = always four waves (round-4 form)
+    const int knob4 = supir_debug_knob_value(3);  // tools only: 1 = round-3 kernel, 2 = always eight waves, 3 = always four waves (round-4 form),
+    const bool ds = knob4 != 4;                   //             4 = the round-4 policy with the fp32 row sum of rounds 1-3 (DS = false)
+    const int knob = knob4 == 4 ? 0 : knob4;
     // EIGHT waves = 256 query rows per workgroup (two waves per SIMD on one K / V^T ring: half the global -> LDS instructions and
     // bytes per wave, the two waves of a SIMD fill each other's issue gaps) where the whole launch is ONE round of such workgroups
     // (<= 256: one per CU): (B2, H20, 1024^2) = 160 workgroups: 21.1 -> 19.8 us.  With more than one round the coarser grid loses
@@ -423,14 +447,17 @@ int supir_attn_launch(const AttnArgs& a, hipStream_t st) {
     const int nwg8 = ((a.Tq + 255) / 256) * a.H * a.B;
     const bool eight = aligned && (knob == 2 || (knob == 0 && nwg8 <= 256 && a.Tq >= 256 && a.Tk >= 256 && !a.causal));
     if (eight) {
-        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 8, true, 1, true>), dim3(nwg8), dim3(512), 0, st, pp);
+        if (ds) SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 8, true, 1, true, true>), dim3(nwg8), dim3(512), 0, st, pp);
+        else SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 8, true, 1, true, false>), dim3(nwg8), dim3(512), 0, st, pp);
         return SUPIR_LAUNCH_STATUS();
     }
     // the round-4 epilogue needs 16-byte aligned output rows; anything else (and knob 3 = 1) runs the round-3 form
     if (knob == 1 || !aligned) {
-        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, false>), grid, dim3(256), 0, st, pp);
+        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, false, true>), grid, dim3(256), 0, st, pp);
+    } else if (ds) {
+        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, true, true>), grid, dim3(256), 0, st, pp);
     } else {
-        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, true>), grid, dim3(256), 0, st, pp);
+        SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 1, true, false>), grid, dim3(256), 0, st, pp);
     }
     return SUPIR_LAUNCH_STATUS();
 }
@@ -447,7 +474,7 @@ int supir_attn_launch_n(const AttnArgs* a, int n, hipStream_t st) {
     }
     if (a[0].B != a[1].B || a[0].H != a[1].H || a[0].Tq != a[1].Tq) return SUPIR_ERR_SHAPE;
     const int nwg = ((a[0].Tq + 127) / 128) * a[0].H * a[0].B;
-    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 2, false>), dim3(8 * ((nwg + 3) / 4)), dim3(256), 0, st, pp);
+    SUPIR_LAUNCH((attn_d64_pipe_kernel<3, 4, true, 2, false, true>), dim3(8 * ((nwg + 3) / 4)), dim3(256), 0, st, pp);
     return SUPIR_LAUNCH_STATUS();
 }
 

@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 typedef u16 u16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 
 #include "../../include/supir_hip.h"  // error codes shared with the C ABI
@@ -71,6 +72,16 @@ __device__ __forceinline__ float bflo2f(uint32_t w) { return __uint_as_float(w <
 __device__ __forceinline__ float bfhi2f(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 #endif
+
+// acc + lo + hi of a packed pair of 16-bit elements AS STORED (v_dot2c_f32_bf16 / v_dot2_f32_f16 against (1, 1)): one instruction for two
+// terms of a softmax row sum, and the sum is then the sum of the rounded probabilities the P.V product actually uses
+__device__ __forceinline__ float pair_sum_acc(uint32_t packed, float acc) {
+#ifdef SUPIR_F16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(bf16x2, packed), __builtin_bit_cast(bf16x2, 0x3c003c00u), acc, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), __builtin_bit_cast(bf16x2, 0x3f803f80u), acc, false);
+#endif
+}
 
 // x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division: the division expands to ~10 VALU
 // instructions per element -- more than the rest of the GroupNorm + SiLU apply pass put together -- and the result is rounded to bf16

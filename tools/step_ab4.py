@@ -61,7 +61,8 @@ def configure(v):
     lib.supir_debug_knob(1, 1 if "w42" in v else 0)
     lib.supir_debug_knob(2, 1 if "gn1" in v else 2 if "gn2" in v else 0)
     lib.supir_debug_knob(4, 1 if "qkv160" in v else 0)   # qkv160: the fused q|k|v launch on its 256 x 160 tile wherever that fits (the round-3 form)
-    lib.supir_debug_knob(3, 1 if "attn3" in v else 3 if "attn4w" in v else 0)   # attn3: round-3 kernel; attn4w: four waves everywhere
+    # attn3: round-3 kernel; attn4w: four waves everywhere; attnfp32sum: the policy's kernels with the fp32 row sum of rounds 1-3
+    lib.supir_debug_knob(3, 1 if "attn3" in v else 3 if "attn4w" in v else 4 if "attnfp32sum" in v else 0)
     if v in ("t38", "t38k1280"):
         ops.G16_TILES = {32, 33, 34, 35, 38}
         n = 0
