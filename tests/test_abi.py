@@ -102,6 +102,12 @@ def test_round2_entry_points_validate_arguments_without_a_gpu():
     assert ws(2, 16384, 16384, 0) == 0 and ws(1, 200, 200, 0) == 0 and ws(1, 16384, 16384, 1) == 0 and ws(0, 64, 64, 0) == 0
     assert ws(1, 128, 16384, 64) == 16 * 128 * 514 * 4 and ws(1, 128, 96, 8) == 3 * 128 * 514 * 4
     assert ws(1, 128, 9 * 32, 4) == 3 * 128 * 514 * 4          # 9 tiles / 4 -> 3 per split -> 3 splits, none empty
+    # the library's choice follows rounds-of-256-workgroups x tiles per split (profiles/r04/micro_attn_d512_key_split_sweep.log): eight
+    # stacked 5184-token tiled-VAE tiles are 328 workgroups = 2 rounds unsplit, 4 rounds of a third with 3 splits; two full rounds stay whole
+    per = 514 * 4
+    assert ws(8, 5184, 5184, 0) == 3 * 8 * 5184 * per and ws(16, 4096, 4096, 0) == 0 and ws(8, 7396, 7396, 0) == 0
+    assert ws(1, 5184, 5184, 0) == 6 * 5184 * per and ws(1, 7396, 7396, 0) == 4 * 7396 * per
+    assert ws(1, 1024, 1024, 0) == 8 * 1024 * per and ws(16, 1024, 1024, 0) == 2 * 16 * 1024 * per and ws(1, 480, 480, 0) == 0
     split = lib.supir_flash_attn_d512_split
     assert split(None, None, None, None, 1, 64, 64, 512, 512, 64, 512, 0.044, 0, None, 0, None) == -1
     assert split(fake, fake, fake, fake, 1, 4096, 4096, 512, 512, 4096, 512, 0.044, 0, None, 0, None) == -1          # needs a workspace
