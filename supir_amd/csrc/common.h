@@ -83,6 +83,15 @@ __device__ __forceinline__ float pair_sum_acc(uint32_t packed, float acc) {
 #endif
 }
 
+// acc + a.lo * b.lo + a.hi * b.hi over packed pairs of 16-bit elements (v_dot2c_f32_bf16 / v_dot2_f32_f16): two MACs per VALU instruction
+__device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float acc) {
+#ifdef SUPIR_F16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+#endif
+}
+
 // x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division: the division expands to ~10 VALU
 // instructions per element -- more than the rest of the GroupNorm + SiLU apply pass put together -- and the result is rounded to bf16
 // (2^-9) right after.  exp2(+inf) -> rcp(inf) = 0 -> -0 for very negative x, as before.

@@ -175,9 +175,106 @@ __global__ __launch_bounds__(256) void conv3x3_smallcout_kernel(const bf16_t* __
     }
 }
 
+// Register-resident form for Cin = 128 (round 4): the VAE decoder's conv_out (sgm/modules/diffusionmodules/model.py:694, 128 -> 3 at full
+// image resolution: 268 MB of input per 1024^2 image).  In the kernel above every lane re-reads its 9 x COUT weight vectors from LDS for
+// every pixel (27 reads of 16 B per pixel and lane: LDS-port bound, ~1 TB/s of input).  Here lane l of a 16-lane group owns channels
+// 8 l .. 8 l + 7 and keeps its slice of all 9 x COUT weight rows in registers (9 x COUT x 4 packed pairs: 108 for COUT = 3); a group walks
+// along an image row with a 3 x 3 window of 16-byte vectors -- one new column (3 loads) per pixel instead of 9 taps -- and multiplies with
+// v_dot2c (two MACs per instruction): no LDS in the loop, a third of the global-load instructions, half the VALU.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_c128_smallcout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                                     int B, int H, int W, int ldx, int nseg, int ntask) {
+    static_assert(COUT >= 1 && COUT <= 4, "9 x COUT x 4 weight registers per lane");
+    constexpr int SEG = 64;                          // pixels of one row a group handles per task
+    const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+    u32x4 wr[9][COUT];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) wr[tap][o] = *(const u32x4*)(w + (size_t)(tap * COUT + o) * 128 + 8 * l16);
+    const float bz = (l16 < COUT && bias) ? bias[l16] : 0.f;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const int nwg = (int)gridDim.x;
+    const int wg = xcd_remap((int)blockIdx.x, nwg);  // neighbouring image rows (they share two of their three input rows) on one XCD's L2
+    for (int task = wg * 16 + grp; task < ntask; task += nwg * 16) {
+        const int sg = task % nseg, by = task / nseg;
+        const int y = by % H, b = by / H;
+        const int x0 = sg * SEG, x1 = x0 + SEG < W ? x0 + SEG : W;
+        const bf16_t* rowp[3];
+        bool rok[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            rok[ky] = (unsigned)iy < (unsigned)H;
+            rowp[ky] = x + ((size_t)b * H + (rok[ky] ? iy : y)) * W * ldx + 8 * l16;
+        }
+        auto ld = [&](int ky, int ix) -> u32x4 {
+            return (rok[ky] && (unsigned)ix < (unsigned)W) ? *(const u32x4*)(rowp[ky] + (size_t)ix * ldx) : zero;
+        };
+        // one output pixel: columns xx - 1 / xx / xx + 1 of the window are A / B / C; C is loaded here, A and B came from the previous steps
+        auto step = [&](const u32x4 (&A)[3], const u32x4 (&Bc)[3], u32x4 (&C)[3], int xx) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) C[ky] = ld(ky, xx + 1);
+            float acc[COUT];
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[o] = dot2_acc(A[ky][e], wr[ky * 3 + 0][o][e], acc[o]);
+                        acc[o] = dot2_acc(Bc[ky][e], wr[ky * 3 + 1][o][e], acc[o]);
+                    }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[o] = dot2_acc(C[ky][e], wr[ky * 3 + 2][o][e], acc[o]);
+            float r = 0.f;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                float a = acc[o];
+                a += __shfl_xor(a, 8, 64);
+                a += __shfl_xor(a, 4, 64);
+                a += __shfl_xor(a, 2, 64);
+                a += __shfl_xor(a, 1, 64);
+                r = (l16 == o) ? a : r;
+            }
+            if (l16 < COUT) out[(((size_t)b * COUT + l16) * H + y) * W + xx] = r + bz;
+        };
+        u32x4 c0[3], c1[3], c2[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            c0[ky] = ld(ky, x0 - 1);
+            c1[ky] = ld(ky, x0);
+        }
+        for (int xx = x0; xx < x1; xx += 3) {   // the window's three column buffers rotate: no register moves
+            step(c0, c1, c2, xx);
+            if (xx + 1 >= x1) break;
+            step(c1, c2, c0, xx + 1);
+            if (xx + 2 >= x1) break;
+            step(c2, c0, c1, xx + 2);
+        }
+    }
+}
+
 int supir_conv3x3_smallcout_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* out, int B, int Cin,
                                    int H, int W, int Cout, int ldx, hipStream_t st) {
     if (B <= 0 || Cin % 8 != 0 || ldx % 8 != 0) return SUPIR_ERR_SHAPE;
+    if (Cin == 128 && (Cout == 3 || Cout == 4) && H > 0 && W > 0 && (long)B * H * ((W + 63) / 64) < 0x7fffffffL) {
+        const int nseg = (W + 63) / 64, ntask = B * H * nseg;
+        int nwg = (ntask + 15) / 16;
+        if (nwg > 512) nwg = 512;                    // two workgroups per CU (185 registers); the 27 weight loads of a lane are paid once per workgroup
+        if (Cout == 3)
+            SUPIR_LAUNCH(conv3x3_c128_smallcout_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, st, x, w, bias, out, B, H, W, ldx, nseg, ntask);
+        else
+            SUPIR_LAUNCH(conv3x3_c128_smallcout_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, x, w, bias, out, B, H, W, ldx, nseg, ntask);
+        return SUPIR_LAUNCH_STATUS();
+    }
     const size_t smem = (size_t)9 * Cout * Cin * 2;
     if (smem > 160 * 1024) return SUPIR_ERR_SHAPE;
     const long npix = (long)B * H * W;

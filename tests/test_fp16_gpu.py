@@ -197,6 +197,13 @@ def test_boundary_convs_f16():
     out = ops.conv3x3_smallcout(h, w9, None)
     check(out, F.conv2d(h.float().permute(0, 3, 1, 2), w9.float().reshape(3, 3, 4, 320).permute(2, 3, 0, 1), None, padding=1),
           rel=1e-4, name="smallcout")
+    # Cin = 128 -> 3: the register-resident form (v_dot2_f32_f16 in this build), ragged row segments
+    h = rnd(1, 24, 70, 128).to(HF)
+    w3, b3 = rnd(3, 128, 3, 3, scale=(9 * 128) ** -0.5, seed=4), rnd(3, seed=5)
+    with Wt.compute_dtype(HF):
+        w9 = Wt.conv3x3_w9(w3)
+    check(ops.conv3x3_smallcout(h, w9, b3),
+          F.conv2d(h.float().permute(0, 3, 1, 2), w9.float().reshape(3, 3, 3, 128).permute(2, 3, 0, 1), b3, padding=1), rel=1e-4, name="smallcout c128")
 
 
 # ------------------------------------------------------------------------------------------------- network level

@@ -267,7 +267,11 @@ def test_conv_smallcin(B, Cin, H, W, Cout):
     check(out, ref + add.float(), name="smallcin+add")
 
 
-@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 320, 32, 32, 4), (1, 512, 16, 24, 8), (1, 128, 64, 64, 3)])
+# Cin = 128 with Cout 3 / 4 takes the register-resident kernel (conv3x3_c128_smallcout_kernel: a 16-lane group walks 64-pixel row segments
+# with a rotating three-column window): ragged segment ends (W = 100, 65), rows of fewer pixels than the window (W = 2, 1), a single row,
+# batch > 1, and a 1024-wide row (16 segments)
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 320, 32, 32, 4), (1, 512, 16, 24, 8), (1, 128, 64, 64, 3), (2, 128, 40, 100, 3),
+                                            (1, 128, 33, 65, 4), (1, 128, 5, 2, 3), (2, 128, 1, 1, 3), (1, 128, 3, 1024, 3)])
 def test_conv_smallcout(B, Cin, H, W, Cout):
     x = rnd(B, H, W, Cin).to(BF)
     w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
