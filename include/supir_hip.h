@@ -8,10 +8,10 @@
  * Conventions
  *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
  *   - caller owns every buffer (including workspaces); the library allocates nothing.  Its only mutable state is the per-thread
- *     last-HIP-error code read by supir_last_hip_error -- plus, for callers of the DEPRECATED one-shot setters
- *     (supir_set_next_prefetch / supir_set_next_gn_partials, kept for one more round), the request those park until the next
- *     GEMM / conv launch of the thread.  New code passes the same requests as an ARGUMENT: the *_ex entry points take a
- *     `const supir_launch_hints*` (round 4) and touch no library state; results never depend on a prefetch request;
+ *     last-HIP-error code read by supir_last_hip_error.  Optional per-launch requests (next-weight prefetch, GroupNorm partials
+ *     from the producer) are an ARGUMENT: the *_ex entry points take a `const supir_launch_hints*` (may be NULL) and the entry
+ *     points without it carry no request (ABI 2 removed the thread-local one-shot setters of ABI 1); results never depend on a
+ *     prefetch request;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and stream ordered, never synchronise;
  *   - return 0 on success, <0 on error (SUPIR_ERR_*); never throws;
  *   - "bf16" buffers are raw 16-bit bfloat16 (IEEE binary16 in the f16 build, see supir_elem_type); activations are NHWC / token-major: element (b, y, x, c) of a
@@ -228,17 +228,16 @@ int supir_groupnorm_nhwc(const void* x1, const void* x2, const void* x1raw, cons
                          size_t workspace_bytes, const float* given_mean_var, void* stream);
 
 /* GroupNorm with the statistics supplied by the PRODUCER of its input(s) instead of a statistics pass over the tensor:
- *   supir_launch_hints.gn_partials_out of the producing *_ex launch (preferred), or the DEPRECATED
- *   supir_set_next_gn_partials(buf) -- per calling thread, one-shot (like supir_set_next_prefetch): the next supir_gemm_bf16 /
- *     supir_gemm_bf16_ln / supir_conv3x3_bf16 launch (tiles 32..35 only, bf16 row-major output, rows_per_batch % BM == 0,
- *     N % 10 == 0; anything else -> SUPIR_ERR_SHAPE) also writes, per batch b, tile row c (BM = 128 or 256 tokens) and 10-channel
- *     unit u, the (sum, sum of squares) of the bf16 values it stored: buf[((b * (rows_per_batch / BM) + c) * (N / 10) + u) * 2 + {0,1}];
+ *   supir_launch_hints.gn_partials_out of the producing *_ex launch: the supir_gemm_bf16_ex / supir_gemm_bf16_ln_ex /
+ *     supir_conv3x3_bf16_ex launch (tiles 32..35 and 39 / 40 only, bf16 row-major output, rows_per_batch % BM == 0, N % unit == 0
+ *     with unit = 10 channels for the 80 / 160-column tiles and 4 for the 128 / 256-column ones; anything else -> SUPIR_ERR_SHAPE)
+ *     also writes, per batch b, tile row c (BM = 128 or 256 tokens) and channel unit u, the (sum, sum of squares) of the bf16
+ *     values it stored: buf[((b * (rows_per_batch / BM) + c) * (N / unit) + u) * 2 + {0,1}];
  *   supir_groupnorm_nhwc_parts(..., part1, nchunk1, part2, nchunk2, stream) -- supir_groupnorm_nhwc with those buffers for x1
  *     (and x2 when C1 < C; each source with its own chunk count) in place of workspace / given_mean_var: one launch, no
  *     statistics pass.  Needs (C / 32) % 10 == 0 and C1 % 10 == 0 (every GroupNorm32 of the UNet / control net qualifies).
  * Replaces the statistics half of GroupNorm32 (sgm/modules/diffusionmodules/util.py:258-276) wherever the input comes straight
  * out of a convolution or linear layer (openaimodel.py:295-308 out_layers, :260-264 in_layers, attention.py:583-586 norm). */
-int supir_set_next_gn_partials(float* part_out);
 int supir_groupnorm_nhwc_parts(const void* x1, const void* x2, const void* x1raw, const void* x2raw, int B, int HW, int C, int C1,
                                int ld1, int ld2, const float* gamma, const float* beta, float eps, int act, const void* mod_g,
                                const void* mod_b, int ldm, float control_scale, void* out, int ldo, const float* part1, int nchunk1,
@@ -315,20 +314,25 @@ int supir_edm_step_pre(const float* x, const float* eps, float s_noise, float no
 int supir_edm_step_post(const float* net_out, const float* x_hat, const float* x_center, float c_out, float c_skip, float cfg_scale,
                         float restore_mul, float sigma_hat, float dt, float* x_next, long n, int reps, void* stream);
 
+/* The tiled sampler's step edges (TiledRestoreEDMSampler.__call__, sgm/modules/diffusionmodules/sampling.py:600-660): per step the
+ * latent canvas x [b][C][Hc][Wc] (fp32) is cut into overlapping T x T tiles (`_sliding_windows`, :752-766), each tile takes a
+ * sampler_step, and `x_next[:, :, hi:he, wi:we] += _x * tile_weights` (:654-657) blends them.  One network call serves k tiles
+ * stacked along the batch axis (tile j, sample i at row j*b + i); tile_hw = HOST array of k (hi, wi) origins, k <= 64.
+ *   supir_edm_step_pre_tiles: supir_edm_step_pre reading x / eps (both canvases; eps may be NULL) through the k tile windows:
+ *       x_hat [k*b][C][T][T], net_in [reps][k*b][C][T][T].  Same arithmetic per element as the crop + supir_edm_step_pre.
+ *   supir_tile_blend: canvas[tile_j] += tiles[j] * weights for j = 0..k-1 in ONE launch, per element in tile order, evaluated as
+ *       torch does for `fp32 += fp32 * fp64` (weights [T][T] are float64 there, sampling.py:733-750): (float)((double)acc + (double)t * w)
+ *       with separately rounded multiply and add -- bitwise the k sequential slice-adds of the reference. */
+int supir_edm_step_pre_tiles(const float* x, const float* eps, float s_noise, float noise_mul, float c_in, float* x_hat, float* net_in,
+                             const int* tile_hw, int k, int b, int C, int Hc, int Wc, int T, int reps, void* stream);
+int supir_tile_blend(const float* tiles, const double* weights, float* canvas, const int* tile_hw, int k, int b, int C, int Hc, int Wc,
+                     int T, void* stream);
+
 /* Touch one dword per 128-byte line of [p, p+bytes) (a weight matrix) so that it is in flight through the memory-side
  * cache before the kernel that consumes it starts; launched a few ops ahead on a separate stream. `sink`: any 4 writable
  * device bytes (never written in practice). No reference counterpart: the reference re-reads fp32 weights through
  * autocast casts every step (sgm/modules/diffusionmodules/wrappers.py:87). */
 int supir_prefetch(const void* p, size_t bytes, void* sink, void* stream);
-
-/* DEPRECATED (round 4; removed next round) -- pass supir_launch_hints.next_weight to the *_ex entry points instead: a caller that
- * interleaves launches for two streams from one thread can arm the wrong launch with a thread-local one-shot.
- * One-shot request, consumed by the NEXT supir_gemm_bf16 / supir_gemm_bf16_ln / supir_conv3x3_bf16 call made from this thread:
- * that launch, after its last store, touches the first `bytes` (whole 128-byte lines) of `p` so that a LATER launch finds
- * them in the Infinity Cache / L2 instead of HBM.  `p` is the bf16 weight matrix of that later launch (the host mirror knows
- * the launch order of a network call: supir_amd/ops.py WeightPrefetch).  Read-only, results unaffected; bytes = 0 cancels.
- * No reference counterpart (the reference's cuBLAS / cuDNN calls meet every weight cold each step as well). */
-int supir_set_next_prefetch(const void* p, size_t bytes);
 
 /* Split-K form of supir_conv3x3_bf16 for convolutions whose tile grid is a fraction of the machine and whose K = 9 * Cin is long -- the
  * `mlp_shared` convolutions of ZeroSFT (SUPIR/modules/SUPIR_v0.py:72-75, 100: label_nc -> 128 channels: 64 tiles of 64 x 64 at 32 x 32
@@ -340,8 +344,9 @@ int supir_conv3x3_bf16_splitk(const void* X, const void* W, float* partials, int
                               int OW, int stride, int pad_t, int pad_l, int upsample, int ksplit, int tile, void* stream);
 int supir_splitk_finalize(const float* partials, int ksplit, int M, int N, const float* bias, int act, void* out, int ldo, void* stream);
 
+#ifdef SUPIR_EXPERIMENTAL
 /* ---- Grouped launches: n (1 or 2) independent problems of identical shape in ONE kernel launch ------------------------------------
- * EXPERIMENTAL (round 3): correct and tested (bitwise equal to the single launches, tests/test_grouped_gpu.py), but NOT used by the
+ * EXPERIMENTAL (round 3; declared only under -DSUPIR_EXPERIMENTAL, exported by the library either way): correct and tested (bitwise equal to the single launches, tests/test_grouped_gpu.py), but NOT used by the
  * product's default path -- on the 1024^2 step two free-running chains of single launches measured faster than grouped launches
  * (every grouped launch is a join of the two chains: DESIGN.md section 3).  The entry points and struct layouts may change.
  * SUPIR runs two networks of identical architecture on independent data inside every sampling step: GLVControl (the control
@@ -351,7 +356,7 @@ int supir_splitk_finalize(const float* partials, int ksplit, int M, int N, const
  * two layers as one grid (problem q on XCDs [4 q, 4 q + 4), its operands in those four L2s); the host mirror records both
  * branches and issues the pairs (supir_amd/ops.py paired_run).  Arguments that fix the grid (`shape`) are shared; pointers,
  * strides and optional operands are per problem.  n = 1 is exactly the corresponding single entry point.  Per problem the
- * explicit `prefetch` / `gn_partials_out` fields replace the one-shot supir_set_next_* requests (which these calls ignore).
+ * explicit `prefetch` / `gn_partials_out` fields play the role of supir_launch_hints.
  * The structs are HOST memory, read during the call only. */
 typedef struct supir_gemm_problem {
     const void* A;            /* [M][lda] bf16 (conv: NHWC input [B][H][W][lda]) */
@@ -364,8 +369,8 @@ typedef struct supir_gemm_problem {
     float* rowstats_out;      /* LayerNorm-fold producer output or NULL (see supir_gemm_bf16_ln) */
     const float* ln_stats;    /* LayerNorm-fold consumer input or NULL */
     const float* ln_colsum;
-    float* gn_partials_out;   /* GroupNorm unit partials or NULL (see supir_set_next_gn_partials) */
-    const void* prefetch;     /* weight matrix of a later launch to touch on the way out, or NULL (see supir_set_next_prefetch) */
+    float* gn_partials_out;   /* GroupNorm unit partials or NULL (see supir_launch_hints.gn_partials_out) */
+    const void* prefetch;     /* weight matrix of a later launch to touch on the way out, or NULL (see supir_launch_hints.next_weight) */
     size_t prefetch_bytes;
     int lda, ldc, ldc2, ldr, ld_rowbias, rs_ld, ln_ld, ln_slots;
 } supir_gemm_problem;
@@ -416,6 +421,7 @@ typedef struct supir_gn_problem {
 /* supir_groupnorm_nhwc / supir_groupnorm_nhwc_parts for n problems sharing (B, HW, C, eps, act); every problem must take its
  * statistics the same way (all from producer partials, or all from their own statistics pass). */
 int supir_groupnorm_grouped(const supir_gn_problem* problems, int n, int B, int HW, int C, float eps, int act, void* stream);
+#endif /* SUPIR_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

@@ -231,11 +231,13 @@ def main():
             torch.randn_like = orig
         gold["sliding_windows_24_40_16_8"] = S._sliding_windows(24, 40, 16, 8)
 
-        # DPM++ 2M restore sampler (config 5). k_diffusion is not installed: the reference class is run with the published
-        # Karras schedule (supir_amd.modules.sampling.get_sigmas_karras) and a scripted noise sampler injected, so the
-        # solver arithmetic is pinned while the schedule / Brownian-tree noise stream stay parity-unpinned.
-        from supir_amd.modules.sampling import get_sigmas_karras as karras
-        S.get_sigmas_karras = lambda n, smin, smax, device="cpu": karras(n, float(smin), float(smax), device=device)
+        # DPM++ 2M restore sampler (config 5). k_diffusion is not installed: the reference class is run with the ORACLE's
+        # restatement of the published k-diffusion 0.1.1 `get_sigmas_karras` (oracle/supir_oracle.py kdiff_get_sigmas_karras,
+        # called exactly as the reference calls it: 0-dim fp32 tensors) -- NOT with the product's function, which
+        # tests/test_host_logic.py checks against the same restatement -- and a scripted noise sampler injected, so the solver
+        # arithmetic and the schedule formula are pinned while the Brownian-tree seed -> noise map stays parity-unpinned.
+        from oracle.supir_oracle import kdiff_get_sigmas_karras
+        S.get_sigmas_karras = kdiff_get_sigmas_karras
 
         class ScriptedNoise:
             def __init__(self, x, smin, smax):

@@ -248,6 +248,26 @@ def control_wrapper(sd, x, t, c, control_scale=1.0, p="model."):
 
 
 # ----------------------------------------------------------------------------------------------- denoiser / sampler
+def kdiff_append_zero(x):
+    """k-diffusion 0.1.1.post1 `append_zero` (k_diffusion/sampling.py; third-party, requirements.txt:41 -- not in the reference tree)."""
+    return torch.cat([x, x.new_zeros([1])])
+
+
+def kdiff_get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0, device="cpu"):
+    """k-diffusion 0.1.1.post1 `get_sigmas_karras` (k_diffusion/sampling.py, "Constructs the noise schedule of Karras et al.
+    (2022)"), restated from the PUBLISHED package source -- third-party (requirements.txt:41), absent from /root/reference and not
+    installable here.  Called by the reference at sgm/modules/diffusionmodules/sampling.py:491-492 and :684-685 with
+    sigma_min = sigmas[-2].cpu(), sigma_max = sigmas[0].cpu() (0-dim fp32 tensors) and device = x.device: the ramp is a default-dtype
+    (fp32) linspace on the CPU, the rho-th roots and the rho-th power are fp32 TENSOR pows, and the zero is appended before the move.
+    Independent of supir_amd.modules.sampling.get_sigmas_karras, which tests/test_host_logic.py checks against THIS function.
+    Still third-party: "parity unpinned" against an installed k-diffusion, pinned against the published formula."""
+    ramp = torch.linspace(0, 1, n)
+    min_inv_rho = sigma_min ** (1 / rho)
+    max_inv_rho = sigma_max ** (1 / rho)
+    sigmas = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
+    return kdiff_append_zero(sigmas).to(device)
+
+
 def ddpm_sigmas(n=1000, linear_start=0.00085, linear_end=0.0120, num_timesteps=1000, device="cpu"):
     """LegacyDDPMDiscretization (sgm/modules/diffusionmodules/discretizer.py:42-69) incl. make_beta_schedule('linear')
     = linspace(sqrt(start), sqrt(end), n)**2 in float64 (util.py:25-33). Returned in INCREASING-t order flipped, i.e.

@@ -41,10 +41,12 @@ SIGNATURES = {
     "supir_bicubic_f32": [P, P, P, I, I, I, I, I, P],
     "supir_edm_step_pre": [P, P, F, F, F, P, P, L, I, P],
     "supir_edm_step_post": [P, P, P, F, F, F, F, F, F, P, L, I, P],
+    # x, eps, s_noise, noise_mul, c_in, x_hat, net_in, tile_hw (host int[2k]), k, b, C, Hc, Wc, T, reps, stream
+    "supir_edm_step_pre_tiles": [P, P, F, F, F, P, P, P, I, I, I, I, I, I, I, P],
+    # tiles, weights (fp64 [T][T]), canvas, tile_hw, k, b, C, Hc, Wc, T, stream
+    "supir_tile_blend": [P, P, P, P, I, I, I, I, I, I, P],
     "supir_gemm_tile_for": [I, I, I],
     "supir_prefetch": [P, c_size_t, P, P],
-    "supir_set_next_prefetch": [P, c_size_t],
-    "supir_set_next_gn_partials": [P],
     "supir_groupnorm_nhwc_parts": [P, P, P, P, I, I, I, I, I, I, P, P, F, I, P, P, I, F, P, I, P, I, P, I, P],
     "supir_rowstats_finalize": [P, P, I, I, I, I, F, P],
     "supir_gemm_bf16_qkv": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, F, P],
@@ -101,6 +103,7 @@ SIGNATURES.update({
 # entry points that return a byte count (size_t) instead of a status
 SIZE_SIGNATURES = {"supir_flash_attn_d512_workspace": [I, I, I, I]}
 
+ABI_VERSION = 2   # include/supir_hip.h: round 5 removed the thread-local one-shot setters, added the tiled-sampler edges
 _lib = None       # the bf16 library (the product default)
 _lib_f16 = None   # the fp16 build, loaded on first use
 
@@ -142,7 +145,7 @@ def load(dtype=None):
     lib.supir_hip_error_string.argtypes = [c_int]
     lib.supir_elem_type.restype = c_char_p
     lib.supir_elem_type.argtypes = []
-    if lib.supir_abi_version() != 1:
+    if lib.supir_abi_version() != ABI_VERSION:
         raise SupirHipError(f"{os.path.basename(path)} ABI version mismatch")
     want = b"f16" if f16 else b"bf16"
     if lib.supir_elem_type() != want:

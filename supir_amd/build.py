@@ -31,8 +31,16 @@ def _stale(lib=LIB):
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "xattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
+def _obj_stale(src, obj):
+    """An object is rebuilt when its source or any shared header is newer (headers are few and included everywhere)."""
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in [src] + HEADERS)
+
+
 def build(force=False, verbose=True):
-    """Compile every stale variant (all translation units of all variants in parallel), link, return the bf16 library's path."""
+    """Compile every stale translation unit of every stale variant (in parallel), link, return the bf16 library's path."""
     todo = [v for v in VARIANTS if force or _stale(v[0])]
     if not todo:
         return LIB
@@ -45,11 +53,13 @@ def build(force=False, verbose=True):
         objs[lib] = []
         for src in SOURCES:
             obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            objs[lib].append(obj)
+            if not force and not _obj_stale(src, obj):
+                continue
             cmd = base + cflags + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print("[supir_amd.build]", " ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))
-            objs[lib].append(obj)
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)

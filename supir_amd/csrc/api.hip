@@ -10,29 +10,9 @@ int supir_note_hip_status(hipError_t e) {
     return SUPIR_ERR_HIP;
 }
 
-// one-shot prefetch request, consumed by the next GEMM / conv launch issued from this thread
-static thread_local const char* g_pf_ptr = nullptr;
-static thread_local unsigned g_pf_lines = 0;
-// one-shot request for GroupNorm partial statistics from the producer (supir_set_next_gn_partials), same scope and lifetime
-static thread_local float* g_gn_part_out = nullptr;
-// DEPRECATED path (supir_set_next_prefetch / supir_set_next_gn_partials + the entry points without a hints argument): the
-// thread-local one-shot request, consumed here
-static void take_prefetch(GemmArgs& a) {
-    a.pf_ptr = g_pf_ptr;
-    a.pf_lines = g_pf_lines;
-    g_pf_ptr = nullptr;
-    g_pf_lines = 0;
-    a.gn_part_out = g_gn_part_out;
-    g_gn_part_out = nullptr;
-}
-// The *_ex entry points carry the same two requests as an ARGUMENT (supir_launch_hints, may be NULL): no library state involved.
-// hints == SUPIR_HINTS_FROM_TLS marks a call that came in through a legacy entry point.
-static const supir_launch_hints* const SUPIR_HINTS_FROM_TLS = (const supir_launch_hints*)(uintptr_t)1;
+// Per-launch requests (next-weight prefetch, GroupNorm partials) arrive as an ARGUMENT of the *_ex entry points
+// (supir_launch_hints, may be NULL); the entry points without that argument carry none.  The library holds no request state.
 static int apply_hints(GemmArgs& a, const supir_launch_hints* h) {
-    if (h == SUPIR_HINTS_FROM_TLS) {
-        take_prefetch(a);
-        return SUPIR_OK;
-    }
     if (!h) return SUPIR_OK;
     if (h->next_weight_bytes && !h->next_weight) return SUPIR_ERR_ARG;
     const size_t lines = h->next_weight_bytes / 128;
@@ -54,23 +34,10 @@ int supir_debug_knob(int which, int value) {
     return SUPIR_OK;
 }
 
-int supir_set_next_prefetch(const void* p, size_t bytes) {
-    if (bytes && !p) return SUPIR_ERR_ARG;
-    const size_t lines = bytes / 128;
-    g_pf_ptr = (const char*)p;
-    g_pf_lines = lines > 0x7fffffffu ? 0x7fffffffu : (unsigned)lines;
-    return SUPIR_OK;
-}
-
-int supir_set_next_gn_partials(float* part_out) {
-    g_gn_part_out = part_out;
-    return SUPIR_OK;
-}
-
 int supir_last_hip_error(void) { return g_last_hip_error; }
 const char* supir_hip_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
-int supir_abi_version(void) { return 1; }
+int supir_abi_version(void) { return 2; }
 const char* supir_target_arch(void) { return "gfx950"; }
 const char* supir_elem_type(void) { return SUPIR_ELEM_NAME; }
 int supir_gemm_tile_for(int M, int N, int act) { return supir_gemm_select_tile(M, N, act, -1); }
@@ -79,7 +46,7 @@ int supir_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int 
                        const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                        int out_mode, float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 40 || tile == 36) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 42 || tile == 36 || tile == 41) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
@@ -97,7 +64,7 @@ int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, 
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream) {
     return supir_gemm_bf16_ex(A, W, C, M, N, K, lda, ldc, bias, rowbias, ld_rowbias, rows_per_batch, residual, ldr, act, out_mode, alpha,
-                              tile, SUPIR_HINTS_FROM_TLS, stream);
+                              tile, nullptr, stream);
 }
 
 int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
@@ -105,7 +72,7 @@ int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, i
                           float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                           const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 40 || tile == 36) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 42 || tile == 36 || tile == 41) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
     if (rowstats_out && (out_mode != 0 || act == 2 || rs_ld <= 0)) return SUPIR_ERR_ARG;
@@ -120,7 +87,7 @@ int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, i
     if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0))) return SUPIR_ERR_SHAPE;
     if (rowstats_out) {  // the slot index is tile_n * waves_n + wave_n: the caller's rs_ld must cover the tile actually used
         const int sel = supir_gemm_select_tile(M, N, act, tile < 0 ? -1 : (tile & 7));
-        const int bn = (tile == 32 || tile == 35 || tile == 38) ? 80 : (tile == 33 || tile == 34) ? 160 : tile == 39 ? 128 : tile == 40 ? 256 : (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
+        const int bn = (tile == 32 || tile == 35 || tile == 38) ? 80 : (tile == 33 || tile == 34) ? 160 : tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
         if ((N + bn - 1) / bn > rs_ld || (rs_ld & 1)) return SUPIR_ERR_ARG;
     }
     if (const int rc = apply_hints(a, hints)) return rc;
@@ -132,7 +99,7 @@ int supir_gemm_bf16_ln(const void* A, const void* W, void* C, int M, int N, int 
                        float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                        const float* ln_colsum, float ln_eps, void* stream) {
     return supir_gemm_bf16_ln_ex(A, W, C, M, N, K, lda, ldc, bias, residual, ldr, act, out_mode, rows_per_batch, alpha, tile, rowstats_out,
-                                 rs_ld, ln_stats, ln_ld, ln_slots, ln_colsum, ln_eps, SUPIR_HINTS_FROM_TLS, stream);
+                                 rs_ld, ln_stats, ln_ld, ln_slots, ln_colsum, ln_eps, nullptr, stream);
 }
 
 int supir_gemm_bf16_qkv_ex(const void* A, const void* W, void* Cqk, void* Cvt, int M, int N, int n_split, int K, int lda, int ldc,
@@ -156,7 +123,7 @@ int supir_gemm_bf16_qkv(const void* A, const void* W, void* Cqk, void* Cvt, int 
                         int ldc_vt, int rows_per_batch, const float* bias, const float* ln_stats, int ln_ld, int ln_slots,
                         const float* ln_colsum, float ln_eps, void* stream) {
     return supir_gemm_bf16_qkv_ex(A, W, Cqk, Cvt, M, N, n_split, K, lda, ldc, ldc_vt, rows_per_batch, bias, ln_stats, ln_ld, ln_slots,
-                                  ln_colsum, ln_eps, SUPIR_HINTS_FROM_TLS, stream);
+                                  ln_colsum, ln_eps, nullptr, stream);
 }
 
 int supir_rowstats_finalize(const float* partials, float* mean_rstd, int M, int ld, int slots, int dim, float eps,
@@ -171,7 +138,7 @@ int supir_conv3x3_bf16_ex(const void* X, const void* W, void* Y, int B, int H, i
                           float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!X || !W || !Y) return SUPIR_ERR_ARG;
     if (B <= 0 || H <= 0 || Wd <= 0 || OH <= 0 || OW <= 0) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || (tile > 35 && (tile < 38 || tile > 40))) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || (tile > 35 && (tile < 38 || tile > 40) && tile != 42)) return SUPIR_ERR_ARG;
     if (stride != 1 && stride != 2) return SUPIR_ERR_SHAPE;
     if (upsample && stride != 1) return SUPIR_ERR_SHAPE;
     if (ldy % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)) return SUPIR_ERR_SHAPE;
@@ -192,7 +159,7 @@ int supir_conv3x3_bf16(const void* X, const void* W, void* Y, int B, int H, int 
                        const void* rowbias, int ld_rowbias, const void* residual, int ldr, int act, int out_mode,
                        float alpha, int tile, void* stream) {
     return supir_conv3x3_bf16_ex(X, W, Y, B, H, Wd, Cin, ldx, Cout, ldy, OH, OW, stride, pad_t, pad_l, upsample, bias, rowbias, ld_rowbias,
-                                 residual, ldr, act, out_mode, alpha, tile, SUPIR_HINTS_FROM_TLS, stream);
+                                 residual, ldr, act, out_mode, alpha, tile, nullptr, stream);
 }
 
 int supir_conv3x3_bf16_splitk(const void* X, const void* W, float* partials, int B, int H, int Wd, int Cin, int ldx, int Cout, int OH,
@@ -207,8 +174,6 @@ int supir_conv3x3_bf16_splitk(const void* X, const void* W, float* partials, int
     a.H = H; a.W = Wd; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
     a.up = upsample ? 1 : 0;
     a.out_mode = 1; a.alpha = 1.0f; a.ksplit = ksplit;
-    take_prefetch(a);
-    if (a.gn_part_out) return SUPIR_ERR_ARG;
     return supir_gemm_launch(a, true, (hipStream_t)stream, tile);
 }
 
@@ -389,6 +354,32 @@ int supir_edm_step_post(const float* net_out, const float* x_hat, const float* x
     if (!net_out || !x_hat || !x_next) return SUPIR_ERR_ARG;   // x_center NULL: no restoration guidance on this step
     return supir_edm_post_launch(net_out, x_hat, x_center, c_out, c_skip, cfg_scale, restore_mul, sigma_hat, dt, x_next, n, reps,
                                  (hipStream_t)stream);
+}
+
+static int pack_tiles(SupirTileList& tl, const int* tile_hw, int k) {
+    if (!tile_hw || k <= 0 || k > SUPIR_MAX_TILES) return SUPIR_ERR_ARG;
+    tl.n = k;
+    for (int j = 0; j < k; ++j) {
+        tl.hi[j] = tile_hw[2 * j];
+        tl.wi[j] = tile_hw[2 * j + 1];
+    }
+    return SUPIR_OK;
+}
+
+int supir_edm_step_pre_tiles(const float* x, const float* eps, float s_noise, float noise_mul, float c_in, float* x_hat, float* net_in,
+                             const int* tile_hw, int k, int b, int C, int Hc, int Wc, int T, int reps, void* stream) {
+    if (!x || !x_hat || !net_in) return SUPIR_ERR_ARG;
+    SupirTileList tl;
+    if (const int rc = pack_tiles(tl, tile_hw, k)) return rc;
+    return supir_edm_pre_tiles_launch(x, eps, s_noise, noise_mul, c_in, x_hat, net_in, tl, b, C, Hc, Wc, T, reps, (hipStream_t)stream);
+}
+
+int supir_tile_blend(const float* tiles, const double* weights, float* canvas, const int* tile_hw, int k, int b, int C, int Hc, int Wc,
+                     int T, void* stream) {
+    if (!tiles || !weights || !canvas) return SUPIR_ERR_ARG;
+    SupirTileList tl;
+    if (const int rc = pack_tiles(tl, tile_hw, k)) return rc;
+    return supir_tile_blend_launch(tiles, weights, canvas, tl, b, C, Hc, Wc, T, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------- grouped launches

@@ -33,6 +33,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 
+#define SUPIR_EXPERIMENTAL 1          // the library always builds (and exports) the experimental section of the header
 #include "../../include/supir_hip.h"  // error codes shared with the C ABI
 
 // hipGetLastError() is per-thread sticky state shared with every other HIP user in the process (PyTorch): clear whatever

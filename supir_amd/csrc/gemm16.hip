@@ -22,6 +22,10 @@
 //   40   256 x 256  4x2               1       2   128 KB   256 / 512-channel outputs of the VAE (32 B/clk of fill per CU: the one tile
 //                                                          of the family under the 38 B/clk the loops sustain); one 32-wide K slice of
 //                                                          fragments in registers at a time (128 accumulator registers)
+//   42   256 x 256  2x4  8-phase      1       2   128 KB   the same outputs on the eight-phase ping-pong schedule (round 5, below): half-tile
+//                                                          staging with three half-tiles in flight across the barriers, the two waves of
+//                                                          every SIMD alternating between a fragment-read / load-issue segment and a
+//                                                          16-MFMA segment
 //
 //  * 512 threads.  KS = 2: two K groups of four waves, group g takes K steps g, g+2, ... from its own LDS ring, so every SIMD
 //    holds two waves (one per group) whose load issue / LDS reads / MFMAs interleave; the partial accumulators are
@@ -81,7 +85,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     const int vxcd = (int)blockIdx.x & (NX - 1), vidx = (int)blockIdx.x >> 3;   // XCD inside the problem's share, index on that XCD
     G16_TL(tl_start);
     constexpr int NW = WM * WN;                          // waves per K group
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, RING = S * STAGE_BYTES;
+    constexpr bool PH8 = S == 8;                         // the eight-phase schedule (tile 42): S names the schedule, the ring is 2 deep
+    constexpr int SD = PH8 ? 2 : S;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, RING = SD * STAGE_BYTES;
     constexpr int A_Q = BM / 8 / NW;                     // 8-row chunks of A per wave and K step (chunk id = wave + NW q)
     constexpr int B_CH = BN / 8, B_Q = (B_CH + NW - 1) / NW;   // chunks of W per tile / per wave (the last q may be partial)
     constexpr int LOADS = A_Q + B_Q;                     // global->LDS instructions per wave and stage
@@ -89,7 +95,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     constexpr int NWT = NW * KS, NTHREADS = 64 * NWT;   // waves / threads per workgroup (8 / 512; tile 38: 4 / 256)
     static_assert((NWT == 8 || (NWT == 4 && KS == 1 && !MIXED && NP == 1)) && (BM / 8) % NW == 0 && (NW & 1) == 0,
                   "512 threads (or the four-wave single-group form); A chunks divide over the waves");
-    static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3), "tile / wave grid");
+    static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3 || S == 8), "tile / wave grid");
+    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && KS == 1 && !TRANS && !MIXED && NP == 1), "eight-phase schedule: 256 x 256, 2 x 4 waves");
     static_assert(!(CONV && TRANS) && !(MIXED && (TRANS || CONV || KS != 1)), "the implicit-GEMM loader has no transposed epilogue");
     // epilogue LDS map (the rings are idle by then): [0, XCH) K-group exchange, then per-wave C staging, bias / column sums,
     // row-statistics scratch
@@ -147,6 +154,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     const bf16_t* c_tap[CONV ? A_Q : 1];
     int c_cin0 = kg * 64, c_ky = 0, c_kx = 0;
     const int VH = p.up ? 2 * p.H : p.H, VW = p.up ? 2 * p.W : p.W;
+    // eight-phase schedule: a tile's 256 rows lie in ONE batch element (dispatcher), so the image base is wave-uniform and a lane keeps a
+    // 32-bit element offset per row (< 0: halo / padding) instead of two pointers -- 10 VGPRs less in a kernel that sits at the 256 limit
+    int ph8_toff[CONV && PH8 ? A_Q : 1];
+    const bf16_t* ph8_cbase = nullptr;
     auto conv_set_tap = [&]() {
         if constexpr (CONV) {
 #pragma unroll
@@ -154,20 +165,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                 int iy = c_iy0[q] + c_ky, ix = c_ix0[q] + c_kx;
                 const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW;
                 if (p.up) { iy >>= 1; ix >>= 1; }
-                c_tap[q] = ok ? c_base[q] + ((size_t)iy * p.W + ix) * p.lda : nullptr;
+                if constexpr (PH8) ph8_toff[q] = ok ? (iy * p.W + ix) * p.lda : -1;
+                else c_tap[q] = ok ? c_base[q] + ((size_t)iy * p.W + ix) * p.lda : nullptr;
             }
         }
     };
     if constexpr (CONV) {
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
-            const int m = m0 + (wave + NW * q) * 8 + lrow;
+            // eight-phase schedule: q = 2 h + qq is this lane's row of A-half h (token fragments [4h, 4h + 4) of both wave rows), wave row qq
+            const int m = PH8 ? m0 + (q & 1) * 128 + (q >> 1) * 64 + wave * 8 + lrow : m0 + (wave + NW * q) * 8 + lrow;
             const int b = m / p.rows_per_batch, r = m - b * p.rows_per_batch;
             const int oy = r / p.OW, ox = r - oy * p.OW;
             c_iy0[q] = oy * p.stride - p.pad_t;
             c_ix0[q] = ox * p.stride - p.pad_l;
-            c_base[q] = p.A + (size_t)b * p.H * p.W * p.lda + lchunk * 8;
+            if constexpr (!PH8) c_base[q] = p.A + (size_t)b * p.H * p.W * p.lda + lchunk * 8;
         }
+        if constexpr (PH8) ph8_cbase = p.A + (size_t)(m0 / p.rows_per_batch) * p.H * p.W * p.lda + lchunk * 8;
         conv_set_tap();
     }
     // one global->LDS instruction: q < A_Q -> A chunk wave + NW q, else W chunk wave + NW (q - A_Q).  A wave whose last W chunk
@@ -223,12 +237,81 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     const int a_row_off = (wm * WTM + l15) * 128;
     const int b_row_off = A_BYTES + (wn * WTN + l15) * 128;
 
-    const int nk = (p.K >> 6) / KS;   // K steps of this group (>= S - 1: dispatcher)
+    const int nk = (p.K >> 6) / KS;   // K steps of this group (>= S - 1: dispatcher; eight-phase schedule: >= 2)
+
+    // ---- eight-phase schedule (tile 42): LDS = two K-tile buffers of four 16 KB HALF-TILES [A0 | A1 | W0 | W1].  A-half h holds token
+    // fragments [4h, 4h + 4) of BOTH wave rows (local row wm * 64 + i * 16 + l15), W-half h channel fragments [2h, 2h + 2) of all four wave
+    // columns (local row wn * 32 + j * 16 + l15): a half-tile is what ONE phase's MFMAs newly need, so it is free again a phase after it was
+    // read and its successor (K-tile + 2, same buffer) can be on its way seven phases before it is needed.  A K-tile is four phases:
+    //     phase  fragment reads (ds_read_b128)      MFMAs (16 each)                    half-tile staged (2 x 1 KB per wave)
+    //       0    A0 (8) + W0 (4)                     tokens 0-3 x channels 0-1          W0 of K-tile u + 1
+    //       1    W1 (4)                              tokens 0-3 x channels 2-3          A0 of K-tile u + 2
+    //       2    A1 (8)                              tokens 4-7 x channels 2-3          W1 of K-tile u + 2
+    //       3    W0 (4, again)                       tokens 4-7 x channels 0-1          A1 of K-tile u + 2   + the K-tile's ONE counted wait
+    // Each phase is [reads + loads + lgkmcnt(0)] s_barrier [MFMAs] s_barrier; wave row 1 runs ONE barrier behind wave row 0, so on every
+    // SIMD (one wave of each row) one wave is in its MFMA segment while the other reads fragments and issues loads.  Hazards (interval =
+    // the time between two consecutive barriers; row g's phase p reads in interval 2p + g):
+    //   WAR  a half-tile's last reads are complete (lgkmcnt(0)) before the barrier that ends their interval, for both rows by the end of
+    //        interval 2p + 1; its successor is issued in phase p + 1 or later (interval >= 2p + 2);
+    //   RAW  every wave waits vmcnt(6) in the read segment of phase 3 (after issuing that phase's loads): everything up to W0 of the NEXT
+    //        K-tile -- the youngest half-tile it needs -- has landed, three half-tiles stay in flight; row 1 executes that wait one interval
+    //        later than row 0, i.e. before the barrier that ends interval 8u + 7, and the first read of K-tile u + 1 is in interval 8u + 8.
+    int ph8_kw0 = 64, ph8_kw1 = 0, ph8_ka = 0;   // K offsets (elements) of the next W0 / W1 / A half-tiles to stage
+    const bf16_t* ph8_a = nullptr;
+    const bf16_t* ph8_w = nullptr;
+    if constexpr (PH8) {
+        ph8_a = p.A + (size_t)(m0 + wave * 8 + lrow) * p.lda + lchunk * 8;
+        ph8_w = p.Wt + (size_t)(n0 + (wave >> 2) * 64 + (wave & 3) * 8 + lrow) * p.K + lchunk * 8;
+    }
+    auto ph8_stage_a = [&](int buf, int h) {
+        char* dst = smem + buf * STAGE_BYTES + h * 16384 + wave * 1024;
 #pragma unroll
-    for (int s = 0; s < S - 1; ++s) {
+        for (int qq = 0; qq < 2; ++qq) {
+            if constexpr (CONV) {
+                const int off = ph8_toff[2 * h + qq];
+                const bf16_t* src = off >= 0 ? ph8_cbase + (off + c_cin0) : (const bf16_t*)g16_zero_page;
+                glds16(src, dst + qq * 8192);
+            } else {
+                glds16(ph8_a + (size_t)(qq * 128 + h * 64) * p.lda + ph8_ka, dst + qq * 8192);
+            }
+        }
+    };
+    auto ph8_adv_a = [&]() {
+        if constexpr (CONV) {
+            c_cin0 += 64;
+            if (c_cin0 >= p.Cin) {
+                c_cin0 -= p.Cin;
+                if (++c_kx == 3) { c_kx = 0; ++c_ky; }
+                conv_set_tap();
+            }
+        } else {
+            ph8_ka += 64;
+        }
+    };
+    auto ph8_stage_w = [&](int buf, int h, int koff) {
+        char* dst = smem + buf * STAGE_BYTES + 32768 + h * 16384 + wave * 1024;
 #pragma unroll
-        for (int q = 0; q < LOADS; ++q) stage_one(s, q);
-        stage_advance();
+        for (int qq = 0; qq < 2; ++qq) glds16(ph8_w + (size_t)(qq * 128 + h * 32) * p.K + koff, dst + qq * 8192);
+    };
+    if constexpr (PH8) {
+        // K-tile 0 complete, A0 / W1 / A1 of K-tile 1 behind it (its W0 goes out in phase 0 of K-tile 0)
+        ph8_stage_a(0, 0);
+        ph8_stage_w(0, 0, 0);
+        ph8_stage_w(0, 1, 0);
+        ph8_stage_a(0, 1);
+        ph8_adv_a();
+        ph8_stage_a(1, 0);
+        ph8_stage_w(1, 1, 64);
+        ph8_stage_a(1, 1);
+        ph8_adv_a();
+        ph8_kw1 = 128;
+    } else {
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s) {
+#pragma unroll
+            for (int q = 0; q < LOADS; ++q) stage_one(s, q);
+            stage_advance();
+        }
     }
 
     // LayerNorm folding: mean / rstd of the token rows this wave finishes after the K-group exchange (token fragments
@@ -367,7 +450,101 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         if constexpr (S == 3) kstep(F_{}, std::integral_constant<int, 1>{}, trans_c);
         kstep(F_{}, std::integral_constant<int, 0>{}, trans_c);
     };
-    if constexpr (MIXED) {
+    if constexpr (PH8) {
+        const int fa_off = (wm * 64 + l15) * 128, fw_off = 32768 + (wn * 32 + l15) * 128;
+        int cur = 0;
+        // one K-tile.  SW0: stage W0 of the next K-tile (phase 0); SA: stage A0 / W1 / A1 of the K-tile after it (phases 1 - 3);
+        // WAITN: the counted wait of phase 3 (6 = three half-tiles stay in flight; 0 = the tail; -1 = nothing left to wait for)
+        auto ph8_tile = [&](auto sw0_c, auto sa_c, auto wait_c) {
+            constexpr bool SW0 = decltype(sw0_c)::value, SA = decltype(sa_c)::value;
+            constexpr int WAITN = decltype(wait_c)::value;
+            const char* sT = smem + cur * STAGE_BYTES;
+            bf16x8 af[2][4], wf[2][2];
+            auto read_a = [&](int h) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[kk][i] = *(const bf16x8*)(sT + h * 16384 + fa_off + i * 2048 + (((4 * kk + quad) ^ sw) * 16));
+            };
+            auto read_w = [&](int h) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) wf[kk][j] = *(const bf16x8*)(sT + h * 16384 + fw_off + j * 2048 + (((4 * kk + quad) ^ sw) * 16));
+            };
+            auto mid = [&]() {     // end of a read segment: this wave's fragment reads are complete before anyone passes the barrier
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mma = [&](auto ah_c, auto wh_c) {
+                constexpr int AH = decltype(ah_c)::value, WH = decltype(wh_c)::value;
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[AH * 4 + i][WH * 2 + j] = SUPIR_MFMA_16x16x32(wf[kk][j], af[kk][i], acc[AH * 4 + i][WH * 2 + j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            // phase 0
+            read_w(0);
+            read_a(0);
+            if constexpr (SW0) ph8_stage_w(cur ^ 1, 0, ph8_kw0);
+            mid();
+            mma(I0{}, I0{});
+            // phase 1
+            read_w(1);
+            if constexpr (SA) ph8_stage_a(cur, 0);
+            mid();
+            mma(I0{}, I1{});
+            // phase 2
+            read_a(1);
+            if constexpr (SA) ph8_stage_w(cur, 1, ph8_kw1);
+            mid();
+            mma(I1{}, I1{});
+            // phase 3
+            read_w(0);
+            if constexpr (SA) {
+                ph8_stage_a(cur, 1);
+                ph8_adv_a();
+            }
+            if constexpr (WAITN >= 0) g16_wait_vmcnt<WAITN>();
+            mid();
+            mma(I1{}, I0{});
+            ph8_kw0 += 64;
+            ph8_kw1 += 64;
+            cur ^= 1;
+        };
+        g16_wait_vmcnt<6>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wm == 1) {      // wave row 1 runs one barrier behind row 0 from here on
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        using W6 = std::integral_constant<int, 6>;
+        using W0 = std::integral_constant<int, 0>;
+        using WN_ = std::integral_constant<int, -1>;
+        for (int u = 0; u + 2 < nk; ++u) ph8_tile(T_{}, T_{}, W6{});
+        ph8_tile(T_{}, F_{}, W0{});
+        ph8_tile(F_{}, F_{}, WN_{});
+        if (wm == 0) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    } else if constexpr (MIXED) {
         if (tr) main_loop(T_{});
         else main_loop(F_{});
     } else {
@@ -713,7 +890,7 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
         pp.p[q].gn = a.gn;
         pp.p[q].order = a.order;
     }
-    constexpr int smem = KS * S * (BM + BN) * 128 + 256;   // the ring(s) + the prefetch scratch row
+    constexpr int smem = KS * (S == 8 ? 2 : S) * (BM + BN) * 128 + 256;   // the ring(s) + the prefetch scratch row
     static_assert(smem <= 163840, "LDS");
     auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED, NP>;
     static bool attr_set = false;
@@ -727,17 +904,19 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40)) return false;
-    const bool wide = tile == 34 || tile == 39 || tile == 40;
-    const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : tile == 40 ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
-    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;
+    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42) return false;
+    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42;
+    const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
+    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tile 42: at least two K-tiles
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
     // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU); their GroupNorm
     // partials come in 4-channel units (channel counts 128 / 256 / 512: 4 / 8 / 16 channels per group)
-    if ((tile == 39 || tile == 40) && (a.out_mode != 0 || a.act == 2)) return false;
+    if ((tile == 39 || tile == 40 || tile == 42) && (a.out_mode != 0 || a.act == 2)) return false;
     if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % (bn % 10 == 0 ? 10 : 4))) return false;
     if (conv) {
+        // tile 42 keeps 32-bit tap offsets against ONE image base per tile: rows of a tile in one batch element, the image below 2^31 elements
+        if (tile == 42 && (a.rows_per_batch % 256 || (long)a.H * a.W * a.lda >= (1L << 31))) return false;
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }
     if (a.act == 2)
@@ -762,6 +941,7 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
             case 38: return launch_gemm16<128, 80, 4, 1, 1, 3, false, true>(&a, st);
             case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false, true>(&a, st);
             case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false, true>(&a, st);
+            case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false, true>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
@@ -769,6 +949,7 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
     switch (tile) {
         case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false>(&a, st);
         case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false>(&a, st);
+        case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false>(&a, st);
         case 38: return t ? launch_gemm16<128, 80, 4, 1, 1, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 1, 3, false>(&a, st);
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);
@@ -792,7 +973,7 @@ static bool g16_same_shape(const GemmArgs& x, const GemmArgs& y) {
 
 int supir_gemm16_launch_n(const GemmArgs* a, int n, hipStream_t st, int tile, bool conv) {
     if (n == 1) return supir_gemm16_launch(a[0], st, tile, conv);
-    if (n != 2 || tile == 32 || tile == 38) return SUPIR_ERR_SHAPE;
+    if (n != 2 || tile == 32 || tile >= 38) return SUPIR_ERR_SHAPE;
     if (!supir_gemm16_supported(a[0], tile, conv) || !supir_gemm16_supported(a[1], tile, conv) || !g16_same_shape(a[0], a[1])) return SUPIR_ERR_SHAPE;
     // the wave arrangement of the 256 x 160 tile follows the single-launch policy (4 x 2 for convolutions and M >= 8192): a grouped launch
     // must stay bitwise the two single launches, GroupNorm partials and row statistics included (their cross-wave sums are ordered by it)

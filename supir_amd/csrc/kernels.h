@@ -167,6 +167,17 @@ int supir_edm_pre_launch(const float* x, const float* eps, float s_noise, float 
                          long n, int reps, hipStream_t st);
 int supir_edm_post_launch(const float* net_out, const float* x_hat, const float* x_center, float c_out, float c_skip, float cfg,
                           float restore_mul, float sigma_hat, float dt, float* x_next, long n, int reps, hipStream_t st);
+// tiled sampler: origins of the (<= SUPIR_MAX_TILES) tiles one network call stacks; passed to the kernels by value
+#define SUPIR_MAX_TILES 64
+struct SupirTileList {
+    int n;
+    int hi[SUPIR_MAX_TILES];
+    int wi[SUPIR_MAX_TILES];
+};
+int supir_edm_pre_tiles_launch(const float* x, const float* eps, float s_noise, float noise_mul, float c_in, float* x_hat, float* net_in,
+                               const SupirTileList& tl, int b, int C, int Hc, int Wc, int T, int reps, hipStream_t st);
+int supir_tile_blend_launch(const float* tiles, const double* w, float* canvas, const SupirTileList& tl, int b, int C, int Hc, int Wc, int T,
+                            hipStream_t st);
 int supir_prefetch_launch(const void* p, size_t bytes, void* sink, hipStream_t st);
 int supir_resample_u8_launch(const uint8_t* src, uint8_t* dst_u8, float* dst_f32, const float* lut, const int* bounds, const int* kk,
                              int ksize, int in_h, int in_w, int out_h, int out_w, int ch, int vertical, hipStream_t st);

@@ -15,6 +15,16 @@
 //          den  -= (den - x_center) * restore_mul     (x_center != NULL: restoration guidance, (sigma / sigma_max)^restore_cfg)
 //          x_next = x_hat + dt * ((x_hat - den) / sigma_hat)                    (dt = sigma_next - sigma_hat)
 // fp32 throughout, IEEE division, same association as the reference expressions; n = elements of ONE copy of the latent batch.
+//
+// Tiled sampler (TiledRestoreEDMSampler.__call__, sampling.py:600-660): every step cuts the latent canvas [b][C][Hc][Wc] into k
+// overlapping T x T tiles, runs sampler_step on each and blends `x_next[tile] += out * w; count[tile] += w` (sampling.py:654-657).
+//   pre_tiles : `pre` with the crop folded in -- reads x / eps at the tile windows of the canvas, writes the STACKED tiles
+//               [k*b][C][T][T] (tile j, sample bi at row j*b + bi: torch.cat of the crops along dim 0); same arithmetic per element;
+//   blend     : x_next[tile_j] += out_j * w for the k tiles of one network call, one launch.  Tiles overlap, so a thread owns one
+//               canvas element of the group's bounding box and adds the tiles that cover it IN TILE ORDER: the fp32 result is
+//               bitwise the k sequential slice-adds.  The reference's weights are float64 (gaussian_weights builds them with
+//               numpy, sampling.py:733-750), so torch evaluates `fp32 += fp32 * fp64` in float64 and rounds to fp32 once per add:
+//               (float)((double)acc + (double)out * w), mul and add rounded separately (no fma) -- reproduced here.
 #include "kernels.h"
 
 namespace {
@@ -81,7 +91,77 @@ __global__ __launch_bounds__(256) void edm_post_kernel(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void edm_pre_tiles_kernel(const float* __restrict__ x, const float* __restrict__ eps, float s_noise,
+                                                             float noise_mul, float c_in, float* __restrict__ x_hat,
+                                                             float* __restrict__ net_in, SupirTileList tl, int b, int C, int Hc, int Wc,
+                                                             int T, int reps) {
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (idx >= T * T) return;
+    const int y = idx / T, xx = idx - y * T;
+    const int bc = (int)blockIdx.y, j = (int)blockIdx.z;   // (sample, channel) plane; tile
+    const int bi = bc / C;
+    const long src = ((long)bc * Hc + tl.hi[j] + y) * Wc + tl.wi[j] + xx;
+    const long dst = (((long)j * b * C + bc) * T + y) * T + xx;
+    (void)bi;
+    float v = x[src];
+    if (eps) v = v + (eps[src] * s_noise) * noise_mul;
+    x_hat[dst] = v;
+    const float w = v * c_in;
+    const long n = (long)tl.n * b * C * T * T;
+    for (int r = 0; r < reps; ++r) net_in[(long)r * n + dst] = w;
+}
+
+__global__ __launch_bounds__(256) void tile_blend_kernel(const float* __restrict__ tiles, const double* __restrict__ w,
+                                                          float* __restrict__ canvas, SupirTileList tl, int b, int C, int Hc, int Wc,
+                                                          int T, int y0, int x0, int bh, int bw) {
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (idx >= bh * bw) return;
+    const int yy = idx / bw, Y = y0 + yy, X = x0 + (idx - yy * bw);
+    const int bc = (int)blockIdx.y;
+    float* dst = canvas + ((long)bc * Hc + Y) * Wc + X;
+    float acc = *dst;
+    bool any = false;
+    for (int j = 0; j < tl.n; ++j) {
+        const int ty = Y - tl.hi[j], tx = X - tl.wi[j];
+        if ((unsigned)ty < (unsigned)T && (unsigned)tx < (unsigned)T) {
+            const double prod = __dmul_rn((double)tiles[(((long)j * b * C + bc) * T + ty) * T + tx], w[ty * T + tx]);
+            acc = (float)__dadd_rn((double)acc, prod);
+            any = true;
+        }
+    }
+    if (any) *dst = acc;
+}
+
 }  // namespace
+
+int supir_edm_pre_tiles_launch(const float* x, const float* eps, float s_noise, float noise_mul, float c_in, float* x_hat, float* net_in,
+                               const SupirTileList& tl, int b, int C, int Hc, int Wc, int T, int reps, hipStream_t st) {
+    if (tl.n <= 0 || tl.n > SUPIR_MAX_TILES || b <= 0 || C <= 0 || T <= 0 || reps < 1 || reps > 2) return SUPIR_ERR_ARG;
+    for (int j = 0; j < tl.n; ++j)
+        if (tl.hi[j] < 0 || tl.wi[j] < 0 || tl.hi[j] + T > Hc || tl.wi[j] + T > Wc) return SUPIR_ERR_SHAPE;
+    if ((long)b * C > 65535) return SUPIR_ERR_SHAPE;
+    SUPIR_LAUNCH(edm_pre_tiles_kernel, dim3((unsigned)((T * T + 255) / 256), (unsigned)(b * C), (unsigned)tl.n), dim3(256), 0, st, x, eps,
+                 s_noise, noise_mul, c_in, x_hat, net_in, tl, b, C, Hc, Wc, T, reps);
+    return SUPIR_LAUNCH_STATUS();
+}
+
+int supir_tile_blend_launch(const float* tiles, const double* w, float* canvas, const SupirTileList& tl, int b, int C, int Hc, int Wc, int T,
+                            hipStream_t st) {
+    if (tl.n <= 0 || tl.n > SUPIR_MAX_TILES || b <= 0 || C <= 0 || T <= 0) return SUPIR_ERR_ARG;
+    int y0 = Hc, x0 = Wc, y1 = 0, x1 = 0;
+    for (int j = 0; j < tl.n; ++j) {
+        if (tl.hi[j] < 0 || tl.wi[j] < 0 || tl.hi[j] + T > Hc || tl.wi[j] + T > Wc) return SUPIR_ERR_SHAPE;
+        y0 = tl.hi[j] < y0 ? tl.hi[j] : y0;
+        x0 = tl.wi[j] < x0 ? tl.wi[j] : x0;
+        y1 = tl.hi[j] + T > y1 ? tl.hi[j] + T : y1;
+        x1 = tl.wi[j] + T > x1 ? tl.wi[j] + T : x1;
+    }
+    if ((long)b * C > 65535) return SUPIR_ERR_SHAPE;
+    const int bh = y1 - y0, bw = x1 - x0;
+    SUPIR_LAUNCH(tile_blend_kernel, dim3((unsigned)(((long)bh * bw + 255) / 256), (unsigned)(b * C)), dim3(256), 0, st, tiles, w, canvas, tl,
+                 b, C, Hc, Wc, T, y0, x0, bh, bw);
+    return SUPIR_LAUNCH_STATUS();
+}
 
 int supir_edm_pre_launch(const float* x, const float* eps, float s_noise, float noise_mul, float c_in, float* x_hat, float* net_in,
                          long n, int reps, hipStream_t st) {

@@ -200,7 +200,9 @@ class UNetModel(nn.Module):
             self.out = nn.Sequential(GroupNorm32(ch), Passthrough(), Conv3x3(model_channels, out_channels))
         object.__setattr__(self, "_emb_w", Prep())
         object.__setattr__(self, "_label_cache", None)
-        object.__setattr__(self, "_schedule", None)
+        object.__setattr__(self, "_schedule", None)         # the embedding table the next announced call reads (prepare_schedule)
+        object.__setattr__(self, "_schedules", {})          # every table prepared so far: (batch, element type, device) -> table
+        object.__setattr__(self, "_sched_counter", [0])
 
     # ------------------------------------------------------------------ embeddings
     def _res_blocks(self):
@@ -246,25 +248,47 @@ class UNetModel(nn.Module):
         M = n B rows per image instead of three M = B GEMVs and a dozen elementwise launches at the head of EVERY step (they sit on
         the critical path of both chains: nothing else can run until the first ResBlock has its row bias).  `row` = a device
         int64 [1] owned by the caller that selects the step; tables live in persistent buffers refreshed in place (captured
-        graphs keep pointing at them).  Same arithmetic, same K order: bitwise the per-step values."""
+        graphs keep pointing at them).  Same arithmetic, same K order: bitwise the per-step values.
+
+        One table per (batch, element type, device), allocated at a CAPACITY of rows (>= 64): a caller that alternates step counts
+        or serves several batch sizes at once (the tiled sampler's full and remainder tile groups) keeps every table -- and with it
+        every captured graph, whose key carries the table's version -- alive; the version changes on real reallocations only."""
         n, B = len(t_values), y.shape[0]
         t = torch.tensor(list(t_values), dtype=torch.int64, device=y.device)
         emb = self._time_emb(t)[:, None, :] + self._label(y)[None, :, :]             # [n, B, 1280] fp32
         proj_all, blocks, offs = self._emb_project(emb.reshape(n * B, -1))
-        sch = self._schedule
-        if sch is None or sch["proj"].shape != (n, B, proj_all.shape[-1]) or sch["cdt"] != cdt() or sch["proj"].device != y.device:
-            sch = dict(proj=torch.empty(n, B, proj_all.shape[-1], dtype=cdt(), device=y.device),
-                       raw=torch.empty(n, B, emb.shape[-1], dtype=cdt(), device=y.device), version=0)
-            sch["version"] = (self._schedule["version"] + 1) if self._schedule is not None else 1
-        sch["proj"].copy_(proj_all.view(n, B, -1))
-        sch["raw"].copy_(emb.to(cdt()))
-        sch.update(row=row, blocks=blocks, offs=offs, B=B, cdt=cdt(), active=True, t_values=tuple(int(v) for v in t_values))
+        key = (B, cdt(), y.device)
+        sch = self._schedules.get(key)
+        if sch is None or sch["proj"].shape[0] < n or sch["proj"].shape[2] != proj_all.shape[-1]:
+            cap = max(64, n)
+            sch = dict(proj=torch.empty(cap, B, proj_all.shape[-1], dtype=cdt(), device=y.device),
+                       raw=torch.empty(cap, B, emb.shape[-1], dtype=cdt(), device=y.device))
+            self._sched_counter[0] += 1
+            sch["version"] = self._sched_counter[0]
+            self._schedules[key] = sch
+        sch["proj"][:n].copy_(proj_all.view(n, B, -1))
+        sch["raw"][:n].copy_(emb.to(cdt()))
+        sch.update(row=row, blocks=blocks, offs=offs, B=B, cdt=cdt(), active=True, n=n, t_values=tuple(int(v) for v in t_values))
         object.__setattr__(self, "_schedule", sch)
         return sch["version"]
 
-    def end_schedule(self):
+    def use_schedule(self, B, on):
+        """Select the table prepared for batch `B` (None -> keep the current one) and switch it on / off for the next call."""
+        if B is not None:
+            sch = self._schedules.get((B, cdt(), self._schedule["proj"].device)) if self._schedule is not None else None
+            if sch is not None:
+                if self._schedule is not sch:
+                    self._schedule["active"] = False
+                object.__setattr__(self, "_schedule", sch)
+            else:
+                on = False
         if self._schedule is not None:
-            self._schedule["active"] = False
+            self._schedule["active"] = bool(on)
+        return bool(on)
+
+    def end_schedule(self):
+        for sch in self._schedules.values():
+            sch["active"] = False
 
     def _label(self, y):
         """label_emb(y): constant over the sampling loop -> cached per y-shape on tensor identity/version and refreshed in

@@ -267,9 +267,12 @@ class RestoreEDMSampler(BaseDiffusionSampler):
         return den, net
 
     def _fused_step(self, ctx, sigma_f, next_sigma_f, x, gamma, x_center, eps_noise, control_scale, use_linear_control_scale,
-                    control_scale_start, cond_cat, sched_row=None):
+                    control_scale_start, cond_cat, sched_row=None, tiles=None):
         """sampler_step (sampling.py:548-570) with every sigma-derived factor evaluated on the host in fp32, in the reference's
-        operation order, and the tensor work in supir_edm_step_pre / _post.  Same RNG consumption as the generic path."""
+        operation order, and the tensor work in supir_edm_step_pre / _post.  Same RNG consumption as the generic path.
+        tiles = (windows, T): x / eps_noise are whole canvases and the step runs on the k stacked T x T windows of them
+        (supir_edm_step_pre_tiles does the crop); x_center is then the pre-stacked centre [k*b, C, T, T] and the result the stacked
+        x_next of the k tiles."""
         from .. import ops
         den, net = ctx
         f32 = np.float32
@@ -285,7 +288,11 @@ class RestoreEDMSampler(BaseDiffusionSampler):
         twice = not isinstance(self.guider, IdentityGuider)
         reps = 2 if twice else 1
         x = x if x.is_contiguous() else x.contiguous()
-        x_hat, net_in = ops.edm_step_pre(x, None if eps is None else eps.float().contiguous(), self.s_noise, noise_mul, c_in, reps)
+        if tiles is not None:
+            x_hat, net_in = ops.edm_step_pre_tiles(x, None if eps is None else eps.float().contiguous(), tiles[0], tiles[1],
+                                                   self.s_noise, noise_mul, c_in, reps)
+        else:
+            x_hat, net_in = ops.edm_step_pre(x, None if eps is None else eps.float().contiguous(), self.s_noise, noise_mul, c_in, reps)
         if sched_row is not None:
             net.select_step(sched_row, idx)     # this call's timestep embeddings come out of the per-image table (ControlWrapper.prepare_schedule)
         out = net(net_in, den.idx_tensor(idx, net_in.shape[0], x.device), cond_cat, control_scale)
@@ -403,10 +410,18 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
         if shared:
             world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
         kb = 1 if use_local_prompt else self.tile_batch
+        src = 0
         if shared:
             src = dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0
             x = x.contiguous()
             dist.broadcast(x, src=src, group=self.process_group)
+        ctx = None
+        if not use_local_prompt and type(self).sampler_step is RestoreEDMSampler.sampler_step and x_center is not None:
+            ctx = self._fused_ctx(denoiser, x)
+        if ctx is not None:
+            return self._call_fused(ctx, x, tiles, tile_weights, lq, static[0], sf, num_sigmas, x_center, control_scale,
+                                    use_linear_control_scale, control_scale_start, kb, shared, world, rank, src)
+        if shared:
             count_all = torch.zeros_like(x)
             for (hi, he, wi, we) in tiles:
                 count_all[:, :, hi:he, wi:we] += tile_weights
@@ -459,6 +474,69 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
             x = x_next
         return x
 
+    def _call_fused(self, ctx, x, tiles, tile_weights, lq, static, sf, num_sigmas, x_center, control_scale, use_linear_control_scale,
+                    control_scale_start, kb, shared, world, rank, src):
+        """The loop of __call__ (sampling.py:624-659) on the fused step: per tile group ONE supir_edm_step_pre_tiles (crop of x and of
+        the step's churn noise + the `pre` half), the network call -- announced to the per-image embedding schedule prepared once per
+        group size, replayed from one hipGraph per group shape --, supir_edm_step_post on the stacked tiles and ONE supir_tile_blend into
+        x_next.  What does not depend on the step is built once per image: the normalising `count` canvas (tile geometry only; the
+        reference rebuilds it every step, :629,657), every group's stacked LQ-latent windows (c / uc `control`), its x_center windows and
+        its repeated text / vector conditioning.  Tile order, RNG consumption (one randn_like(x) per step) and the per-element
+        arithmetic are the generic path's: same results (tests/test_sampler_fused_gpu.py)."""
+        import torch.distributed as dist
+        from .. import ops
+        T = self.tile_size
+        twice = not isinstance(self.guider, IdentityGuider)
+        groups = [tiles[j0:j0 + kb] for j0 in range(0, len(tiles), kb)]
+        mine = [gi for gi in range(len(groups)) if world == 1 or gi % world == rank]
+        w64 = tile_weights[0, 0].contiguous()
+        count = torch.zeros_like(x)
+        for (hi, he, wi, we) in tiles:
+            count[:, :, hi:he, wi:we] += tile_weights
+
+        def stack(t, grp):
+            return torch.cat([t[:, :, a:b_, c:d] for (a, b_, c, d) in grp], 0)
+
+        gstat = {}
+        for gi in mine:
+            grp = groups[gi]
+            k = len(grp)
+            ctl = stack(lq, grp)
+            cat = self._static_rep(static, k) if k > 1 else dict(static)
+            cat["control"] = torch.cat((ctl, ctl), 0) if twice else ctl
+            gstat[gi] = (cat, stack(x_center, grp).float().contiguous())
+        sched = False
+        if mine and EMB_SCHEDULE and hasattr(ctx[1], "prepare_schedule") and "vector" in static:
+            f32 = np.float32
+            t_all = [ctx[0].host_scalars(f32(sf[i]) * f32(self._gamma(sf[i], num_sigmas) + 1.0))[0] for i in range(num_sigmas - 1)]
+            seen = set()
+            for gi in mine:      # one table per group size (all tiles share the timestep); the LQ windows differ per group: no cached hint
+                k = len(groups[gi])
+                if k not in seen:
+                    seen.add(k)
+                    ctx[1].prepare_schedule(t_all, gstat[gi][0]["vector"])
+            sched = True
+        try:
+            for i in range(num_sigmas - 1):
+                gamma = self._gamma(sf[i], num_sigmas)
+                x_next = torch.zeros_like(x)
+                eps_noise = torch.randn_like(x)
+                if shared:
+                    dist.broadcast(eps_noise, src=src, group=self.process_group)
+                for gi in mine:
+                    cat, xc = gstat[gi]
+                    out = self._fused_step(ctx, sf[i], sf[i + 1], x, gamma, xc, eps_noise, control_scale, use_linear_control_scale,
+                                           control_scale_start, cat, sched_row=i if sched else None, tiles=(groups[gi], T))
+                    ops.tile_blend(out, w64, x_next, groups[gi], T)
+                if shared:
+                    dist.all_reduce(x_next, op=dist.ReduceOp.SUM, group=self.process_group)
+                x_next /= count
+                x = x_next
+        finally:
+            if sched:
+                ctx[1].end_schedule()
+        return x
+
     def _static_rep(self, cat, k):
         """[uncond; cond] text / vector conditioning repeated for k stacked tiles: [uc]*k ; [c]*k (cached per k, so the
         network's per-context caches and its hipGraph see the same tensors every step)."""
@@ -478,13 +556,18 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
 
 # ----------------------------------------------------------------------------------------------- DPM++ 2M restore sampler
 def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0, device="cpu"):
-    """Karras et al. (2022) schedule as published / as in k-diffusion 0.1.1.post1 `get_sigmas_karras` (third-party, not in
-    the reference tree: requirements.txt:41): n sigmas from sigma_max to sigma_min on a rho-warped ramp, then 0."""
-    ramp = torch.linspace(0, 1, n, device=device)
-    min_inv_rho = float(sigma_min) ** (1 / rho)
-    max_inv_rho = float(sigma_max) ** (1 / rho)
+    """Karras et al. (2022) schedule as in k-diffusion 0.1.1.post1 `get_sigmas_karras` (third-party, not in the reference tree:
+    requirements.txt:41): n sigmas from sigma_max to sigma_min on a rho-warped ramp, then 0.  The reference passes
+    sigmas[-2].cpu() / sigmas[0].cpu() (sampling.py:490-491): fp32 0-dim tensors, so the roots and the power are fp32 tensor
+    arithmetic on the host -- evaluated the same way here (floats are taken as fp32 values).  Checked against the oracle's own
+    restatement of the published function (tests/test_host_logic.py::test_karras_schedule_vs_the_oracles_restatement)."""
+    ramp = torch.linspace(0, 1, n, dtype=torch.float32)
+    smin = torch.as_tensor(sigma_min, dtype=torch.float32).cpu()
+    smax = torch.as_tensor(sigma_max, dtype=torch.float32).cpu()
+    min_inv_rho = smin ** (1 / rho)
+    max_inv_rho = smax ** (1 / rho)
     sig = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
-    return torch.cat([sig, sig.new_zeros([1])])
+    return torch.cat([sig, sig.new_zeros([1])]).to(device)
 
 
 class IntervalNoiseSampler:

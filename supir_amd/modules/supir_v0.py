@@ -133,14 +133,20 @@ class GLVControl(UNetModel):
         control chain."""
         ver = super().prepare_schedule(t_values, y, row)
         sch = self._schedule
+        old = sch.get("hint")
         if control is not None:
-            old = sch.get("hint")
             shape = (control.shape[0], control.shape[2], control.shape[3], self.model_channels)
             if old is None or tuple(old.shape) != shape or old.dtype != cdt() or old.device != control.device:
                 old = torch.empty(shape, dtype=cdt(), device=control.device)
-                sch["version"] = ver = sch["version"] + 1
+                self._sched_counter[0] += 1
+                sch["version"] = ver = self._sched_counter[0]
             sch["hint"] = self._guided_hint(control, out=old)
         else:
+            if old is not None:
+                # a graph captured while the hint was cached reads that buffer instead of convolving c["control"]: without the
+                # cache the launches differ, so the table's version (part of the graph key) must change with the hint's PRESENCE
+                self._sched_counter[0] += 1
+                sch["version"] = ver = self._sched_counter[0]
             sch["hint"] = None
         return ver
 

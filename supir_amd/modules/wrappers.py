@@ -76,7 +76,8 @@ class ControlWrapper(nn.Module):
         # per-image timestep-embedding schedule (prepare_schedule / select_step): row selector shared by both networks
         self._emb_row = None
         self._emb_rows = None
-        self._sched = None
+        self._sched = None             # the schedule prepared last; _scheds: one per batch size (same timesteps)
+        self._scheds = {}
         self._sched_armed = False
 
     @property
@@ -95,7 +96,10 @@ class ControlWrapper(nn.Module):
         announces itself with select_step(i) right before its forward call; a forward call that was not announced takes the normal
         path, so callers that know nothing about schedules are unaffected.  `vector` must be the tensor the calls will pass as
         c["vector"]; `control` (optional) the CFG-doubled LQ latent the calls will pass as c["control"]: the control branch's
-        input_hint_block convolution of it is step-invariant too and is then computed once per image as well."""
+        input_hint_block convolution of it is step-invariant too and is then computed once per image as well.
+
+        One schedule per batch size may be prepared (the tiled sampler stacks k tiles per call and has a remainder group: two
+        batch sizes, same timesteps); a call is served by the schedule prepared for ITS batch."""
         with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
             if self._emb_row is None or self._emb_row.device != vector.device:
                 self._emb_row = torch.zeros(1, dtype=torch.int64, device=vector.device)
@@ -106,6 +110,9 @@ class ControlWrapper(nn.Module):
             self.control_model.end_schedule()       # inactive until a step announces itself
             self.diffusion_model.end_schedule()
         self._sched = (len(t_values), v1, v2, self.effective_dtype, tuple(int(v) for v in t_values))
+        if self._scheds and next(iter(self._scheds.values()))[4] != self._sched[4]:
+            self._scheds.clear()                    # another image's timesteps: those tables are stale
+        self._scheds[int(vector.shape[0])] = self._sched
         self._sched_armed = False
 
     def select_step(self, i, expect_t=None):
@@ -120,19 +127,25 @@ class ControlWrapper(nn.Module):
 
     def end_schedule(self):
         self._sched, self._sched_armed = None, False
+        self._scheds.clear()
         for m in (self.control_model, self.diffusion_model):
             if m is not None and hasattr(m, "end_schedule"):
                 m.end_schedule()
 
-    def _use_schedule(self, kwargs):
-        """Consume the one-call announcement; switch both networks' tables on / off for this call."""
-        use = self._sched is not None and self._sched_armed and not kwargs and self._sched[3] == self.effective_dtype
+    def _use_schedule(self, kwargs, B=None):
+        """Consume the one-call announcement; switch both networks' tables (the ones prepared for batch B) on / off for this call.
+        Returns the schedule entry that serves the call, or None."""
+        ent = self._scheds.get(B) if B is not None else self._sched
+        use = ent is not None and self._sched_armed and not kwargs and ent[3] == self.effective_dtype
         self._sched_armed = False
         for m in (self.control_model, self.diffusion_model):
-            sch = getattr(m, "_schedule", None)
-            if sch is not None:
-                sch["active"] = bool(use)
-        return use
+            if m is not None and hasattr(m, "use_schedule"):
+                use = m.use_schedule(B, use) and use
+        if not use:
+            for m in (self.control_model, self.diffusion_model):
+                if m is not None and hasattr(m, "use_schedule"):
+                    m.use_schedule(None, False)
+        return ent if use else None
 
     # ------------------------------------------------------------------ eager
     def _forward_eager(self, x, t, c, control_scale, **kwargs):
@@ -203,11 +216,11 @@ class ControlWrapper(nn.Module):
             self._graphs.clear()
             self._cs_miss.clear()
 
-    def _forward_graph(self, x, t, c, control_scale, sched=False):
+    def _forward_graph(self, x, t, c, control_scale, sched=None):
         ctx, vec, ctl = c["crossattn"], c["vector"], c["control"]
         # a step of a prepared embedding schedule reads its embeddings out of the per-image tables (other launches than a plain
         # call): its own graph, valid as long as the tables are the same buffers (version)
-        key = (tuple(x.shape), float(control_scale), tuple(ctx.shape), tuple(vec.shape), Wt.cdt()) + ((self._sched[1:3],) if sched else ())
+        key = (tuple(x.shape), float(control_scale), tuple(ctx.shape), tuple(vec.shape), Wt.cdt()) + ((sched[1:3],) if sched else ())
         g = self._graphs.get(key)
         if g is None:
             # control_scale is a launch argument baked into the captured kernels.  With use_linear_control_scale
@@ -288,7 +301,8 @@ class ControlWrapper(nn.Module):
             self._cs_miss.clear()
             self._resident.clear()
             self._last_cdt = self.effective_dtype
-        sched = self._use_schedule(kwargs)
+        vec = c.get("vector", None) if isinstance(c, dict) else None
+        sched = self._use_schedule(kwargs, None if vec is None else int(vec.shape[0]))   # the schedule entry serving this call, or None
         with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
             if self._graph_on and not kwargs and x.is_cuda:
                 return self._forward_graph(x, t, c, control_scale, sched)

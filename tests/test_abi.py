@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(fns) >= 14
     for name in fns:
         assert hasattr(lib, name), f"{name} declared in supir_hip.h but not exported"
-    assert lib.supir_abi_version() == 1
+    assert lib.supir_abi_version() == _lib.ABI_VERSION == 2
     assert lib.supir_target_arch() == b"gfx950"
     assert lib.supir_elem_type() == b"bf16"
 
@@ -38,7 +38,7 @@ def test_f16_library_exports_the_same_surface():
     assert lib16 is not lib and _lib.load(torch.bfloat16) is lib and _lib.load(torch.float16) is lib16
     for name in _header_functions():
         assert hasattr(lib16, name), f"{name} not exported by the f16 build"
-    assert lib16.supir_abi_version() == 1 and lib16.supir_target_arch() == b"gfx950" and lib16.supir_elem_type() == b"f16"
+    assert lib16.supir_abi_version() == _lib.ABI_VERSION and lib16.supir_target_arch() == b"gfx950" and lib16.supir_elem_type() == b"f16"
     assert lib16.supir_gemm_bf16(None, None, None, 64, 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 0, 1.0, -1, None) == -1
     fake = 0x10000
     assert lib16.supir_gemm_bf16(fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 32, None) == -2
@@ -63,10 +63,16 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
 
 
 def test_new_entry_points_validate_arguments_without_a_gpu():
-    """supir_set_next_prefetch / supir_wavelet_level: argument errors are reported before any HIP call."""
+    """supir_launch_hints / supir_wavelet_level: argument errors are reported before any HIP call; the thread-local one-shot
+    setters of ABI 1 are gone (ABI 2: the library keeps no request state)."""
+    import ctypes
     lib = _lib.load()
-    assert lib.supir_set_next_prefetch(None, 4096) == -1          # bytes without a pointer
-    assert lib.supir_set_next_prefetch(None, 0) == 0              # cancel is always fine
+    assert lib.supir_abi_version() == 2
+    for gone in ("supir_set_next_prefetch", "supir_set_next_gn_partials"):
+        assert not hasattr(lib, gone), gone
+    fake = 0x10000
+    bad = _lib.LaunchHints(next_weight=None, next_weight_bytes=4096, gn_partials_out=None)      # bytes without a pointer
+    assert lib.supir_gemm_bf16_ex(fake, fake, fake, 64, 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 0, 1.0, -1, ctypes.byref(bad), None) == -1
     assert lib.supir_wavelet_level(None, None, None, 3, 8, 8, 1, 1, None) == -1
     fake = 0x10000                                                  # never dereferenced: validation comes first
     assert lib.supir_wavelet_level(fake, fake, fake + 4096, 3, 8, 8, 1, 1, None) == -1      # img aliases low
@@ -140,7 +146,7 @@ def test_grouped_launch_structs_match_the_header_layout(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text("\n".join(lines))
     exe = tmp_path / "layout"
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)   # also: the header is plain C
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-DSUPIR_EXPERIMENTAL", str(src), "-o", str(exe)], check=True)   # also: the header is plain C
     got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines())
     for cname, cls in pairs.items():
         assert int(got[cname]) == ctypes.sizeof(cls), cname

@@ -204,6 +204,20 @@ def test_tiled_dpmpp2m_sampler_vs_reference(g):
     assert rel_l2(out, g["sampler_dpmpp_tiled_4"]) <= 5e-5
 
 
+def test_karras_schedule_vs_the_oracles_restatement():
+    """The product's Karras schedule against the oracle's INDEPENDENT restatement of the published k-diffusion 0.1.1 function
+    (oracle/supir_oracle.py kdiff_get_sigmas_karras), called the way the reference calls it (sampling.py:490-491: sigmas[-2].cpu(),
+    sigmas[0].cpu() of the step table -- 0-dim fp32 tensors) for config 5's step counts and the EDM default: bitwise."""
+    from oracle import supir_oracle as O
+    for n in (4, 8, 50):
+        table = S.LegacyDDPMDiscretization()(n, device="cpu")
+        smin, smax = table[-2].cpu(), table[0].cpu()
+        want = O.kdiff_get_sigmas_karras(n, smin, smax)
+        assert torch.equal(S.get_sigmas_karras(n, smin, smax), want)
+        assert torch.equal(S.get_sigmas_karras(n, float(smin), float(smax)), want)      # the sampler hands over host floats of the same fp32 values
+        assert want.dtype == torch.float32 and want.shape == (n + 1,) and want[-1] == 0
+
+
 def test_karras_schedule_properties():
     s = S.get_sigmas_karras(8, 0.0292, 14.6146)
     assert s.shape == (9,) and s[-1] == 0 and abs(s[0].item() - 14.6146) < 1e-4 and abs(s[-2].item() - 0.0292) < 1e-5

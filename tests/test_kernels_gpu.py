@@ -377,8 +377,10 @@ def test_gemm_layernorm_folding(M, C, N, tile):
 @pytest.mark.parametrize("nbytes", [0, 128, 1000, 3 * 1280 * 1280 * 2])
 @pytest.mark.parametrize("tile", [-1, 0, 3, 5])
 def test_next_weight_prefetch_is_read_only(nbytes, tile):
-    """supir_set_next_prefetch: the launch that carries the request returns bit-identical results, the request is one-shot,
-    and the prefetched buffer is untouched (whole 128-byte lines only, so 1000 bytes -> 7 lines)."""
+    """supir_launch_hints.next_weight: the launch that carries the request returns bit-identical results and the prefetched buffer
+    is untouched (whole 128-byte lines only, so 1000 bytes -> 7 lines); the request is an argument of that one launch (ABI 2: no
+    library state), so the next launch carries none."""
+    import ctypes
     from supir_amd import _lib
     lib = _lib.load()
     a = rnd(300, 640).to(BF)
@@ -387,14 +389,18 @@ def test_next_weight_prefetch_is_read_only(nbytes, tile):
     nxt = rnd(3 * 1280, 1280, seed=3).to(BF)
     nxt_copy = nxt.clone()
     ref = ops.gemm(a, w, b, tile=tile)
-    assert lib.supir_set_next_prefetch(nxt.data_ptr(), nbytes) == 0
-    out = ops.gemm(a, w, b, tile=tile)          # consumes the request
-    out2 = ops.gemm(a, w, b, tile=tile)         # no request pending any more
+    out = torch.empty_like(ref)
+    hints = _lib.LaunchHints(next_weight=nxt.data_ptr(), next_weight_bytes=nbytes, gn_partials_out=None)
+    rc = lib.supir_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), out.data_ptr(), 300, 320, 640, 640, 320, b.data_ptr(), None, 0, 0, None, 0, 0, 0,
+                                1.0, tile, ctypes.byref(hints), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    out2 = ops.gemm(a, w, b, tile=tile)
     torch.cuda.synchronize()
     assert torch.equal(out, ref) and torch.equal(out2, ref)
     assert torch.equal(nxt, nxt_copy)
-    assert lib.supir_set_next_prefetch(None, 128) != 0      # bytes without a pointer is an argument error
-    assert lib.supir_set_next_prefetch(None, 0) == 0
+    bad = _lib.LaunchHints(next_weight=None, next_weight_bytes=128, gn_partials_out=None)       # bytes without a pointer
+    assert lib.supir_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), out.data_ptr(), 300, 320, 640, 640, 320, b.data_ptr(), None, 0, 0, None, 0, 0,
+                                  0, 1.0, tile, ctypes.byref(bad), torch.cuda.current_stream().cuda_stream) == -1
 
 
 def _wavelet_ref(img, levels=5):
@@ -774,10 +780,11 @@ G16_VAE_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", G16_VAE_CONV_CASES)
-@pytest.mark.parametrize("tile", [39, 40])
+@pytest.mark.parametrize("tile", [39, 40, 42])
 def test_gemm16_vae_tiles_conv3x3(case, tile):
-    """Tiles 39 (256 x 128) / 40 (256 x 256, one K slice of fragments in registers at a time) of csrc/gemm16.hip on the VAE's
-    convolution shapes: against torch fp32, against the gemm.hip tile that ran them before, repeatable, epilogue terms."""
+    """Tiles 39 (256 x 128) / 40 (256 x 256, one K slice of fragments in registers at a time) / 42 (256 x 256 on the eight-phase
+    ping-pong schedule, round 5) of csrc/gemm16.hip on the VAE's convolution shapes: against torch fp32, against the gemm.hip tile that
+    ran them before, repeatable, epilogue terms; tile 42 accumulates in tile 40's K order: BITWISE tile 40."""
     B, H, W, Cin, Cout, stride, pad, up, out_hw = case
     bn = 128 if tile == 39 else 256
     x = rnd(B, H, W, Cin).to(BF)
@@ -799,6 +806,10 @@ def test_gemm16_vae_tiles_conv3x3(case, tile):
     check(out, ref, name=f"conv16 {case} tile{tile}")
     assert torch.equal(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile))
     check(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=4).float(), rel=3e-3, name="vs gemm.hip tile 4")
+    if tile == 42:
+        for _ in range(3):      # a racy hand-off (LDS-DMA landing late, a half-tile restaged early) shows up as run-to-run differences
+            assert torch.equal(ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=42),
+                               ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=40))
     res = rnd(B, OH, OW, Cout, seed=5).to(BF)
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, residual=res, act=1, alpha=0.5, tile=tile)
     check(out, 0.5 * F.silu(ref) + res.float(), name="conv16 epilogue")
@@ -824,8 +835,8 @@ def test_gemm16_vae_tiles_conv3x3(case, tile):
     assert torch.equal(yc, o_parts)
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (1024, 256, 128), (512, 128, 256), (16384, 512, 512)])
-@pytest.mark.parametrize("tile", [39, 40])
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (1024, 256, 128), (512, 128, 256), (16384, 512, 512), (8192, 1280, 5120), (65536, 256, 192)])
+@pytest.mark.parametrize("tile", [39, 40, 42])
 def test_gemm16_vae_tiles_plain(M, N, K, tile):
     """The same tiles as plain GEMMs (the VAE's 1x1 convolutions: nin_shortcut model.py:124, attention q / k / v / proj_out :164-175)."""
     bn = 128 if tile == 39 else 256
@@ -838,6 +849,9 @@ def test_gemm16_vae_tiles_plain(M, N, K, tile):
     out = ops.gemm(a, w, bias, tile=tile)
     check(out, base, name=f"gemm16{(M, N, K)} tile{tile}")
     assert torch.equal(out, ops.gemm(a, w, bias, tile=tile))
+    if tile == 42:       # same MFMA, same K order as tile 40: bitwise, on every repetition (a racy LDS hand-off would differ run to run)
+        for _ in range(3):
+            assert torch.equal(ops.gemm(a, w, bias, tile=42), ops.gemm(a, w, bias, tile=40))
     res = rnd(M, N, seed=3).to(BF)
     check(ops.gemm(a, w, bias, residual=res, alpha=0.5, tile=tile), 0.5 * base + res.float(), name="res+alpha")
     acc = res.clone()

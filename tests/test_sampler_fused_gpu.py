@@ -149,3 +149,83 @@ def test_embedding_schedule_is_bitwise_the_per_step_embeddings(monkeypatch, grap
     t = torch.tensor([500, 37], dtype=torch.int64, device=DEV)
     with torch.no_grad():
         assert torch.equal(mini(x, t, cond, 1.0), mini(x, t, cond, 1.0))
+
+
+@pytest.mark.parametrize("geom", [(1, 4, 256, 256, 128, 64, 4), (2, 4, 160, 200, 64, 48, 3), (1, 4, 130, 131, 128, 64, 4), (1, 4, 96, 96, 32, 16, 7)])
+def test_tile_edges_are_bitwise_the_torch_slice_ops(geom):
+    """supir_edm_step_pre_tiles / supir_tile_blend (round 5) against the expressions of TiledRestoreEDMSampler.__call__
+    (sampling.py:624-659): the crop + `pre` half per stacked tile, and `x_next[tile] += _x * tile_weights` with the reference's
+    float64 Gaussian weights -- BITWISE the k sequential slice-adds (torch evaluates fp32 += fp32 * fp64 in float64 per add), for
+    ragged canvases (last windows shifted, odd origins), several samples and groups of k tiles."""
+    from supir_amd.modules.sampling import _sliding_windows, gaussian_weights
+    b, C, Hc, Wc, Tt, stride, k = geom
+    tiles = _sliding_windows(Hc, Wc, Tt, stride)
+    w = gaussian_weights(Tt, Tt, 1, device=DEV)
+    assert w.dtype == torch.float64
+    x, eps = T("tile.x", (b, C, Hc, Wc)), T("tile.e", (b, C, Hc, Wc))
+    s_noise, noise_mul, c_in = 1.01, 0.7312, 0.0683
+    x_next, ref_next = torch.zeros_like(x), torch.zeros_like(x)
+    for j0 in range(0, len(tiles), k):
+        grp = tiles[j0:j0 + k]
+
+        def stack(t):
+            return torch.cat([t[:, :, a:b_, c:d] for (a, b_, c, d) in grp], 0)
+
+        for e in (eps, None):
+            x_hat, net_in = ops.edm_step_pre_tiles(x, e, grp, Tt, s_noise, noise_mul, c_in, 2)
+            ref_hat, ref_in = ops.edm_step_pre(stack(x).contiguous(), None if e is None else stack(e).contiguous(), s_noise, noise_mul, c_in, 2)
+            assert torch.equal(x_hat, ref_hat) and torch.equal(net_in, ref_in)
+        out = T(f"tile.o{j0}", (len(grp) * b, C, Tt, Tt))
+        ops.tile_blend(out, w[0, 0].contiguous(), x_next, grp, Tt)
+        for (hi, he, wi, we), o in zip(grp, out.chunk(len(grp), 0)):
+            ref_next[:, :, hi:he, wi:we] += o * w.repeat(b, 1, 1, 1)
+    assert torch.equal(x_next, ref_next)
+
+
+def test_tiled_sampler_fused_path_vs_generic_path(monkeypatch):
+    """TiledRestoreEDMSampler on the fused step + per-group embedding schedule + one graph per group shape (round 5) against its
+    generic path (torch slice ops + sampler_step), reduced-depth network, latent 48 x 64 as 32 x 32 tiles (stride 16: 6 tiles -> a
+    full group of 4 and a remainder group of 2, i.e. two batch sizes and two schedules), 3 steps, same seed: same RNG consumption,
+    results within the bf16 network's sensitivity to ulp-level input differences -- eagerly and under hipGraph replay, twice in a
+    row (the second image re-uses tables and graphs)."""
+    from supir_amd.modules import sampling
+    from supir_amd.modules.sampling import DiscreteDenoiserWithControl, LinearCFG, TiledRestoreEDMSampler
+    mini = build_unet(depth=(1, 1, 2), device=DEV)
+    den = DiscreteDenoiserWithControl().to(DEV)
+    h, w = 48, 64
+    ctx, y = T("context", (2, 77, 2048)), T("vector", (2, 2816))
+    lq, xc = T("lq_tiled2", (1, 4, h, w)), T("fs.center2", (1, 4, h, w))
+    c = {"crossattn": ctx[:1], "vector": y[:1], "control": lq}
+    uc = {"crossattn": ctx[1:], "vector": y[1:], "control": lq}
+
+    def denoiser(i, s, cc, cs):
+        return den(mini, i, s, cc, cs)
+
+    res = {}
+    for mode in ("generic", "fused", "fused+graph"):
+        if mode == "generic":
+            denoiser.__dict__.pop("fused", None)
+        else:
+            denoiser.fused = (den, mini)
+        monkeypatch.setattr(sampling, "FUSED_EDM_STEP", mode != "generic")
+        mini.enable_graph(mode == "fused+graph")
+        smp = TiledRestoreEDMSampler(32, 16, num_steps=3, s_churn=5, s_noise=1.01, restore_cfg=4.0, guider_config=LinearCFG(1.0, 4.0),
+                                     device=DEV, tile_batch=4)
+        outs = []
+        try:
+            for img in range(2):
+                torch.manual_seed(321 + img)
+                with torch.no_grad():
+                    outs.append(smp(denoiser, T(f"fs.x0t{img}", (1, 4, h, w)).clone(), cond=dict(c), uc=dict(uc), x_center=xc).float().clone())
+                outs.append(torch.randn(4, device=DEV))
+        finally:
+            mini.enable_graph(False)
+        assert mini._sched is None and not mini._scheds
+        res[mode] = outs
+    for mode in ("fused", "fused+graph"):
+        for i in (0, 2):
+            e = rel_l2(res[mode][i], res["generic"][i])
+            print(f"[tiled {mode}] image {i // 2}: rel-L2 vs generic {e:.3e}")
+            assert e <= 1e-2, (mode, i, e)
+        assert torch.equal(res[mode][1], res["generic"][1]) and torch.equal(res[mode][3], res["generic"][3])   # same RNG consumption
+    assert torch.equal(res["fused"][0], res["fused+graph"][0]) and torch.equal(res["fused"][2], res["fused+graph"][2])   # graph == eager
