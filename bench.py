@@ -325,28 +325,52 @@ def vae_colorfix_profile(model, P, device):
     return out
 
 
-_ROCPROF_NAMES = {"gemm16_kernel<128,80,2k,s3>": "gemm16_kernel<128, 80, 4, 1, 2, 3, false, false, false, 1>",
-                  "gemm16_kernel<128,80,2k,s2>": "gemm16_kernel<128, 80, 4, 1, 2, 2, false, false, false, 1>",
-                  "geglu_big_kernel<256,320,4x2>": "geglu_big_kernel<1, true>", "attn": "attn_d64_pipe_kernel<3, 4, true, 1, true>",
-                  "gemm16_kernel<256,160,1k,s3,qkv>": "gemm16_kernel<256, 160, 8, 1, 1, 3, false, false, true, 1>",
-                  "gemm16_kernel<256,128,1k,s3,qkv>": "gemm16_kernel<256, 128, 4, 2, 1, 3, false, false, true, 1>"}
+def _rocprof_kernel_name(kernel):
+    """Name rocprofv3 prints for a gemm-family instantiation the trace names `kernel` (ops.gemm_tile_name)."""
+    names = {"gemm16_kernel<128,80,2k,s3>": "gemm16_kernel<128, 80, 4, 1, 2, 3, false, false, false, 1>",
+             "gemm16_kernel<128,80,2k,s2>": "gemm16_kernel<128, 80, 4, 1, 2, 2, false, false, false, 1>",
+             "geglu_big_kernel<256,320,4x2>": "geglu_big_kernel<1, true>", "attn": "attn_d64_pipe_kernel<3, 4, true, 1, true>",
+             "gemm16_kernel<256,160,1k,s3,qkv>": "gemm16_kernel<256, 160, 8, 1, 1, 3, false, false, true, 1>",
+             "gemm16_kernel<256,128,1k,s3,qkv>": "gemm16_kernel<256, 128, 4, 2, 1, 3, false, false, true, 1>",
+             "xattn_q": "xattn_q_kernel"}
+    return names.get(kernel)
 
 
-def _replay_average_us(kernel):
-    """(average microseconds, file) of `kernel` in the newest committed rocprofv3 --stats summary of the bench command."""
+def replay_profile(args, tune_path):
+    """THIS command again, on THIS box, inside this invocation, under `rocprofv3 --kernel-trace --stats` (one timed image of graph
+    replay with exactly the kernel picks the timed region ran): per-kernel average durations under replay -- no event pairs, next-weight
+    prefetch on, the other chain running beside it.  Returns {rocprof kernel name: (average us, calls)} and the CSV's path (copied to
+    gpurun_out/ when that directory exists), or None when rocprofv3 is missing / the run fails (the bench line never depends on it)."""
     import csv
     import glob
-    want = _ROCPROF_NAMES.get(kernel)
-    if want is None:
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
         return None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_rocprofv3_kernel_stats*.csv")), reverse=True):
-        try:
-            for row in csv.DictReader(open(f)):
-                if want in row.get("Name", ""):
-                    return float(row["AverageNs"]) / 1e3, os.path.relpath(f, ROOT)
-        except Exception:
-            continue
-    return None
+    d = tempfile.mkdtemp(prefix="supir_replay_", dir="/tmp")
+    cmd = [rp, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
+           "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--extra-batch", "0", "--no-kernel-profile", "--no-replay-profile",
+           "--tune", "file", "--tune-file", tune_path, "--edm-steps", str(args.edm_steps), "--res", str(args.res),
+           "--diff-dtype", args.diff_dtype, "--save-tune", os.path.join(d, "tune_child.json")]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        subprocess.run(cmd, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", env=env, check=True)
+        f = next(iter(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)), None)
+        if f is None:
+            return None
+        rows = {r["Name"]: (float(r["AverageNs"]) / 1e3, int(r["Calls"])) for r in csv.DictReader(open(f))}
+        keep = f
+        go = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(go):
+            keep = os.path.join(go, "bench_replay_rocprofv3_kernel_stats.csv")
+            shutil.copyfile(f, keep)
+        return rows, os.path.relpath(keep, ROOT) if keep.startswith(ROOT) else keep
+    except Exception:   # noqa: BLE001 -- a profiling extra must never take the bench line down
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def _fused_step_on():
@@ -379,6 +403,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-replay-profile", action="store_true",
+                    help="skip the same-box sub-step that re-runs this command (1 image) under rocprofv3 --kernel-trace --stats for the "
+                         "dominant kernel's average duration under graph replay (roofline.frac_graph_replay)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -460,6 +487,11 @@ def main():
     if rank == 0 and save_to and args.warmup > 0:
         ops.save_tuning(save_to)
         picks["saved_to"] = os.path.relpath(save_to, ROOT)
+    replay_tune = None
+    if rank == 0 and world == 1 and args.warmup > 0 and not args.no_replay_profile and not args.no_kernel_profile:
+        import tempfile
+        replay_tune = os.path.join(tempfile.gettempdir(), f"supir_bench_picks_{os.getpid()}.json")   # the picks the timed region runs with
+        ops.save_tuning(replay_tune)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -583,12 +615,16 @@ def main():
                         algorithmic_gflop_per_launch=round(v["flops"] / v["launches"] / 1e9, 3),
                         algorithmic_mb_per_launch=round(v["bytes"] / v["launches"] / 1e6, 3),
                         share_of_step_time=round(v["us"] / total_us, 3), shapes=shapes)
-        # the same kernel under graph REPLAY (no event pairs, next-weight prefetch on, the other chain running beside it): its
-        # average duration in the committed rocprofv3 --kernel-trace --stats summary of this command
-        rp = _replay_average_us(name)
-        if rp is not None and v["flops"] > 0:
-            roofline.update(frac_graph_replay=round(v["flops"] / v["launches"] / (rp[0] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                            avg_launch_us_graph_replay=round(rp[0], 2), graph_replay_source=rp[1])
+        # the same kernel under graph REPLAY (no event pairs, next-weight prefetch on, the other chain running beside it): its average
+        # duration in a rocprofv3 --kernel-trace --stats run of THIS command made now, on this box, with this run's kernel picks
+        want = _rocprof_kernel_name(name)
+        if want is not None and v["flops"] > 0 and world == 1 and not args.no_replay_profile and replay_tune is not None:
+            rp = replay_profile(args, replay_tune)
+            hit = None if rp is None else next(((us, calls) for nm, (us, calls) in rp[0].items() if want in nm), None)
+            if hit is not None:
+                roofline.update(frac_graph_replay=round(v["flops"] / v["launches"] / (hit[0] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                avg_launch_us_graph_replay=round(hit[0], 2), graph_replay_calls=hit[1],
+                                graph_replay_source=f"{rp[1]}: rocprofv3 --kernel-trace --stats of this command (1 timed image), same box, same invocation")
         # the same figures for every kernel class that takes >= 3 % of the step (the dominant one is `roofline`)
         by_kernel = []
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):
