@@ -30,6 +30,9 @@ UNET_STEP_TFLOP = {128: 20.281, 64: 4.763}          # algorithmic, BASELINE.md s
 IMAGE_TFLOP_1024 = 1044.8                          # 50 steps + 2 VAE enc + 2 VAE dec
 
 
+BUILD_STATS = {}   # per-rank start-up figures (construction, fill, broadcast) for --rank-report
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -39,8 +42,14 @@ def build_model(device, rank, world, dist_on=False):
     from supir_amd.plugin import instantiate_from_config
     from supir_amd.synth import synth_param
     cfg = supir_v0_config(sampler_device=str(device))
-    with torch.device(device):
-        model = instantiate_from_config(cfg)
+    from supir_amd.parallel import broadcast_module_, construct_replica
+    replicated = world > 1 or dist_on
+    t0 = time.time()
+    # rank 0 constructs on the device and fills the weights; every other rank constructs on META and only allocates: all of its
+    # parameters and buffers arrive by the one broadcast below (no initialiser kernels, no host RAM, on any rank)
+    model = construct_replica(lambda: instantiate_from_config(cfg), device, materialize=(rank == 0 or not replicated))
+    torch.cuda.synchronize()
+    t_construct = time.time() - t0
     t0 = time.time()
     sd = model.state_dict()
     if rank == 0:
@@ -51,13 +60,18 @@ def build_model(device, rank, world, dist_on=False):
     torch.cuda.synchronize()
     t_fill = time.time() - t0
     t_bcast = 0.0
-    if world > 1 or dist_on:
-        # ONE weight broadcast rank0 -> all over RCCL/xGMI, coalesced into 2^28-element buckets; nothing else is communicated
-        from supir_amd.parallel import broadcast_module_
+    BUILD_STATS.update(construct_s=round(t_construct, 2), fill_s=round(t_fill, 2), meta_construction=bool(replicated and rank != 0))
+    if replicated:
+        # ONE weight broadcast rank0 -> all over RCCL/xGMI, coalesced into 2^28-element buckets; nothing else is communicated.  fp32
+        # masters as they are (15.9 GB, once): every rank computes what a 1-GPU run computes.  skip=(): the constructor-computed buffers
+        # (the denoiser's sigma table) travel too -- ranks > 0 never ran a constructor on real memory
         t0 = time.time()
-        broadcast_module_(model, src=0)   # fp32 masters as they are (15.9 GB, once): every rank computes what a 1-GPU run computes
+        nb = broadcast_module_(model, src=0, skip=())
         torch.cuda.synchronize()
         t_bcast = time.time() - t0
+        nbytes = sum(t.numel() * t.element_size() for t in sd.values())
+        BUILD_STATS.update(broadcast_s=round(t_bcast, 3), broadcast_buckets=nb, broadcast_GB=round(nbytes / 1e9, 2),
+                           broadcast_GBps=round(nbytes / 1e9 / max(t_bcast, 1e-9), 1))
     return model, t_fill, t_bcast
 
 

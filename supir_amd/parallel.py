@@ -36,7 +36,12 @@ def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), pay
     and an fp16 compute scope loses the three mantissa bits it would have kept.  Not used by bench.py."""
     if not collectives_active():
         return 0
-    tensors = [t for k, t in module.state_dict().items() if t.is_floating_point() and not any(k.endswith(s) for s in skip)]
+    # floating tensors travel in dtype buckets; the few integer buffers (none on SUPIR's path today) would travel one by one below
+    state = {k: t for k, t in module.state_dict().items() if not any(k.endswith(s) for s in skip)}
+    tensors = [t for t in state.values() if t.is_floating_point()]
+    for t in state.values():
+        if not t.is_floating_point():
+            dist.broadcast(t, src=src)
     groups = {}
     for t in tensors:
         groups.setdefault((t.dtype, t.device), []).append(t)
@@ -63,6 +68,22 @@ def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), pay
                 bucket.append(t)
                 size += t.numel()
     return sent
+
+
+def construct_replica(factory, device, materialize):
+    """Build the module `factory()` returns on `device`.
+
+    materialize=True (the rank that owns the weights): an ordinary construction on the device.
+    materialize=False (every other rank of a replicated job): construct on the META device -- no allocation, no initialiser kernels,
+    no host RAM -- then `to_empty(device)`: parameters AND buffers exist uninitialised and must ALL be received
+    (`broadcast_module_(module, skip=())`: buffers computed in constructors, e.g. the denoiser's sigma table, are not recomputed on
+    this rank).  SURVEY 8(e): weights replicated, one broadcast; this keeps rank > 0 start-up at allocation + receive."""
+    if materialize:
+        with torch.device(device):
+            return factory()
+    with torch.device("meta"):
+        module = factory()
+    return module.to_empty(device=device)
 
 
 def shard_items(n_items, rank=None, world=None):

@@ -51,6 +51,29 @@ def _worker(rank, world, port, q):
         n_rounded += int(big)
         same = same and a.dtype == torch.float32 and torch.equal(a, b.to(torch.bfloat16).to(b.dtype) if big else b)
     same = same and n_rounded > 0
+    # replica start-up as bench.py does it for N > 1 (parallel.construct_replica): rank 0 constructs for real and owns the weights, every
+    # other rank constructs on META, allocates (to_empty) and RECEIVES everything -- parameters and constructor-computed buffers (the
+    # denoiser's sigma table) alike; the received module must be the one rank 0 holds, bit for bit, buffers included
+    from supir_amd.configs import supir_v0_config
+    from supir_amd.plugin import instantiate_from_config
+    cfg = supir_v0_config(transformer_depth=[0, 0, 1], sampler_device="cpu")
+    cfg["params"]["first_stage_config"]["params"]["ddconfig"].update(ch=32, ch_mult=[1, 2])
+    for key in ("control_stage_config", "network_config"):
+        cfg["params"][key]["params"].update(model_channels=64, context_dim=64, adm_in_channels=64)
+    try:
+        mdl = parallel.construct_replica(lambda: instantiate_from_config(cfg), "cpu", materialize=(rank == 0))
+        if rank == 0:
+            fill_state_dict_(mdl)
+        else:
+            assert all(t.device.type == "cpu" for t in mdl.state_dict().values())
+        parallel.broadcast_module_(mdl, src=0, bucket_elems=200_000, skip=())
+        ref_m = instantiate_from_config(cfg)
+        fill_state_dict_(ref_m)
+        rsd = ref_m.state_dict()
+        same = same and set(rsd) == set(mdl.state_dict()) and "denoiser.sigmas" in rsd
+        same = same and all(torch.equal(v, rsd[k]) for k, v in mdl.state_dict().items())
+    except NotImplementedError:
+        same = False
     # autotune winners: ranks that tuned differently end with rank 0's picks
     from supir_amd import ops
     ops._TUNE.clear(); ops._CHOICE.clear()

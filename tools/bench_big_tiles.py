@@ -50,7 +50,7 @@ for (B, H, W, Cin, Cout, up) in CONVS:
     tiles = [t for t in (40, 42, 39, 34, 5) if not (t in (40, 42) and Cout % 256) and not (t == 39 and Cout % 128) and not (t == 34 and Cout % 160)
              and not (t == 42 and (OH * OW) % 256)]
     fns = {f"tile{t}": (lambda t=t: ops.conv3x3(x, w, bias, upsample=up, tile=t)) for t in tiles}
-    r = ab(fns, max(3, int(2e3 / (fl / 1.0e9 / 1e3))))   # ~2 ms of launches per round at 1 PFLOP/s
+    r = ab(fns, max(3, int(2000.0 / (fl / 1e9))))   # fl / 1e9 = microseconds at 1 PFLOP/s: ~2 ms of launches per round
     row = {"kind": "conv3x3", "shape": [B, H, W, Cin, Cout, int(up)], "M": M}
     for k, (med, mn) in r.items():
         row[k] = {"us_median": round(med, 1), "us_min": round(mn, 1), "tflops_median": round(fl / med / 1e6, 1)}
@@ -70,7 +70,7 @@ for (M, N, K) in GEMMS:
     tiles = [t for t in (40, 42, 39, 34, 33, 5) if not (t in (40, 42) and N % 256) and not (t == 39 and N % 128) and not (t in (33, 34) and N % 160)
              and not (t == 33 and K % 128)]
     fns = {f"tile{t}": (lambda t=t: ops.gemm(a, w, None, residual=res, tile=t)) for t in tiles}
-    r = ab(fns, max(3, int(2e3 / (fl / 1.0e9 / 1e3))))
+    r = ab(fns, max(3, int(2000.0 / (fl / 1e9))))
     row = {"kind": "gemm", "shape": [M, N, K]}
     for k, (med, mn) in r.items():
         row[k] = {"us_median": round(med, 1), "us_min": round(mn, 1), "tflops_median": round(fl / med / 1e6, 1)}
