@@ -466,9 +466,11 @@ def vae_decoder(sd, z, p="decoder."):
     return _conv(sd, p + "conv_out", F.silu(_gn(sd, p + "norm_out", h, 1e-6)))
 
 
-def vae_moments(sd, x, p="first_stage_model.", encoder="encoder"):
-    """AutoencoderKL.encode up to the moments (sgm/models/autoencoder.py:304-311): encoder -> quant_conv 1x1."""
-    return _conv(sd, p + "quant_conv", vae_encoder(sd, x, p + encoder + "."), padding=0)
+def vae_moments(sd, x, p="first_stage_model.", encoder="encoder", tile=None):
+    """AutoencoderKL.encode up to the moments (sgm/models/autoencoder.py:304-311): encoder -> quant_conv 1x1.
+    tile: encoder tile size in pixels when the encoder runs under VAEHook (SUPIRModel.init_tile_vae, SUPIR_model.py:138-150)."""
+    h = vae_encoder(sd, x, p + encoder + ".") if tile is None else vae_tiled_forward(sd, x, p + encoder + ".", tile, False)
+    return _conv(sd, p + "quant_conv", h, padding=0)
 
 
 def gaussian_mode_sample(moments, noise=None):
@@ -480,38 +482,42 @@ def gaussian_mode_sample(moments, noise=None):
     return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
 
 
-def vae_decode(sd, z, p="first_stage_model."):
-    """AutoencoderKL.decode (autoencoder.py:313-316): post_quant_conv 1x1 -> decoder."""
-    return vae_decoder(sd, _conv(sd, p + "post_quant_conv", z, padding=0), p + "decoder.")
+def vae_decode(sd, z, p="first_stage_model.", tile=None):
+    """AutoencoderKL.decode (autoencoder.py:313-316): post_quant_conv 1x1 -> decoder (tile: decoder tile size in latent pixels under
+    VAEHook, as vae_moments)."""
+    h = _conv(sd, p + "post_quant_conv", z, padding=0)
+    return vae_decoder(sd, h, p + "decoder.") if tile is None else vae_tiled_forward(sd, h, p + "decoder.", tile, True)
 
 
 SCALE_FACTOR = 0.13025  # options/SUPIR_v0.yaml:6
 
 
-def encode_first_stage_with_denoise(sd, x):
+def encode_first_stage_with_denoise(sd, x, tile=None):
     """SUPIRModel.encode_first_stage_with_denoise(use_sample=False) (SUPIR/models/SUPIR_model.py:49-62)."""
-    return SCALE_FACTOR * gaussian_mode_sample(vae_moments(sd, x, encoder="denoise_encoder"))
+    return SCALE_FACTOR * gaussian_mode_sample(vae_moments(sd, x, encoder="denoise_encoder", tile=tile))
 
 
-def encode_first_stage(sd, x, noise):
+def encode_first_stage(sd, x, noise, tile=None):
     """SUPIRModel.encode_first_stage (SUPIR_model.py:42-46): posterior.sample() with the injected noise."""
-    return SCALE_FACTOR * gaussian_mode_sample(vae_moments(sd, x), noise)
+    return SCALE_FACTOR * gaussian_mode_sample(vae_moments(sd, x, tile=tile), noise)
 
 
-def decode_first_stage(sd, z):
+def decode_first_stage(sd, z, tile=None):
     """SUPIRModel.decode_first_stage (SUPIR_model.py:65-69)."""
-    return vae_decode(sd, z / SCALE_FACTOR).float()
+    return vae_decode(sd, z / SCALE_FACTOR, tile=tile).float()
 
 
 def batchify_sample(sd, x, c, uc, noises, *, num_steps, s_churn=5, s_noise=1.01, restoration_scale=-1.0,
-                    cfg_scale=4.0, cfg_scale_start=1.0, control_scale=1.0, table=None):
+                    cfg_scale=4.0, cfg_scale_start=1.0, control_scale=1.0, table=None, tile_vae=None):
     """SUPIRModel.batchify_sample (SUPIR_model.py:80-136) with use_linear_CFG=True, color_fix 'None', conditioner
     bypassed (c / uc given: crossattn, vector).  noises = {'posterior': [N,4,h,w], 'init': [N,4,h,w],
-    'steps': [num_steps x [N,4,h,w]]} replaces the three RNG draws (q1 in SURVEY 3.7)."""
+    'steps': [num_steps x [N,4,h,w]]} replaces the three RNG draws (q1 in SURVEY 3.7).
+    tile_vae = (encoder tile px, decoder tile latent px): the three VAE nets under VAEHook (test.py --use_tile_vae, test.py:65-66)."""
     table = denoiser_table(x.device) if table is None else table
-    _z = encode_first_stage_with_denoise(sd, x)
-    x_stage1 = decode_first_stage(sd, _z)
-    z_stage1 = encode_first_stage(sd, x_stage1, noises["posterior"])
+    te, td = (None, None) if tile_vae is None else tile_vae
+    _z = encode_first_stage_with_denoise(sd, x, tile=te)
+    x_stage1 = decode_first_stage(sd, _z, tile=td)
+    z_stage1 = encode_first_stage(sd, x_stage1, noises["posterior"], tile=te)
     c = dict(c, control=_z)
     uc = dict(uc, control=_z)
 
@@ -524,7 +530,7 @@ def batchify_sample(sd, x, c, uc, noises, *, num_steps, s_churn=5, s_noise=1.01,
     samples = restore_edm_sample(denoise_fn, noises["init"].clone(), c, uc, z_stage1, noises["steps"], num_steps=num_steps,
                                  s_churn=s_churn, s_noise=s_noise, restore_cfg=restoration_scale, scale=cfg_scale_start,
                                  scale_min=cfg_scale, control_scale=control_scale)
-    return decode_first_stage(sd, samples), dict(z=_z, x_stage1=x_stage1, z_stage1=z_stage1, samples=samples)
+    return decode_first_stage(sd, samples, tile=td), dict(z=_z, x_stage1=x_stage1, z_stage1=z_stage1, samples=samples)
 
 
 def wavelet_reconstruction(content, style):

@@ -553,6 +553,40 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 
     // ------------------------------------------------------------------ epilogue
     G16_TL(tl_loop1);
+    // Large tiles (no room to hold the residual / row-bias operands across the main loop: !PRE): fetch them block-wise AHEAD of their
+    // use instead of inside each 16-token block -- the timeline of round 5 (profiles/r05/timeline_large.log) shows the epilogue of the
+    // 256 x 160 / 256 x 256 tiles at 14-22 k cycles per wave, 10-26 % of the launch, ~2 k cycles per block = one dependent L2 / fabric
+    // round trip each.  EPD blocks are in flight: all of them where 2 x MIH x NI x 2 registers fit beside the accumulators (<= 20
+    // fragments), two otherwise (256 x 256); the first ones are issued HERE, under the barrier and the K-group exchange.  In-place
+    // residuals stay safe: a block's rows are read before any of ITS stores, rows of other blocks are disjoint.
+    constexpr bool EPF = !PRE && !TRANS && (MIH * NI <= 20 || PH8);   // not tile 40 (256 x 256, 4 x 2: 8 fragments per block -- it spills; tile 42 supersedes it)
+    constexpr int EPD = !EPF ? 0 : (MIH * NI <= 20 ? MIH : 2);
+    u32x2 q_res[EPF ? MIH : 1][EPF ? NI : 1], q_rb[EPF ? MIH : 1][EPF ? NI : 1];
+    auto ep_fetch = [&](int h) {
+        if constexpr (EPF) {
+            const int m = m0 + wm * WTM + (kg * MIH + h) * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) q_res[h][j] = q_rb[h][j] = u32x2{0u, 0u};
+            if (p.rowbias) {
+                const bf16_t* rbp = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rb + n0 + wn * WTN + 4 * quad;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) q_rb[h][j] = *(const u32x2*)(rbp + j * 16);
+            }
+            if (p.res) {
+                const bf16_t* rp = p.res + (size_t)m * p.ldr + n0 + wn * WTN + 4 * quad;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) q_res[h][j] = *(const u32x2*)(rp + j * 16);
+            }
+        }
+    };
+    if constexpr (EPF) {
+        __builtin_amdgcn_sched_barrier(0);      // not into the last K step (its fragment registers are still live there)
+        if (!tr && p.act != 2) {
+#pragma unroll
+            for (int h = 0; h < EPD; ++h) ep_fetch(h);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();   // every wave is done with its last fragment reads: the rings are scratch from here on
     if constexpr (!TRANS) {
         if (kg == 0 && tid < BN && !tr) {
@@ -723,6 +757,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                     for (int j = 0; j < NI; ++j) {
                         e_rb[j] = pre_rb[h][j];
                         e_res[j] = pre_res[h][j];
+                    }
+                } else if constexpr (EPF) {
+                    if (h + EPD < MIH) ep_fetch(h + EPD);     // keep EPD blocks of residual / row-bias operands in flight
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        e_rb[j] = q_rb[h][j];
+                        e_res[j] = q_res[h][j];
                     }
                 } else {
 #pragma unroll

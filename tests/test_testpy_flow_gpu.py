@@ -110,6 +110,54 @@ def test_testpy_call_sequence_on_the_gpu(tok, tmp_path):
     e_f16 = _rel(f16, base)
     print(f"test.py flow: half-params vs fp32 masters {e_half:.3e}; tiled VAE vs untiled {e_tiled:.3e}; fp16 vs bf16 network {e_f16:.3e}")
     assert e_half <= 5e-2 and e_tiled <= 8e-2 and e_f16 <= 5e-2
+    # What the REFERENCE's own arithmetic makes of the same three mode switches, on the same model / image / prompts / step count (the
+    # oracle, fp32 ATen on the GPU; every RNG draw injected so that the two runs of a pair differ in the mode only): the distance
+    # between "same image, other mode" is a property of the algorithm (tile seams and pooled GroupNorm statistics; fp16-rounded
+    # masters; fp16 vs bf16 activations), and the product's distance must be of the reference's size, not merely under a cap.
+    from oracle import supir_oracle as O
+    from supir_amd.utils.imageio import PIL2Tensor
+    from PIL import Image
+    dev = "cuda:0"
+    rng = np.random.default_rng(7)
+    basei = rng.integers(0, 256, size=(12, 10, 3), dtype=np.uint8)
+    lq, _, _ = PIL2Tensor(Image.fromarray(np.kron(basei, np.ones((6, 6, 1), dtype=np.uint8))), upsacle=1, min_size=256)
+    lq = lq.unsqueeze(0).to(dev)[:, :3]
+    with torch.no_grad():
+        sd = {k: v.float() for k, v in model.state_dict().items()}
+        zc = model.encode_first_stage_with_denoise(lq, use_sample=False)
+        c, uc = model.prepare_condition(zc, [""], A_PROMPT, N_PROMPT, 1)
+        c = {k: v.float() for k, v in c.items() if k in ("crossattn", "vector")}
+        uc = {k: v.float() for k, v in uc.items() if k in ("crossattn", "vector")}
+        lat = tuple(zc.shape)
+        from supir_amd.synth import synth_tensor
+        noises = {"posterior": synth_tensor("flow.post", lat).to(dev), "init": synth_tensor("flow.init", lat).to(dev),
+                  "steps": [synth_tensor(f"flow.eps{i}", lat).to(dev) for i in range(4)]}
+
+        def ref_run(sd_, tile=None, autocast=None):
+            ns = {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in noises.items()}
+            kw = dict(num_steps=4, s_churn=5, s_noise=1.01, restoration_scale=-1.0, cfg_scale=4.0, cfg_scale_start=1.0,
+                      table=model.denoiser.sigmas.to(dev).float(), tile_vae=tile)
+            if autocast is None:
+                out, mid = O.batchify_sample(sd_, lq, c, uc, ns, **kw)
+            else:
+                with torch.autocast("cuda", dtype=autocast):
+                    out, mid = O.batchify_sample(sd_, lq, c, uc, ns, **kw)
+            return O.wavelet_reconstruction(out.float(), mid["x_stage1"].float()).cpu()
+
+        r_base = ref_run(sd)
+        d_tiled = _rel(ref_run(sd, tile=(128, 16)), r_base)
+        d_half = _rel(ref_run({k: v.half().float() for k, v in sd.items()}), r_base)
+        r16, rbf = ref_run(sd, autocast=torch.float16), ref_run(sd, autocast=torch.bfloat16)
+        d_f16 = _rel(r16, rbf)
+    print(f"reference-side (oracle) distances: half-params {d_half:.3e}; tiled VAE {d_tiled:.3e}; autocast fp16 vs bf16 {d_f16:.3e}")
+    from tests.test_parity_production_gpu import record
+    record("testpy_flow_mode_distances", ours=dict(half=e_half, tiled=e_tiled, fp16_vs_bf16=e_f16),
+           reference=dict(half=d_half, tiled=d_tiled, fp16_vs_bf16=d_f16))
+    # the product's runs are bf16 evaluations: two of them that differ by a perturbation of size d end up d + (bf16 floor of this flow)
+    # apart; the floor is what the reference's own bf16 vs fp16 evaluations differ by on identical inputs (d_f16)
+    assert e_tiled <= 1.5 * d_tiled + d_f16, (e_tiled, d_tiled, d_f16)
+    assert e_half <= 1.5 * d_half + d_f16, (e_half, d_half, d_f16)
+    assert e_f16 <= 1.5 * d_f16, (e_f16, d_f16)
 
 
 def test_fp32_requests_warn_or_raise_on_the_gpu(tok, tmp_path, monkeypatch):
