@@ -96,7 +96,18 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     static_assert((NWT == 8 || (NWT == 4 && KS == 1 && !MIXED && NP == 1)) && (BM / 8) % NW == 0 && (NW & 1) == 0,
                   "512 threads (or the four-wave single-group form); A chunks divide over the waves");
     static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3 || S == 8), "tile / wave grid");
-    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && KS == 1 && !TRANS && !MIXED && NP == 1), "eight-phase schedule: 256 x 256, 2 x 4 waves");
+    // eight-phase schedule: 256 token rows, 8 waves as 2 x 4 (256 x 256: 128 x 64 per wave, tile 42) or 4 x 2 (256 x 160: 64 x 80 per wave,
+    // tile 43); the wave tile's MI token fragments split 2 + 2 halves, its NI channel fragments NA + NB parts (2 + 2 / 3 + 2)
+    static_assert(!PH8 || (BM == 256 && KS == 1 && !TRANS && NP == 1 && NWT == 8 && (MI & 1) == 0 && NI >= 2 && (!MIXED || !CONV)), "eight-phase schedule");
+    constexpr int PH_HR = WTM / 2;                       // token rows of one wave in an A half-tile
+    constexpr int PH_AI = MI / 2;                        // token fragments per A half
+    constexpr int PH_NA = (NI + 1) / 2, PH_NB = NI - PH_NA;   // channel fragments per wave in W part 0 / part 1
+    constexpr int PH_WA_ROWS = WN * PH_NA * 16, PH_WB_ROWS = WN * PH_NB * 16;
+    constexpr int PH_WA_CH = PH_WA_ROWS / 8, PH_WB_CH = PH_WB_ROWS / 8;          // 8-row chunks per W part
+    constexpr int PH_WA_Q = (PH_WA_CH + 7) / 8, PH_WB_Q = (PH_WB_CH + 7) / 8;    // global -> LDS instructions per wave (the last may repeat chunk `wave`)
+    constexpr int PH_OFF_W = 32768, PH_OFF_WB = PH_OFF_W + PH_WA_ROWS * 128;     // LDS map of a K-tile buffer: [A0 16K | A1 16K | WA | WB]
+    constexpr int PH_INFLIGHT = 2 + PH_WB_Q + 2;        // loads per wave behind W part 0 of the next K-tile: A0, WB, A1 of the one after
+    static_assert(!PH8 || (PH_WA_CH <= 16 && PH_WB_CH <= 16 && (PH_HR == 64 || PH_HR == 32) && PH_OFF_WB + PH_WB_ROWS * 128 == STAGE_BYTES), "half-tile map");
     static_assert(!(CONV && TRANS) && !(MIXED && (TRANS || CONV || KS != 1)), "the implicit-GEMM loader has no transposed epilogue");
     // epilogue LDS map (the rings are idle by then): [0, XCH) K-group exchange, then per-wave C staging, bias / column sums,
     // row-statistics scratch
@@ -174,7 +185,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
             // eight-phase schedule: q = 2 h + qq is this lane's row of A-half h (token fragments [4h, 4h + 4) of both wave rows), wave row qq
-            const int m = PH8 ? m0 + (q & 1) * 128 + (q >> 1) * 64 + wave * 8 + lrow : m0 + (wave + NW * q) * 8 + lrow;
+            const int m = PH8 ? m0 + (q & 1) * 128 + (q >> 1) * PH_HR + (PH_HR == 64 ? wave * 8 : (wave >> 2) * WTM + (wave & 3) * 8) + lrow
+                              : m0 + (wave + NW * q) * 8 + lrow;
             const int b = m / p.rows_per_batch, r = m - b * p.rows_per_batch;
             const int oy = r / p.OW, ox = r - oy * p.OW;
             c_iy0[q] = oy * p.stride - p.pad_t;
@@ -239,29 +251,32 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 
     const int nk = (p.K >> 6) / KS;   // K steps of this group (>= S - 1: dispatcher; eight-phase schedule: >= 2)
 
-    // ---- eight-phase schedule (tile 42): LDS = two K-tile buffers of four 16 KB HALF-TILES [A0 | A1 | W0 | W1].  A-half h holds token
-    // fragments [4h, 4h + 4) of BOTH wave rows (local row wm * 64 + i * 16 + l15), W-half h channel fragments [2h, 2h + 2) of all four wave
-    // columns (local row wn * 32 + j * 16 + l15): a half-tile is what ONE phase's MFMAs newly need, so it is free again a phase after it was
-    // read and its successor (K-tile + 2, same buffer) can be on its way seven phases before it is needed.  A K-tile is four phases:
-    //     phase  fragment reads (ds_read_b128)      MFMAs (16 each)                    half-tile staged (2 x 1 KB per wave)
-    //       0    A0 (8) + W0 (4)                     tokens 0-3 x channels 0-1          W0 of K-tile u + 1
-    //       1    W1 (4)                              tokens 0-3 x channels 2-3          A0 of K-tile u + 2
-    //       2    A1 (8)                              tokens 4-7 x channels 2-3          W1 of K-tile u + 2
-    //       3    W0 (4, again)                       tokens 4-7 x channels 0-1          A1 of K-tile u + 2   + the K-tile's ONE counted wait
-    // Each phase is [reads + loads + lgkmcnt(0)] s_barrier [MFMAs] s_barrier; wave row 1 runs ONE barrier behind wave row 0, so on every
-    // SIMD (one wave of each row) one wave is in its MFMA segment while the other reads fragments and issues loads.  Hazards (interval =
-    // the time between two consecutive barriers; row g's phase p reads in interval 2p + g):
-    //   WAR  a half-tile's last reads are complete (lgkmcnt(0)) before the barrier that ends their interval, for both rows by the end of
-    //        interval 2p + 1; its successor is issued in phase p + 1 or later (interval >= 2p + 2);
-    //   RAW  every wave waits vmcnt(6) in the read segment of phase 3 (after issuing that phase's loads): everything up to W0 of the NEXT
-    //        K-tile -- the youngest half-tile it needs -- has landed, three half-tiles stay in flight; row 1 executes that wait one interval
-    //        later than row 0, i.e. before the barrier that ends interval 8u + 7, and the first read of K-tile u + 1 is in interval 8u + 8.
-    int ph8_kw0 = 64, ph8_kw1 = 0, ph8_ka = 0;   // K offsets (elements) of the next W0 / W1 / A half-tiles to stage
+    // ---- eight-phase schedule (tiles 42 / 43): LDS = two K-tile buffers of four HALF-TILES [A0 | A1 | WA | WB].  A-half h holds token
+    // fragments [h MI/2, (h + 1) MI/2) of EVERY wave row (local row wm * PH_HR + i * 16 + l15; 128 rows = 16 KB), W part 0 / 1 the first NA /
+    // last NB channel fragments of every wave column (local row wn * N? * 16 + j * 16 + l15): a half-tile is what ONE phase's MFMAs newly
+    // need, so it is free again a phase after it was read and its successor (K-tile + 2, same buffer) can be on its way seven phases
+    // before it is needed.  A K-tile is four phases (256 x 256: AI = 4, NA = NB = 2; 256 x 160: AI = 2, NA = 3, NB = 2):
+    //     phase  fragment reads (ds_read_b128)      MFMAs                               half-tile staged
+    //       0    A0 (2 AI) + WA (2 NA)               A0 x WA   (2 AI NA)                 WA of K-tile u + 1
+    //       1    WB (2 NB)                           A0 x WB   (2 AI NB)                 A0 of K-tile u + 2
+    //       2    A1 (2 AI)                           A1 x WB                             WB of K-tile u + 2
+    //       3    WA (2 NA, again)                    A1 x WA                             A1 of K-tile u + 2   + the K-tile's ONE counted wait
+    // Each phase is [reads + loads + lgkmcnt(0)] s_barrier [MFMAs] s_barrier; waves 4-7 run ONE barrier behind waves 0-3, so on every
+    // SIMD (one wave of each half) one wave is in its MFMA segment while the other reads fragments and issues loads.  Hazards (interval =
+    // the time between two consecutive barriers; half g's phase p reads in interval 2p + g):
+    //   WAR  a half-tile's last reads are complete (lgkmcnt(0)) before the barrier that ends their interval, for both wave halves by the
+    //        end of interval 2p + 1; its successor is issued in phase p + 1 or later (interval >= 2p + 2);
+    //   RAW  every wave waits vmcnt(PH_INFLIGHT) in the read segment of phase 3 (after issuing that phase's loads): everything up to WA of
+    //        the NEXT K-tile -- the youngest half-tile it needs -- has landed, three half-tiles stay in flight; waves 4-7 execute that wait
+    //        one interval later, i.e. before the barrier that ends interval 8u + 7, and the first read of K-tile u + 1 is in interval 8u + 8.
+    // Every wave issues the same number of loads per half-tile (a W part with fewer than 16 chunks: the second instruction of the waves
+    // beyond it re-loads their first chunk), so one count is right for all of them.
+    int ph8_kw0 = 64, ph8_kw1 = 0, ph8_ka = 0;   // K offsets (elements) of the next WA / WB / A half-tiles to stage
     const bf16_t* ph8_a = nullptr;
     const bf16_t* ph8_w = nullptr;
     if constexpr (PH8) {
-        ph8_a = p.A + (size_t)(m0 + wave * 8 + lrow) * p.lda + lchunk * 8;
-        ph8_w = p.Wt + (size_t)(n0 + (wave >> 2) * 64 + (wave & 3) * 8 + lrow) * p.K + lchunk * 8;
+        ph8_a = p.A + (size_t)(m0 + (PH_HR == 64 ? wave * 8 : (wave >> 2) * WTM + (wave & 3) * 8) + lrow) * p.lda + lchunk * 8;
+        ph8_w = p.Wt + (size_t)(n0 + lrow) * p.K + lchunk * 8;
     }
     auto ph8_stage_a = [&](int buf, int h) {
         char* dst = smem + buf * STAGE_BYTES + h * 16384 + wave * 1024;
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                 const bf16_t* src = off >= 0 ? ph8_cbase + (off + c_cin0) : (const bf16_t*)g16_zero_page;
                 glds16(src, dst + qq * 8192);
             } else {
-                glds16(ph8_a + (size_t)(qq * 128 + h * 64) * p.lda + ph8_ka, dst + qq * 8192);
+                glds16(ph8_a + (size_t)(qq * 128 + h * PH_HR) * p.lda + ph8_ka, dst + qq * 8192);
             }
         }
     };
@@ -288,20 +303,31 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             ph8_ka += 64;
         }
     };
-    auto ph8_stage_w = [&](int buf, int h, int koff) {
-        char* dst = smem + buf * STAGE_BYTES + 32768 + h * 16384 + wave * 1024;
+    // W part `part` (0: the first NA fragments of every wave column, 1: the last NB): chunk c = wave + 8 qq holds local rows 8c .. 8c + 7 =
+    // wave column c / (2 N?) , rows (c % (2 N?)) * 8 ...; a chunk index beyond the part re-loads chunk `wave`
+    auto ph8_stage_w = [&](int buf, auto part_c, int koff) {
+        constexpr int PART = decltype(part_c)::value;
+        constexpr int NF = PART ? PH_NB : PH_NA, CH = PART ? PH_WB_CH : PH_WA_CH, NQ = PART ? PH_WB_Q : PH_WA_Q;
+        char* dst = smem + buf * STAGE_BYTES + (PART ? PH_OFF_WB : PH_OFF_W);
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) glds16(ph8_w + (size_t)(qq * 128 + h * 32) * p.K + koff, dst + qq * 8192);
+        for (int qq = 0; qq < NQ; ++qq) {
+            int c = wave + 8 * qq;
+            c = c < CH ? c : wave;
+            const int chan = (c / (2 * NF)) * WTN + (PART ? PH_NA * 16 : 0) + (c % (2 * NF)) * 8;
+            glds16(ph8_w + (size_t)chan * p.K + koff, dst + c * 1024);
+        }
     };
+    using PI0 = std::integral_constant<int, 0>;
+    using PI1 = std::integral_constant<int, 1>;
     if constexpr (PH8) {
-        // K-tile 0 complete, A0 / W1 / A1 of K-tile 1 behind it (its W0 goes out in phase 0 of K-tile 0)
+        // K-tile 0 complete, A0 / WB / A1 of K-tile 1 behind it (its WA goes out in phase 0 of K-tile 0)
         ph8_stage_a(0, 0);
-        ph8_stage_w(0, 0, 0);
-        ph8_stage_w(0, 1, 0);
+        ph8_stage_w(0, PI0{}, 0);
+        ph8_stage_w(0, PI1{}, 0);
         ph8_stage_a(0, 1);
         ph8_adv_a();
         ph8_stage_a(1, 0);
-        ph8_stage_w(1, 1, 64);
+        ph8_stage_w(1, PI1{}, 64);
         ph8_stage_a(1, 1);
         ph8_adv_a();
         ph8_kw1 = 128;
@@ -451,26 +477,31 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         kstep(F_{}, std::integral_constant<int, 0>{}, trans_c);
     };
     if constexpr (PH8) {
-        const int fa_off = (wm * 64 + l15) * 128, fw_off = 32768 + (wn * 32 + l15) * 128;
+        const int fa_off = (wm * PH_HR + l15) * 128;
+        const int fw_off0 = PH_OFF_W + (wn * PH_NA * 16 + l15) * 128, fw_off1 = PH_OFF_WB + (wn * PH_NB * 16 + l15) * 128;
+        const int grp = bwave >> 2;     // waves 4-7 run one barrier behind waves 0-3 (wave w and w + 4 share a SIMD)
         int cur = 0;
-        // one K-tile.  SW0: stage W0 of the next K-tile (phase 0); SA: stage A0 / W1 / A1 of the K-tile after it (phases 1 - 3);
-        // WAITN: the counted wait of phase 3 (6 = three half-tiles stay in flight; 0 = the tail; -1 = nothing left to wait for)
-        auto ph8_tile = [&](auto sw0_c, auto sa_c, auto wait_c) {
-            constexpr bool SW0 = decltype(sw0_c)::value, SA = decltype(sa_c)::value;
+        // one K-tile.  SW0: stage WA of the next K-tile (phase 0); SA: stage A0 / WB / A1 of the K-tile after it (phases 1 - 3);
+        // WAITN: the counted wait of phase 3 (PH_INFLIGHT = three half-tiles stay in flight; 0 = the tail; -1 = nothing left to wait for);
+        // TR: the transposed epilogue's operand order (fused q|k|v: the V^T column tiles)
+        auto ph8_tile = [&](auto sw0_c, auto sa_c, auto wait_c, auto tr_c) {
+            constexpr bool SW0 = decltype(sw0_c)::value, SA = decltype(sa_c)::value, TR = decltype(tr_c)::value;
             constexpr int WAITN = decltype(wait_c)::value;
             const char* sT = smem + cur * STAGE_BYTES;
-            bf16x8 af[2][4], wf[2][2];
+            bf16x8 af[2][PH_AI], wf[2][PH_NA];
             auto read_a = [&](int h) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[kk][i] = *(const bf16x8*)(sT + h * 16384 + fa_off + i * 2048 + (((4 * kk + quad) ^ sw) * 16));
+                    for (int i = 0; i < PH_AI; ++i) af[kk][i] = *(const bf16x8*)(sT + h * 16384 + fa_off + i * 2048 + (((4 * kk + quad) ^ sw) * 16));
             };
-            auto read_w = [&](int h) {
+            auto read_w = [&](auto part_c) {
+                constexpr int PART = decltype(part_c)::value;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) wf[kk][j] = *(const bf16x8*)(sT + h * 16384 + fw_off + j * 2048 + (((4 * kk + quad) ^ sw) * 16));
+                    for (int j = 0; j < (PART ? PH_NB : PH_NA); ++j)
+                        wf[kk][j] = *(const bf16x8*)(sT + (PART ? fw_off1 : fw_off0) + j * 2048 + (((4 * kk + quad) ^ sw) * 16));
             };
             auto mid = [&]() {     // end of a read segment: this wave's fragment reads are complete before anyone passes the barrier
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -479,68 +510,77 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto mma = [&](auto ah_c, auto wh_c) {
-                constexpr int AH = decltype(ah_c)::value, WH = decltype(wh_c)::value;
+            auto mma = [&](auto ah_c, auto part_c) {
+                constexpr int AH = decltype(ah_c)::value, PART = decltype(part_c)::value;
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < PH_AI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[AH * 4 + i][WH * 2 + j] = SUPIR_MFMA_16x16x32(wf[kk][j], af[kk][i], acc[AH * 4 + i][WH * 2 + j], 0, 0, 0);
+                        for (int j = 0; j < (PART ? PH_NB : PH_NA); ++j) {
+                            f32x4_t& c = acc[AH * PH_AI + i][(PART ? PH_NA : 0) + j];
+                            if constexpr (TR) c = SUPIR_MFMA_16x16x32(af[kk][i], wf[kk][j], c, 0, 0, 0);
+                            else c = SUPIR_MFMA_16x16x32(wf[kk][j], af[kk][i], c, 0, 0, 0);
+                        }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             };
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
             // phase 0
-            read_w(0);
+            read_w(PI0{});
             read_a(0);
-            if constexpr (SW0) ph8_stage_w(cur ^ 1, 0, ph8_kw0);
+            if constexpr (SW0) ph8_stage_w(cur ^ 1, PI0{}, ph8_kw0);
             mid();
-            mma(I0{}, I0{});
+            mma(PI0{}, PI0{});
             // phase 1
-            read_w(1);
+            read_w(PI1{});
             if constexpr (SA) ph8_stage_a(cur, 0);
             mid();
-            mma(I0{}, I1{});
+            mma(PI0{}, PI1{});
             // phase 2
             read_a(1);
-            if constexpr (SA) ph8_stage_w(cur, 1, ph8_kw1);
+            if constexpr (SA) ph8_stage_w(cur, PI1{}, ph8_kw1);
             mid();
-            mma(I1{}, I1{});
+            mma(PI1{}, PI1{});
             // phase 3
-            read_w(0);
+            read_w(PI0{});
             if constexpr (SA) {
                 ph8_stage_a(cur, 1);
                 ph8_adv_a();
             }
             if constexpr (WAITN >= 0) g16_wait_vmcnt<WAITN>();
             mid();
-            mma(I1{}, I0{});
+            mma(PI1{}, PI0{});
             ph8_kw0 += 64;
             ph8_kw1 += 64;
             cur ^= 1;
         };
-        g16_wait_vmcnt<6>();
+        g16_wait_vmcnt<PH_INFLIGHT>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (wm == 1) {      // wave row 1 runs one barrier behind row 0 from here on
+        if (grp == 1) {      // the second wave half runs one barrier behind the first from here on
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
-        using W6 = std::integral_constant<int, 6>;
-        using W0 = std::integral_constant<int, 0>;
+        using WF_ = std::integral_constant<int, PH_INFLIGHT>;
+        using W0_ = std::integral_constant<int, 0>;
         using WN_ = std::integral_constant<int, -1>;
-        for (int u = 0; u + 2 < nk; ++u) ph8_tile(T_{}, T_{}, W6{});
-        ph8_tile(T_{}, F_{}, W0{});
-        ph8_tile(F_{}, F_{}, WN_{});
-        if (wm == 0) {
+        auto ph8_loop = [&](auto tr_c) {
+            for (int u = 0; u + 2 < nk; ++u) ph8_tile(T_{}, T_{}, WF_{}, tr_c);
+            ph8_tile(T_{}, F_{}, W0_{}, tr_c);
+            ph8_tile(F_{}, F_{}, WN_{}, tr_c);
+        };
+        if constexpr (MIXED) {
+            if (tr) ph8_loop(T_{});
+            else ph8_loop(F_{});
+        } else {
+            ph8_loop(F_{});
+        }
+        if (grp == 0) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
@@ -945,19 +985,19 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42) return false;
-    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42;
+    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42 && tile != 43) return false;
+    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42 || tile == 43;
     const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
-    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tile 42: at least two K-tiles
+    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tiles 42 / 43: at least two K-tiles
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
     // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU); their GroupNorm
     // partials come in 4-channel units (channel counts 128 / 256 / 512: 4 / 8 / 16 channels per group)
-    if ((tile == 39 || tile == 40 || tile == 42) && (a.out_mode != 0 || a.act == 2)) return false;
+    if ((tile == 39 || tile == 40 || tile == 42 || tile == 43) && (a.out_mode != 0 || a.act == 2)) return false;
     if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % (bn % 10 == 0 ? 10 : 4))) return false;
     if (conv) {
         // tile 42 keeps 32-bit tap offsets against ONE image base per tile: rows of a tile in one batch element, the image below 2^31 elements
-        if (tile == 42 && (a.rows_per_batch % 256 || (long)a.H * a.W * a.lda >= (1L << 31))) return false;
+        if ((tile == 42 || tile == 43) && (a.rows_per_batch % 256 || (long)a.H * a.W * a.lda >= (1L << 31))) return false;
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }
     if (a.act == 2)
@@ -983,6 +1023,7 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
             case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false, true>(&a, st);
             case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false, true>(&a, st);
             case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false, true>(&a, st);
+            case 43: return launch_gemm16<256, 160, 4, 2, 1, 8, false, true>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
@@ -991,6 +1032,7 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
         case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false>(&a, st);
         case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false>(&a, st);
         case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false>(&a, st);
+        case 43: return launch_gemm16<256, 160, 4, 2, 1, 8, false>(&a, st);
         case 38: return t ? launch_gemm16<128, 80, 4, 1, 1, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 1, 3, false>(&a, st);
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);
@@ -1054,7 +1096,7 @@ static int g16_qkv_bn(const GemmArgs& a) {
     const bool ok160 = a.N % 160 == 0 && a.n_split % 160 == 0, ok128 = a.N % 128 == 0 && a.n_split % 128 == 0;
     if (!ok128 || !ok160) return ok128 ? 128 : 160;
     const int knob = supir_debug_knob_value(4);
-    if (knob == 1 || knob == 2) return knob == 1 ? 160 : 128;
+    if (knob == 1 || knob == 2) return knob == 1 ? 160 : 128;   // (3: the eight-phase 256 x 160 form, see supir_gemm16_qkv_launch)
     const long tm = a.M / 256;
     const long c160 = ((tm * (a.N / 160) + 255) / 256) * 160, c128 = ((tm * (a.N / 128) + 255) / 256) * 128;
     return c128 < c160 ? 128 : 160;
@@ -1064,6 +1106,11 @@ int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st) {
     const int bn = g16_qkv_bn(a);
     const int rc = g16_qkv_check(a, bn);
     if (rc != SUPIR_OK) return rc;
+    // knob 4 = 3 (tools) or M >= 8192 (three or more rounds of workgroups: tile batches, --num_samples): the 256 x 160 tile on the
+    // eight-phase schedule (same K order: bitwise-equal results)
+    const int k4 = supir_debug_knob_value(4);
+    if (a.N % 160 == 0 && a.n_split % 160 == 0 && g16_qkv_check(a, 160) == SUPIR_OK && (k4 == 3 || (k4 == 0 && a.M >= 8192)))
+        return launch_gemm16<256, 160, 4, 2, 1, 8, false, false, true>(&a, st);
     if (bn == 128) return launch_gemm16<256, 128, 4, 2, 1, 3, false, false, true>(&a, st);
     if (supir_debug_knob_value(1)) return launch_gemm16<256, 160, 4, 2, 1, 3, false, false, true>(&a, st);
     return launch_gemm16<256, 160, 8, 1, 1, 3, false, false, true>(&a, st);

@@ -486,16 +486,16 @@ G16_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (8192,
               (384, 320, 256)]
 
 
-_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 38: (128, 80)}   # 38: four waves, one K group (round 4)
+_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 38: (128, 80), 43: (256, 160)}   # 38: four waves, one K group (round 4)
 
 
 @pytest.mark.parametrize("M,N,K", G16_SHAPES)
-@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38, 43])
 def test_gemm16_plain_and_epilogues(M, N, K, tile):
     """128 x 80 / 128 x 160 / 256 x 160 tiles (v_mfma_f32_16x16x32_bf16; two K groups per workgroup or eight waves on a 3-deep
     ring): plain, residual + alpha, row bias + SiLU, strided operands, run-to-run bitwise equality."""
     bm, bn = _G16_TILE[tile]
-    if N % bn or M % bm or (tile == 35 and K < 256) or (tile == 38 and K < 128):
+    if N % bn or M % bm or (tile == 35 and K < 256) or (tile in (38, 43) and K < 128):
         pytest.skip("tile needs M % BM == 0, N % BN == 0 and at least ring-depth - 1 K steps per K group")
     a = rnd(M, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
@@ -504,6 +504,9 @@ def test_gemm16_plain_and_epilogues(M, N, K, tile):
     out = ops.gemm(a, w, bias, tile=tile)
     check(out, base, name=f"gemm16{(M, N, K)} tile{tile}")
     assert torch.equal(out, ops.gemm(a, w, bias, tile=tile))
+    if tile == 43:      # the eight-phase 256 x 160 form accumulates in tile 34's K order: bitwise, on every repetition (a racy LDS hand-off
+        for _ in range(3):                                                             # would differ from run to run)
+            assert torch.equal(ops.gemm(a, w, bias, tile=43), ops.gemm(a, w, bias, tile=34))
     check(ops.gemm(a, w, None, tile=tile), a.float() @ w.float().T, name="no bias")
     res = rnd(M, N, seed=3).to(BF)
     check(ops.gemm(a, w, bias, residual=res, alpha=0.5, tile=tile), 0.5 * base + res.float(), name="res+alpha")
@@ -736,12 +739,12 @@ G16_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", G16_CONV_CASES)
-@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38, 43])
 def test_gemm16_conv3x3(case, tile):
     """Implicit-GEMM 3x3 convolution on the 16x16x32 tiles: plain, and with bias + time-embedding row bias + SiLU + residual."""
     B, H, W, Cin, Cout, stride, pad, up, out_hw = case
     bm, bn = _G16_TILE[tile]
-    ks = 1 if tile in (34, 38) else 2
+    ks = 1 if tile in (34, 38, 43) else 2
     x = rnd(B, H, W, Cin).to(BF)
     w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
     bias = rnd(Cout, seed=2)
@@ -755,12 +758,16 @@ def test_gemm16_conv3x3(case, tile):
     else:
         ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=1)
     OH, OW = ref.shape[2:]
-    if (B * OH * OW) % bm or Cout % bn or Cin % (64 * ks):
+    if (B * OH * OW) % bm or Cout % bn or Cin % (64 * ks) or (tile == 43 and (OH * OW) % 256):
         pytest.skip("not an exact fit for this tile")
     ref = ref.permute(0, 2, 3, 1)
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile)
     check(out, ref, name=f"conv16 {case} tile{tile}")
     assert torch.equal(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile))
+    if tile == 43:
+        for _ in range(3):
+            assert torch.equal(ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=43),
+                               ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=34))
     rb = rnd(B, Cout, seed=4).to(BF)
     res = rnd(B, OH, OW, Cout, seed=5).to(BF)
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, rowbias=rb, residual=res, act=1, alpha=0.5,
@@ -906,12 +913,13 @@ def test_gemm_qkv_fused(B, T, C):
         from supir_amd import _lib
         lib, got = _lib.load(BF), []
         try:
-            for width in (1, 2):
+            for width in (1, 2, 3, 3, 3):   # 3: the 256 x 160 tile on the eight-phase schedule (round 5; the default from M = 8192 on), repeated
                 lib.supir_debug_knob(4, width)
                 got.append(ops.gemm_qkv(x, wf, bf_, B, T, 2 * inner, ln=st, colsum=cs))
         finally:
             lib.supir_debug_knob(4, 0)
-        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+        for g in got[1:]:
+            assert torch.equal(got[0][0], g[0]) and torch.equal(got[0][1], g[1])
         assert torch.equal(got[0][0], qk) and torch.equal(got[0][1], vt)
 
 
