@@ -417,6 +417,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--rank-report", action="store_true",
+                    help="every rank prints one '[rank-report] {json}' line on stderr: construction / fill / broadcast seconds and GB/s, host RSS, "
+                         "autotune entries changed by the sync, re-capture seconds, its own images/s (tools/scale_dryrun.sh)")
     ap.add_argument("--no-replay-profile", action="store_true",
                     help="skip the same-box sub-step that re-runs this command (1 image) under rocprofv3 --kernel-trace --stats for the "
                          "dominant kernel's average duration under graph replay (roofline.frac_graph_replay)")
@@ -478,8 +481,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_w = time.perf_counter()
     for i in range(args.warmup):
         out = one_image(model, x, (c, uc), 1234 + rank, args.edm_steps)
+    torch.cuda.synchronize()
+    BUILD_STATS["warmup_s"] = round(time.perf_counter() - t_w, 2)      # autotune of unseen shapes + graph capture + the image(s)
     autotune_resynced = None
     if dist_on and args.warmup > 0:
         # every rank runs the kernels rank 0 picked (per-process autotune can otherwise differ at near-ties, i.e. replicas that
@@ -492,8 +498,12 @@ def main():
         ch = torch.tensor([changed], device=device)
         dist.all_reduce(ch, op=dist.ReduceOp.MAX)
         if int(ch.item()) > 0:   # all ranks run the extra image (keeps them in step; the unchanged ones just replay)
+            t_r = time.perf_counter()
             out = one_image(model, x, (c, uc), 1234 + rank, args.edm_steps)
+            torch.cuda.synchronize()
+            BUILD_STATS["recapture_image_s"] = round(time.perf_counter() - t_r, 2)
         autotune_resynced = int(ch.item())
+        BUILD_STATS.update(autotune_entries_changed_on_this_rank=int(changed), autotune_entries_changed_max_over_ranks=autotune_resynced)
     picks = {"mode": args.tune, "tile_picks": len(ops._TUNE), "choices": len(ops._CHOICE),
              "differ_from_shipped_file": sum(1 for k, v in ops._TUNE.items() if k in shipped[0] and shipped[0][k] != v)
              + sum(1 for k, v in ops._CHOICE.items() if k in shipped[1] and shipped[1][k] != v)}
@@ -510,8 +520,22 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_image(model, x, (c, uc), 1234 + rank + 1000 * (i + 1), args.edm_steps)
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0          # this rank's own clock, before the closing barrier
     sync()
     dt = time.perf_counter() - t0
+    if args.rank_report:
+        # one line per rank on stderr (tools/scale_dryrun.sh collects them): start-up and steady-state figures of THIS rank
+        try:
+            import resource
+            rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+        except Exception:   # noqa: BLE001
+            rss_gb = None
+        rep = dict(rank=rank, world=world, device=torch.cuda.get_device_name(device), host_peak_rss_GB=None if rss_gb is None else round(rss_gb, 2),
+                   device_mem_peak_GB=round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+                   images_per_s_this_rank=round(args.steps * args.images_per_gpu / dt_rank, 4), timed_s_this_rank=round(dt_rank, 3),
+                   timed_s_with_barrier=round(dt, 3), **BUILD_STATS)
+        log("[rank-report] " + json.dumps(rep))
     if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

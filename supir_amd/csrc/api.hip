@@ -46,7 +46,7 @@ int supir_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int 
                        const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                        int out_mode, float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 43 || tile == 36 || tile == 41) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 44 || tile == 36 || tile == 41) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
@@ -72,7 +72,7 @@ int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, i
                           float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                           const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 43 || tile == 36 || tile == 41) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 44 || tile == 36 || tile == 41) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
     if (rowstats_out && (out_mode != 0 || act == 2 || rs_ld <= 0)) return SUPIR_ERR_ARG;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     constexpr int PH_WA_Q = (PH_WA_CH + 7) / 8, PH_WB_Q = (PH_WB_CH + 7) / 8;    // global -> LDS instructions per wave (the last may repeat chunk `wave`)
     constexpr int PH_OFF_W = 32768, PH_OFF_WB = PH_OFF_W + PH_WA_ROWS * 128;     // LDS map of a K-tile buffer: [A0 16K | A1 16K | WA | WB]
     constexpr int PH_INFLIGHT = 2 + PH_WB_Q + 2;        // loads per wave behind W part 0 of the next K-tile: A0, WB, A1 of the one after
-    static_assert(!PH8 || (PH_WA_CH <= 16 && PH_WB_CH <= 16 && (PH_HR == 64 || PH_HR == 32) && PH_OFF_WB + PH_WB_ROWS * 128 == STAGE_BYTES), "half-tile map");
+    static_assert(!PH8 || (PH_WA_CH <= 24 && PH_WB_CH <= 24 && (PH_HR == 64 || PH_HR == 32) && PH_OFF_WB + PH_WB_ROWS * 128 == STAGE_BYTES), "half-tile map");
     static_assert(!(CONV && TRANS) && !(MIXED && (TRANS || CONV || KS != 1)), "the implicit-GEMM loader has no transposed epilogue");
     // epilogue LDS map (the rings are idle by then): [0, XCH) K-group exchange, then per-wave C staging, bias / column sums,
     // row-statistics scratch
@@ -272,11 +272,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     // Every wave issues the same number of loads per half-tile (a W part with fewer than 16 chunks: the second instruction of the waves
     // beyond it re-loads their first chunk), so one count is right for all of them.
     int ph8_kw0 = 64, ph8_kw1 = 0, ph8_ka = 0;   // K offsets (elements) of the next WA / WB / A half-tiles to stage
-    const bf16_t* ph8_a = nullptr;
-    const bf16_t* ph8_w = nullptr;
+    // addresses as (wave-uniform 64-bit base) + (per-lane 32-bit byte offset, constant over the loop): the loads take the scalar-base form
+    // and the loop keeps ONE offset register per operand instead of a strength-reduced 64-bit pointer per load (10 loads = 20 VGPRs on
+    // the 256 x 320 tile, which spilled)
+    const char* ph8_a = nullptr;
+    const char* ph8_w = nullptr;
+    unsigned ph8_a_lane = 0, ph8_w_lane = 0;
     if constexpr (PH8) {
-        ph8_a = p.A + (size_t)(m0 + (PH_HR == 64 ? wave * 8 : (wave >> 2) * WTM + (wave & 3) * 8) + lrow) * p.lda + lchunk * 8;
-        ph8_w = p.Wt + (size_t)(n0 + lrow) * p.K + lchunk * 8;
+        ph8_a = (const char*)(p.A + (size_t)(m0 + (PH_HR == 64 ? wave * 8 : (wave >> 2) * WTM + (wave & 3) * 8)) * p.lda);
+        ph8_w = (const char*)(p.Wt + (size_t)n0 * p.K);
+        ph8_a_lane = (unsigned)(lrow * p.lda + lchunk * 8) * 2u;
+        ph8_w_lane = (unsigned)(lrow * p.K + lchunk * 8) * 2u;
     }
     auto ph8_stage_a = [&](int buf, int h) {
         char* dst = smem + buf * STAGE_BYTES + h * 16384 + wave * 1024;
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                 const bf16_t* src = off >= 0 ? ph8_cbase + (off + c_cin0) : (const bf16_t*)g16_zero_page;
                 glds16(src, dst + qq * 8192);
             } else {
-                glds16(ph8_a + (size_t)(qq * 128 + h * PH_HR) * p.lda + ph8_ka, dst + qq * 8192);
+                glds16(ph8_a + ((size_t)(qq * 128 + h * PH_HR) * p.lda + ph8_ka) * 2 + ph8_a_lane, dst + qq * 8192);
             }
         }
     };
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             int c = wave + 8 * qq;
             c = c < CH ? c : wave;
             const int chan = (c / (2 * NF)) * WTN + (PART ? PH_NA * 16 : 0) + (c % (2 * NF)) * 8;
-            glds16(ph8_w + (size_t)chan * p.K + koff, dst + c * 1024);
+            glds16(ph8_w + ((size_t)chan * p.K + koff) * 2 + ph8_w_lane, dst + c * 1024);
         }
     };
     using PI0 = std::integral_constant<int, 0>;
@@ -593,40 +599,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 
     // ------------------------------------------------------------------ epilogue
     G16_TL(tl_loop1);
-    // Large tiles (no room to hold the residual / row-bias operands across the main loop: !PRE): fetch them block-wise AHEAD of their
-    // use instead of inside each 16-token block -- the timeline of round 5 (profiles/r05/timeline_large.log) shows the epilogue of the
-    // 256 x 160 / 256 x 256 tiles at 14-22 k cycles per wave, 10-26 % of the launch, ~2 k cycles per block = one dependent L2 / fabric
-    // round trip each.  EPD blocks are in flight: all of them where 2 x MIH x NI x 2 registers fit beside the accumulators (<= 20
-    // fragments), two otherwise (256 x 256); the first ones are issued HERE, under the barrier and the K-group exchange.  In-place
-    // residuals stay safe: a block's rows are read before any of ITS stores, rows of other blocks are disjoint.
-    constexpr bool EPF = !PRE && !TRANS && (MIH * NI <= 20 || PH8);   // not tile 40 (256 x 256, 4 x 2: 8 fragments per block -- it spills; tile 42 supersedes it)
-    constexpr int EPD = !EPF ? 0 : (MIH * NI <= 20 ? MIH : 2);
-    u32x2 q_res[EPF ? MIH : 1][EPF ? NI : 1], q_rb[EPF ? MIH : 1][EPF ? NI : 1];
-    auto ep_fetch = [&](int h) {
-        if constexpr (EPF) {
-            const int m = m0 + wm * WTM + (kg * MIH + h) * 16 + l15;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) q_res[h][j] = q_rb[h][j] = u32x2{0u, 0u};
-            if (p.rowbias) {
-                const bf16_t* rbp = p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rb + n0 + wn * WTN + 4 * quad;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) q_rb[h][j] = *(const u32x2*)(rbp + j * 16);
-            }
-            if (p.res) {
-                const bf16_t* rp = p.res + (size_t)m * p.ldr + n0 + wn * WTN + 4 * quad;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) q_res[h][j] = *(const u32x2*)(rp + j * 16);
-            }
-        }
-    };
-    if constexpr (EPF) {
-        __builtin_amdgcn_sched_barrier(0);      // not into the last K step (its fragment registers are still live there)
-        if (!tr && p.act != 2) {
-#pragma unroll
-            for (int h = 0; h < EPD; ++h) ep_fetch(h);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    // (Round 5 tried fetching the residual / row-bias operands of the large tiles AHEAD of their 16-token block -- all blocks at once on
+    // 256 x 160, two in flight on 256 x 256: the per-wave epilogue fell from 14.3 k to 6.4 k cycles and the wait moved in front of the
+    // barrier, 0.5 k -> 11 k cycles; launches +2..5 % slower.  256 workgroups pull 80 KB of residual and push 80 KB of output each in the
+    // same few microseconds: the epilogue of the large tiles is THROUGHPUT-bound, not a chain of round trips.
+    // profiles/r05/experiment_timeline_epilogue_prefetch_and_tile43.log)
     __syncthreads();   // every wave is done with its last fragment reads: the rings are scratch from here on
     if constexpr (!TRANS) {
         if (kg == 0 && tid < BN && !tr) {
@@ -797,13 +774,6 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                     for (int j = 0; j < NI; ++j) {
                         e_rb[j] = pre_rb[h][j];
                         e_res[j] = pre_res[h][j];
-                    }
-                } else if constexpr (EPF) {
-                    if (h + EPD < MIH) ep_fetch(h + EPD);     // keep EPD blocks of residual / row-bias operands in flight
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        e_rb[j] = q_rb[h][j];
-                        e_res[j] = q_res[h][j];
                     }
                 } else {
 #pragma unroll
@@ -985,15 +955,16 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42 && tile != 43) return false;
-    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42 || tile == 43;
-    const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
+    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && (tile < 42 || tile > 44)) return false;
+    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile >= 42;
+    const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : tile == 44 ? 320 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
     const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tiles 42 / 43: at least two K-tiles
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
     // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU); their GroupNorm
     // partials come in 4-channel units (channel counts 128 / 256 / 512: 4 / 8 / 16 channels per group)
     if ((tile == 39 || tile == 40 || tile == 42 || tile == 43) && (a.out_mode != 0 || a.act == 2)) return false;
+    if (tile == 44 && (a.act != 2 || conv)) return false;      // the 256 x 320 eight-phase tile exists for the GEGLU projections only
     if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % (bn % 10 == 0 ? 10 : 4))) return false;
     if (conv) {
         // tile 42 keeps 32-bit tap offsets against ONE image base per tile: rows of a tile in one batch element, the image below 2^31 elements
@@ -1001,7 +972,7 @@ bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }
     if (a.act == 2)
-        return tile == 34 && a.out_mode == 0 && !a.res && !a.rowbias && !a.rowstats_out && a.ldc % 8 == 0 && (((size_t)a.C) & 15) == 0;
+        return (tile == 34 || tile == 44) && a.out_mode == 0 && !a.res && !a.rowbias && !a.rowstats_out && a.ldc % 8 == 0 && (((size_t)a.C) & 15) == 0;
     if (a.out_mode == 2) return a.rows_per_batch % 4 == 0 && a.ldc % 4 == 0 && !a.res && !a.rowbias && a.act == 0;
     if (a.ldc % 8 || (((size_t)a.C) & 15)) return false;
     if ((a.res && a.ldr % 4) || (a.rowbias && a.ld_rb % 4)) return false;
@@ -1033,6 +1004,7 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
         case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false>(&a, st);
         case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false>(&a, st);
         case 43: return launch_gemm16<256, 160, 4, 2, 1, 8, false>(&a, st);
+        case 44: return launch_gemm16<256, 320, 4, 2, 1, 8, false>(&a, st);
         case 38: return t ? launch_gemm16<128, 80, 4, 1, 1, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 1, 3, false>(&a, st);
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);

@@ -83,6 +83,7 @@ struct XattnArgs {
     float scale_log2e;
     const char* pf_ptr;     // next-weight prefetch, as GemmArgs
     unsigned pf_lines;
+    int gm, gn;             // 2-D XCD grid (launcher): XCD x owns token-block chunk x / gn and head chunk x % gn; gm = 0 -> 1-D ranges
 };
 
 struct GnArgs {
@@ -134,6 +135,8 @@ int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st);
 // knob 1: wave arrangement of the 256 x 160 tile (csrc/gemm16.hip): 0 = product policy, 1 = always 4 x 2, 2 = always 8 x 1
 // knob 2: GroupNorm apply with n row batches per workgroup instead of ~32 KB per workgroup (measured: no gain; csrc/norm.hip)
 // knob 3: flash attention d64: 0 = product policy, 1 = the round-3 kernel, 2 = always eight waves, 3 = always four waves (round-4 form)
+// knob 4: fused q|k|v tile: 0 = product policy, 1 = 256 x 160, 2 = 256 x 128, 3 = 256 x 160 on the eight-phase schedule
+// knob 5: xattn_q workgroup order: 0 = 2-D XCD grid (product), 1 = 1-D ranges with the heads fastest (round 4)
 int supir_debug_knob_value(int which);
 bool supir_gemm_big_supported(const GemmArgs& a);
 int supir_gemm_big_launch(const GemmArgs& a, hipStream_t st);

@@ -40,8 +40,21 @@ __global__ __launch_bounds__(256, 2) void xattn_q_kernel(const XattnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int nqb = p.T >> 7;
-    const int id = xcd_remap(blockIdx.x, nqb * p.H * p.B);
-    const int h = id % p.H, rq = id / p.H;          // heads fastest
+    int h, rq;
+    if (p.gm > 0) {
+        // 2-D XCD grid (round 5): block b runs on XCD b % 8 with a private L2; XCD (xm, xn) owns the token blocks of chunk xm and the heads
+        // of chunk xn, so it pulls (blocks / gm) token tiles and (H / gn) heads' weight rows instead of 2 token tiles and ALL of W_q
+        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        const int hpx = p.H / p.gn, tpx = (nqb * p.B) / p.gm;
+        const int xm = xcd / p.gn, xn = xcd - xm * p.gn;
+        const int lt = idx / hpx, lh = idx - lt * hpx;   // heads fastest inside the XCD's region
+        h = xn * hpx + lh;
+        rq = xm * tpx + lt;
+    } else {
+        const int id = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+        h = id % p.H;                                 // heads fastest
+        rq = id / p.H;
+    }
     const int qb = rq % nqb, b = rq / nqb;
     const size_t m0 = (size_t)b * p.T + (size_t)qb * 128;
 
@@ -291,8 +304,29 @@ bool supir_xattn_q_supported(const XattnArgs& a) {
     return true;
 }
 
-int supir_xattn_q_launch(const XattnArgs& a, hipStream_t st) {
-    if (!supir_xattn_q_supported(a)) return SUPIR_ERR_SHAPE;
+int supir_xattn_q_launch(const XattnArgs& a_in, hipStream_t st) {
+    if (!supir_xattn_q_supported(a_in)) return SUPIR_ERR_SHAPE;
+    XattnArgs a = a_in;
+    // XCD partition: every XCD's L2 pulls its own copy of what its workgroups read.  1-D ranges with the heads fastest give an XCD
+    // (blocks / 8) token tiles and every head's weight rows -- at (B 2, H 20, T 1024, C 1280) 0.65 MB of tokens and ALL 3.3 MB of W_q,
+    // 35.8 MB fetched for 9.3 MB of operands (profiles/pmc_traffic.json, round 4).  A gm x gn grid of XCDs (token-block chunks x head
+    // chunks) cuts that to (blocks / gm) x 128 x C + (H / gn) x 64 x C elements per XCD; pick the cheapest grid that divides both counts
+    // (knob 5 = 1, tools: keep the 1-D ranges)
+    a.gm = a.gn = 0;
+    const int blocks = (a.T / 128) * a.B;
+    if (supir_debug_knob_value(5) != 1) {
+        double best = 0.0;
+        for (int gm = 8; gm >= 1; gm >>= 1) {
+            const int gn = 8 / gm;
+            if (blocks % gm || a.H % gn) continue;
+            const double cost = (double)(blocks / gm) * 128.0 + (double)(a.H / gn) * 64.0;     // x C x 2 bytes
+            if (a.gm == 0 || cost < best) {
+                best = cost;
+                a.gm = gm;
+                a.gn = gn;
+            }
+        }
+    }
     SUPIR_LAUNCH(xattn_q_kernel, dim3((a.T / 128) * a.H * a.B), dim3(256), 0, st, a);
     return SUPIR_LAUNCH_STATUS();
 }

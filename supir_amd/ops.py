@@ -78,7 +78,7 @@ def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1, group=1):
         return f"gemm_bf16_kernel<{name},conv,split9>+finalize"
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv",
-              38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2", 41: "256,128,1k,s3,qkv", 42: "256,256,1k,8ph", 43: "256,160,1k,8ph"}[tile]
+              38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2", 41: "256,128,1k,s3,qkv", 42: "256,256,1k,8ph", 43: "256,160,1k,8ph", 44: "256,320,1k,8ph"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}{g}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
@@ -638,7 +638,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         rows_per_batch = M   # one batch: the partials' row-chunk index is computed from it (never 0 in the kernel)
 
     def wb(t):
-        return (alt16[0], alt16[1]) if (t in (34, 37) and act == 2 and alt16 is not None) else (w, bias)
+        return (alt16[0], alt16[1]) if (t in (34, 37, 44) and act == 2 and alt16 is not None) else (w, bias)
 
     def launch(t, outp=None, hints=None):
         wq, bq = wb(t)
@@ -691,16 +691,17 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
 
 _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
-               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2), 38: (80, 1), 39: (128, 2), 40: (256, 2), 42: (256, 4), 43: (160, 2)}
-G16_TILES = {32, 33, 34, 35, 39, 40, 42, 43}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
+               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2), 38: (80, 1), 39: (128, 2), 40: (256, 2), 42: (256, 4), 43: (160, 2), 44: (320, 2)}
+G16_TILES = {32, 33, 34, 35, 39, 40, 42, 44}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
 # tile: (BM, BN, K groups, ring).  38 = 128 x 80 with FOUR waves and a 78 KB ring (two workgroups per CU): known to the mirror, enabled
 # by adding it to G16_TILES (tools/step_ab4.py); not in the default lists -- see DESIGN.md section 3 for what it measured
 # 39 / 40 = 256 x 128 and 256 x 256 (round 4): the VAE's 128 / 256 / 512-channel layers; ordinary epilogue only, and offered only where no
 # 80-column tile fits (N % 80 != 0), so the candidate lists -- and with them the picks -- of the UNet's shapes are what they were
 _G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3), 38: (128, 80, 1, 3),
-        39: (256, 128, 1, 3), 40: (256, 256, 1, 2), 42: (256, 256, 1, 3), 43: (256, 160, 1, 3)}
-# 42 / 43 = 256 x 256 / 256 x 160 on the eight-phase ping-pong schedule (round 5; ring column = 3: they need at least two K-tiles);
-# ordinary epilogue only (no transposed output, no GEGLU)
+        39: (256, 128, 1, 3), 40: (256, 256, 1, 2), 42: (256, 256, 1, 3), 43: (256, 160, 1, 3), 44: (256, 320, 1, 3)}
+# 42 / 43 / 44 = 256 x 256 / 256 x 160 / 256 x 320 on the eight-phase ping-pong schedule (round 5; ring column = 3: they need at least
+# two K-tiles).  42 / 43: ordinary epilogue only (no transposed output, no GEGLU); 44: the GEGLU projections only (16-row interleave, as 34).
+# 43 is known to the mirror but NOT in G16_TILES: it measured 5-10 % slower than tile 34 on every shape (profiles/r05/experiment_*)
 _G16_NO_TRANS = (39, 40, 42, 43)
 _G16_PLAIN_ONLY = (39, 40, 42)
 USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc/gemm16.hip) in the autotune lists
@@ -723,7 +724,9 @@ def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu1
             continue
         if M % bm or N % bn or K % (64 * ks) or (K // 64) // ks < s - 1:
             continue
-        if act == 2 and not (t == 34 and geglu16):
+        if act == 2 and not (t in (34, 44) and geglu16):
+            continue
+        if t == 44 and act != 2:
             continue
         if t in _G16_PLAIN_ONLY and (om != 0 or N % 80 == 0):
             continue
@@ -803,7 +806,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
         assert colsum is not None and colsum.numel() == N
 
     def wcb(t):
-        return alt16 if (t in (34, 37) and act == 2 and alt16 is not None) else (w, colsum, bias)
+        return alt16 if (t in (34, 37, 44) and act == 2 and alt16 is not None) else (w, colsum, bias)
 
     def launch(t, outp=None, hints=None):
         wq, cq, bq = wcb(t)

@@ -657,6 +657,40 @@ def test_gemm_big_geglu(M, K, N2):
         ops.gemm(a[: M - 64], w16, b16, act=2, tile=37)
 
 
+@pytest.mark.parametrize("M,K,N2", [(2048, 1280, 10240), (8192, 640, 5120), (256, 128, 640), (512, 320, 1280)])
+def test_gemm16_geglu_on_the_eight_phase_256x320_tile(M, K, N2):
+    """Tile 44 (round 5): the GEGLU projections (sgm/modules/attention.py:84-91) on a 256 x 320 tile with the eight-phase ping-pong
+    schedule of csrc/gemm16.hip -- same 16-row value / gate interleave, same epilogue and same K order as tile 34: bitwise tile 34, with
+    and without the LayerNorm fold; the reference formula; shapes it does not fit are refused."""
+    from supir_amd.weights import fold_layernorm, interleave_geglu
+    a = rnd(M, K).to(BF)
+    w = rnd(N2, K, scale=K ** -0.5, seed=1).to(BF)
+    bias = rnd(N2, seed=2)
+    w16, b16 = interleave_geglu(w, bias, 16)
+    out = ops.gemm(a, w16, b16, act=2, tile=44)
+    v, g = (a.float() @ w.float().T + bias).chunk(2, dim=-1)
+    check(out, v * F.gelu(g), name="geglu 8-phase")
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, w16, b16, act=2, tile=44), ops.gemm(a, w16, b16, act=2, tile=34))
+    C = K
+    wp = rnd(C, C, scale=C ** -0.5, seed=5).to(BF)
+    x, st = ops.gemm_ln(a, wp, None, emit_stats=True)
+    gamma, beta = rnd(C, seed=6) * 0.2 + 1.0, rnd(C, seed=7) * 0.2
+    wf, cs, bf_ = fold_layernorm(w.float(), bias, gamma, beta)
+    wf16, bf16_ = interleave_geglu(wf, bf_, 16)
+    _, cs16 = interleave_geglu(wf, cs, 16)
+    o44 = ops.gemm_ln(x, wf16, bf16_, act=2, ln=st, colsum=cs16, tile=44)
+    assert torch.equal(o44, ops.gemm_ln(x, wf16, bf16_, act=2, ln=st, colsum=cs16, tile=34))
+    yr = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T + bias
+    vr, gr = yr.chunk(2, dim=-1)
+    check(o44, vr * F.gelu(gr), rel=8e-3, name="geglu 8-phase ln-fold")
+    from supir_amd._lib import SupirHipError
+    with pytest.raises(SupirHipError):
+        ops.gemm(a[: M - 64], w16, b16, act=2, tile=44)
+    with pytest.raises(SupirHipError):
+        ops.gemm(a, w, bias, tile=44)          # GEGLU only
+
+
 def _unit_sums(y, B, rows_per_batch, bm):
     """(sum, sum of squares) per (batch, tile row of bm rows, 10-channel unit) of a bf16 [B * rows, C] tensor, in fp64."""
     C = y.shape[-1]
@@ -1046,6 +1080,13 @@ def test_xattn_q_plain_strided_and_prefetch(B, H, T, Tk, C):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(o2, out.contiguous()) and torch.equal(nxt, nxt_copy)
+    # the 2-D XCD grid (round 5: token-block chunks x head chunks per XCD) only re-orders workgroups: bitwise the 1-D order (tools knob 5 = 1)
+    try:
+        lib.supir_debug_knob(5, 1)
+        o1d = ops.xattn_q(xw[:, :, :C], wb, None, kw[:, :, N:], vt, B, H, T, Tk)
+    finally:
+        lib.supir_debug_knob(5, 0)
+    assert torch.equal(o1d, ops.xattn_q(xw[:, :, :C], wb, None, kw[:, :, N:], vt, B, H, T, Tk))
 
 
 def test_xattn_q_rejects_what_it_does_not_cover():

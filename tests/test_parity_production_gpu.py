@@ -231,6 +231,42 @@ def test_batchify_sample_config2_50_steps_vs_oracle_bf16(model):
     assert errs["latent_hip_vs_aten_bf16"] <= 5e-3 and errs["psnr_hip_vs_aten_bf16_db"] >= 40.0
 
 
+def test_num_samples_4_vs_four_single_image_runs(model):
+    """test.py --num_samples N (test.py:96-101; SUPIR_model.py:90-94: the image is repeated N times and ONE batchify_sample call samples
+    N variations, B = 2N in the network) as a measured product mode (VERDICT r04 missing 5): N = 4 at 1024^2 through the fused sampler
+    step, the per-image embedding schedule (batch 8 tables) and hipGraph replay, every RNG draw injected, against FOUR single-image runs
+    of the same path with the matching noise slices.  The two differ only in the kernels the shapes pick (M = 8192 tiles vs M = 2048
+    tiles: other tile sizes, same K order per element where the tiles share it) -- the bar is the one two bf16 evaluations of the same
+    trajectory get (the product vs ATen-bf16 in test_batchify_sample_config2_50_steps_vs_oracle_bf16)."""
+    P, lat, steps, N = 1024, 128, 10, 4
+    x = T("ns4.img", (1, 3, P, P), scale=0.5).clamp(-1, 1)
+    c, uc = _cond(N)
+    noises = {"posterior": T("ns4.post", (N, 4, lat, lat)), "init": T("ns4.init", (N, 4, lat, lat)),
+              "steps": [T(f"ns4.eps{i}", (N, 4, lat, lat)) for i in range(steps)]}
+    kw = dict(num_steps=steps, restoration_scale=-1, s_churn=5, s_noise=1.01, cfg_scale=4.0, control_scale=1.0, seed=1234,
+              color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=1.0, return_intermediates=True)
+
+    def sl(d, i):
+        return {k: (v[i:i + 1].clone() if torch.is_tensor(v) else [t[i:i + 1].clone() for t in v]) for k, v in d.items()}
+
+    model.model.enable_graph(True)
+    try:
+        with torch.no_grad():
+            out4, mid4 = model.batchify_sample(x, cond=(c, uc), num_samples=N, noises={k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v])
+                                                                                        for k, v in noises.items()}, **kw)
+            singles = [model.batchify_sample(x, cond=(sl(c, i), sl(uc, i)), num_samples=1, noises=sl(noises, i), **kw) for i in range(N)]
+    finally:
+        model.model.enable_graph(False)
+    assert out4.shape == (N, 3, P, P) and torch.isfinite(out4).all()
+    worst_lat, worst_psnr = 0.0, float("inf")
+    for i, (o1, m1) in enumerate(singles):
+        worst_lat = max(worst_lat, rel_l2(mid4["samples"][i:i + 1], m1["samples"]))
+        worst_psnr = min(worst_psnr, psnr(out4[i:i + 1], o1))
+    record("num_samples_4_1024px_10steps_vs_single_image_runs", latent_rel_l2_worst=worst_lat, image_psnr_db_worst=worst_psnr)
+    assert not torch.equal(out4[0], out4[1])                # the four samples are four different draws
+    assert worst_lat <= 5e-3 and worst_psnr >= 40.0, (worst_lat, worst_psnr)
+
+
 def test_batchify_sample_config2_10_steps_vs_fp32_oracle(model):
     """The bench workload's arithmetic against the FP32 oracle in the default run (the 50-step fp32 comparison
     is opt-in because it costs two minutes): 1024^2, 10 EDM steps through the hipGraph path, every noise injected.  Ten steps
