@@ -96,8 +96,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     static_assert((NWT == 8 || (NWT == 4 && KS == 1 && !MIXED && NP == 1)) && (BM / 8) % NW == 0 && (NW & 1) == 0,
                   "512 threads (or the four-wave single-group form); A chunks divide over the waves");
     static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3 || S == 8), "tile / wave grid");
-    // eight-phase schedule: 256 token rows, 8 waves as 2 x 4 (256 x 256: 128 x 64 per wave, tile 42) or 4 x 2 (256 x 160: 64 x 80 per wave,
-    // tile 43); the wave tile's MI token fragments split 2 + 2 halves, its NI channel fragments NA + NB parts (2 + 2 / 3 + 2)
+    // eight-phase schedule: 256 token rows, 8 waves; the wave tile's MI token fragments split into two halves, its NI channel fragments
+    // into NA + NB parts.  Shipped: 256 x 256 as 2 x 4 waves (128 x 64 per wave, 2 + 2 fragments: tile 42).  The same code was measured
+    // as 256 x 160 (4 x 2 waves, 3 + 2) and as 256 x 320 for the GEGLU projections (4 x 2, 5 + 5): bitwise the one-barrier tiles' results,
+    // 5-10 % slower than tile 34 resp. equal to tile 37 -- phases of 8-12 MFMAs are too short for two barriers each, and 216 live registers
+    // spill (profiles/r05/experiment_*); those instantiations are not built
     static_assert(!PH8 || (BM == 256 && KS == 1 && !TRANS && NP == 1 && NWT == 8 && (MI & 1) == 0 && NI >= 2 && (!MIXED || !CONV)), "eight-phase schedule");
     constexpr int PH_HR = WTM / 2;                       // token rows of one wave in an A half-tile
     constexpr int PH_AI = MI / 2;                        // token fragments per A half
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 
     const int nk = (p.K >> 6) / KS;   // K steps of this group (>= S - 1: dispatcher; eight-phase schedule: >= 2)
 
-    // ---- eight-phase schedule (tiles 42 / 43): LDS = two K-tile buffers of four HALF-TILES [A0 | A1 | WA | WB].  A-half h holds token
+    // ---- eight-phase schedule (tile 42): LDS = two K-tile buffers of four HALF-TILES [A0 | A1 | WA | WB].  A-half h holds token
     // fragments [h MI/2, (h + 1) MI/2) of EVERY wave row (local row wm * PH_HR + i * 16 + l15; 128 rows = 16 KB), W part 0 / 1 the first NA /
     // last NB channel fragments of every wave column (local row wn * N? * 16 + j * 16 + l15): a half-tile is what ONE phase's MFMAs newly
     // need, so it is free again a phase after it was read and its successor (K-tile + 2, same buffer) can be on its way seven phases
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                             for (int e = 0; e < 4; ++e) {
                                 const float v = rs * (acc[KG * MIH + h][2 * jp][e] - mu * cv[e]) + bv[e];
                                 const float g = rs * (acc[KG * MIH + h][2 * jp + 1][e] - mu * cg[e]) + bg[e];
-                                r[e] = v * gelu_f(g);
+                                r[e] = v * (p.fast_gelu ? gelu_fast_f(g) : gelu_f(g));
                             }
                             const u32x2 o = {f2bf_pk(r[0], r[1]), f2bf_pk(r[2], r[3])};
                             *(u32x2*)(c_stage + l15 * C_RS + (jp * 16 + 4 * quad) * 2) = o;
@@ -930,7 +933,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1>
 static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     GemmArgsN<NP> pp;
-    for (int q = 0; q < NP; ++q) pp.p[q] = a_in[q];
+    for (int q = 0; q < NP; ++q) {
+        pp.p[q] = a_in[q];
+        pp.p[q].fast_gelu = supir_debug_knob_value(0) ? 0 : 1;   // one switch for every GEGLU epilogue (tile 37 reads the same knob)
+    }
     GemmArgs& a = pp.p[0];
     const int tiles = (a.M / BM) * (a.N / BN);
     if (NP > 1 && tiles % (8 / NP)) return SUPIR_ERR_SHAPE;
@@ -955,24 +961,23 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && (tile < 42 || tile > 44)) return false;
-    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile >= 42;
-    const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : tile == 44 ? 320 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
-    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tiles 42 / 43: at least two K-tiles
+    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42) return false;
+    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42;
+    const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
+    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tile 42: at least two K-tiles
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
     // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU); their GroupNorm
     // partials come in 4-channel units (channel counts 128 / 256 / 512: 4 / 8 / 16 channels per group)
-    if ((tile == 39 || tile == 40 || tile == 42 || tile == 43) && (a.out_mode != 0 || a.act == 2)) return false;
-    if (tile == 44 && (a.act != 2 || conv)) return false;      // the 256 x 320 eight-phase tile exists for the GEGLU projections only
+    if ((tile == 39 || tile == 40 || tile == 42) && (a.out_mode != 0 || a.act == 2)) return false;
     if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % (bn % 10 == 0 ? 10 : 4))) return false;
     if (conv) {
         // tile 42 keeps 32-bit tap offsets against ONE image base per tile: rows of a tile in one batch element, the image below 2^31 elements
-        if ((tile == 42 || tile == 43) && (a.rows_per_batch % 256 || (long)a.H * a.W * a.lda >= (1L << 31))) return false;
+        if (tile == 42 && (a.rows_per_batch % 256 || (long)a.H * a.W * a.lda >= (1L << 31))) return false;
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }
     if (a.act == 2)
-        return (tile == 34 || tile == 44) && a.out_mode == 0 && !a.res && !a.rowbias && !a.rowstats_out && a.ldc % 8 == 0 && (((size_t)a.C) & 15) == 0;
+        return tile == 34 && a.out_mode == 0 && !a.res && !a.rowbias && !a.rowstats_out && a.ldc % 8 == 0 && (((size_t)a.C) & 15) == 0;
     if (a.out_mode == 2) return a.rows_per_batch % 4 == 0 && a.ldc % 4 == 0 && !a.res && !a.rowbias && a.act == 0;
     if (a.ldc % 8 || (((size_t)a.C) & 15)) return false;
     if ((a.res && a.ldr % 4) || (a.rowbias && a.ld_rb % 4)) return false;
@@ -994,7 +999,6 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
             case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false, true>(&a, st);
             case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false, true>(&a, st);
             case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false, true>(&a, st);
-            case 43: return launch_gemm16<256, 160, 4, 2, 1, 8, false, true>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
@@ -1003,8 +1007,6 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
         case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false>(&a, st);
         case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false>(&a, st);
         case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false>(&a, st);
-        case 43: return launch_gemm16<256, 160, 4, 2, 1, 8, false>(&a, st);
-        case 44: return launch_gemm16<256, 320, 4, 2, 1, 8, false>(&a, st);
         case 38: return t ? launch_gemm16<128, 80, 4, 1, 1, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 1, 3, false>(&a, st);
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);
@@ -1068,7 +1070,7 @@ static int g16_qkv_bn(const GemmArgs& a) {
     const bool ok160 = a.N % 160 == 0 && a.n_split % 160 == 0, ok128 = a.N % 128 == 0 && a.n_split % 128 == 0;
     if (!ok128 || !ok160) return ok128 ? 128 : 160;
     const int knob = supir_debug_knob_value(4);
-    if (knob == 1 || knob == 2) return knob == 1 ? 160 : 128;   // (3: the eight-phase 256 x 160 form, see supir_gemm16_qkv_launch)
+    if (knob == 1 || knob == 2) return knob == 1 ? 160 : 128;
     const long tm = a.M / 256;
     const long c160 = ((tm * (a.N / 160) + 255) / 256) * 160, c128 = ((tm * (a.N / 128) + 255) / 256) * 128;
     return c128 < c160 ? 128 : 160;
@@ -1078,11 +1080,6 @@ int supir_gemm16_qkv_launch(const GemmArgs& a, hipStream_t st) {
     const int bn = g16_qkv_bn(a);
     const int rc = g16_qkv_check(a, bn);
     if (rc != SUPIR_OK) return rc;
-    // knob 4 = 3 (tools) or M >= 8192 (three or more rounds of workgroups: tile batches, --num_samples): the 256 x 160 tile on the
-    // eight-phase schedule (same K order: bitwise-equal results)
-    const int k4 = supir_debug_knob_value(4);
-    if (a.N % 160 == 0 && a.n_split % 160 == 0 && g16_qkv_check(a, 160) == SUPIR_OK && (k4 == 3 || (k4 == 0 && a.M >= 8192)))
-        return launch_gemm16<256, 160, 4, 2, 1, 8, false, false, true>(&a, st);
     if (bn == 128) return launch_gemm16<256, 128, 4, 2, 1, 3, false, false, true>(&a, st);
     if (supir_debug_knob_value(1)) return launch_gemm16<256, 160, 4, 2, 1, 3, false, false, true>(&a, st);
     return launch_gemm16<256, 160, 8, 1, 1, 3, false, false, true>(&a, st);

@@ -14,6 +14,8 @@ struct GemmArgs {
     int rows_per_batch;     // rows (tokens) per batch element
     int H, W, Cin, OH, OW, stride, pad_t, pad_l, up;  // conv geometry (virtual input = 2H x 2W when up)
     int act;                // 0 none, 1 SiLU, 2 GEGLU (value/gate interleaved per 32 columns)
+    int fast_gelu;          // GEGLU epilogues: 1 = the fitted GELU (gelu_fast_f, |error| <= 2.5e-5), 0 = erf; set by the launchers from ONE
+                            // switch for every GEGLU tile (supir_debug_knob 0), so a layer's arithmetic does not depend on the tile that ran it
     int out_mode;           // 0 bf16 [M][ldc], 1 fp32 [M][ldc], 2 bf16 transposed [batch][N][ldc]
     float alpha;            // result = alpha * act(acc + bias + rowbias) + residual
     int order;              // tile order inside an XCD's id range: 0 = tile_m fastest (W panel shared), 1 = tile_n fastest
@@ -131,11 +133,11 @@ int supir_gemm16_launch_n(const GemmArgs* a, int n, hipStream_t st, int tile, bo
 int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st);
 // gemm_big.hip: tile 37 = 256 x 320, activation operand global -> VGPR, GEGLU epilogue (16-row value / gate interleave)
 // measurement knobs (NOT part of the C ABI: undeclared in include/supir_hip.h, used by tools/ A/B scripts only).
-// knob 0: 1 = the exact-erf GELU in the 256 x 320 GEGLU tile's epilogue instead of the fitted one (csrc/gemm_big.hip)
+// knob 0: 1 = the exact-erf GELU in EVERY GEGLU epilogue (tiles 34 and 37) instead of the fitted one (the product default)
 // knob 1: wave arrangement of the 256 x 160 tile (csrc/gemm16.hip): 0 = product policy, 1 = always 4 x 2, 2 = always 8 x 1
 // knob 2: GroupNorm apply with n row batches per workgroup instead of ~32 KB per workgroup (measured: no gain; csrc/norm.hip)
 // knob 3: flash attention d64: 0 = product policy, 1 = the round-3 kernel, 2 = always eight waves, 3 = always four waves (round-4 form)
-// knob 4: fused q|k|v tile: 0 = product policy, 1 = 256 x 160, 2 = 256 x 128, 3 = 256 x 160 on the eight-phase schedule
+// knob 4: fused q|k|v tile: 0 = product policy, 1 = 256 x 160, 2 = 256 x 128
 // knob 5: xattn_q workgroup order: 0 = 2-D XCD grid (product), 1 = 1-D ranges with the heads fastest (round 4)
 int supir_debug_knob_value(int which);
 bool supir_gemm_big_supported(const GemmArgs& a);

@@ -78,7 +78,7 @@ def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1, group=1):
         return f"gemm_bf16_kernel<{name},conv,split9>+finalize"
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv",
-              38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2", 41: "256,128,1k,s3,qkv", 42: "256,256,1k,8ph", 43: "256,160,1k,8ph", 44: "256,320,1k,8ph"}[tile]
+              38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2", 41: "256,128,1k,s3,qkv", 42: "256,256,1k,8ph"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}{g}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
@@ -155,7 +155,7 @@ def _packaged_tune_applies():
     """The packaged picks were timed on gfx950: on any other device (or an unknown one) every shape is tuned on first sight."""
     try:
         if torch.cuda.is_available():
-            return str(getattr(torch.cuda.get_device_properties(0), "gcnArchName", "")).startswith("gfx950")
+            return str(getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")).startswith("gfx950")
     except Exception:
         return False
     return True     # no device in this process (CPU tier): nothing is launched, the entries are inert
@@ -172,8 +172,29 @@ def load_tuning(path):
     return len(data.get("tune", [])) + len(data.get("choice", []))
 
 
-if _TUNE_FILE and _TUNE_FILE.lower() != "none" and _os.path.exists(_TUNE_FILE) and (_TUNE_FILE != _TUNE_DEFAULT or _packaged_tune_applies()):
+# The file is read at import (plain file I/O).  Whether the PACKAGED picks apply to this device is decided at the first autotune
+# lookup, not here: asking the device for its architecture is a HIP call, and a HIP call as an import side effect breaks fork-based
+# multiprocessing ("Cannot re-initialize CUDA in forked subprocess") and defeats environment settings that must precede the first HIP
+# call of the process.  On a device the picks were not timed for, the packaged entries are dropped then and every shape is tuned.
+_PACKAGED = (set(), set())
+_ARCH_CHECKED = False
+if _TUNE_FILE and _TUNE_FILE.lower() != "none" and _os.path.exists(_TUNE_FILE):
+    _before = (set(_TUNE), set(_CHOICE))
     load_tuning(_TUNE_FILE)
+    if _TUNE_FILE == _TUNE_DEFAULT:
+        _PACKAGED = (set(_TUNE) - _before[0], set(_CHOICE) - _before[1])
+
+
+def _check_packaged_tune():
+    global _ARCH_CHECKED
+    if _ARCH_CHECKED:
+        return
+    _ARCH_CHECKED = True
+    if (_PACKAGED[0] or _PACKAGED[1]) and not _packaged_tune_applies():
+        for k in _PACKAGED[0]:
+            _TUNE.pop(k, None)
+        for k in _PACKAGED[1]:
+            _CHOICE.pop(k, None)
 
 
 def save_tuning(path=None):
@@ -217,6 +238,7 @@ def _time_options(options, run, repeat=None):
 
 
 def _autotune(key, candidates, launch):
+    _check_packaged_tune()
     best = _TUNE.get(key)
     if best is not None:
         return best
@@ -388,9 +410,14 @@ class _Launch:
         self.w, self.part, self.trace, self.keep, self.out, self.inplace = w, part, trace, keep, out, inplace
 
 
-def _run_single(L):
-    # per-launch requests travel WITH the launch (supir_launch_hints of the *_ex entry points): no thread-local state in the library
-    nxt = _pf(L.w) if L.w is not None else None
+_NO_PF = object()
+
+
+def _run_single(L, nxt=_NO_PF):
+    # per-launch requests travel WITH the launch (supir_launch_hints of the *_ex entry points): no thread-local state in the library.
+    # nxt: a prefetch hint the caller already drew from the WeightPrefetch plan for this launch (the pair fallback below)
+    if nxt is _NO_PF:
+        nxt = _pf(L.w) if L.w is not None else None
     hints = None
     if nxt is not None or L.part is not None:
         hints = _lib.LaunchHints(next_weight=nxt[0] if nxt else None, next_weight_bytes=nxt[1] if nxt else 0,
@@ -547,9 +574,14 @@ def _run_pair(a, b, tile):
     rc = _group_call(a, b, tile, prefetch=pfs)
     if rc in (-1, -2):
         # SUPIR_ERR_ARG / SUPIR_ERR_SHAPE: the C side refuses a pairing the Python key could not tell apart (a cached winner for a
-        # key that under-describes the problems): nothing was launched -- run the two problems one by one
-        _run_single(a)
-        _run_single(b)
+        # key that under-describes the problems): nothing was launched -- run the two problems one by one, WITH the prefetch hints
+        # already drawn for them (drawing again would advance the record / replay cursor twice and shift every later hint of the
+        # pass), and do not retry the pairing on later steps
+        _run_single(a, pfs[0])
+        _run_single(b, pfs[1])
+        pkey = getattr(a, "pkey", None)
+        if pkey is not None:
+            _TUNE[pkey] = -2
         return
     _lib.check(rc, {"attn": "supir_flash_attn_d64_grouped", "gn": "supir_groupnorm_grouped"}.get(a.kind, "supir_gemm_grouped"), a.lib)
     if a.trace is not None:
@@ -638,7 +670,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
         rows_per_batch = M   # one batch: the partials' row-chunk index is computed from it (never 0 in the kernel)
 
     def wb(t):
-        return (alt16[0], alt16[1]) if (t in (34, 37, 44) and act == 2 and alt16 is not None) else (w, bias)
+        return (alt16[0], alt16[1]) if (t in (34, 37) and act == 2 and alt16 is not None) else (w, bias)
 
     def launch(t, outp=None, hints=None):
         wq, bq = wb(t)
@@ -691,18 +723,17 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
 
 _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
-               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2), 38: (80, 1), 39: (128, 2), 40: (256, 2), 42: (256, 4), 43: (160, 2), 44: (320, 2)}
-G16_TILES = {32, 33, 34, 35, 39, 40, 42, 44}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
+               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2), 38: (80, 1), 39: (128, 2), 40: (256, 2), 42: (256, 4)}
+G16_TILES = {32, 33, 34, 35, 39, 40, 42}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
 # tile: (BM, BN, K groups, ring).  38 = 128 x 80 with FOUR waves and a 78 KB ring (two workgroups per CU): known to the mirror, enabled
 # by adding it to G16_TILES (tools/step_ab4.py); not in the default lists -- see DESIGN.md section 3 for what it measured
 # 39 / 40 = 256 x 128 and 256 x 256 (round 4): the VAE's 128 / 256 / 512-channel layers; ordinary epilogue only, and offered only where no
 # 80-column tile fits (N % 80 != 0), so the candidate lists -- and with them the picks -- of the UNet's shapes are what they were
 _G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3), 38: (128, 80, 1, 3),
-        39: (256, 128, 1, 3), 40: (256, 256, 1, 2), 42: (256, 256, 1, 3), 43: (256, 160, 1, 3), 44: (256, 320, 1, 3)}
-# 42 / 43 / 44 = 256 x 256 / 256 x 160 / 256 x 320 on the eight-phase ping-pong schedule (round 5; ring column = 3: they need at least
-# two K-tiles).  42 / 43: ordinary epilogue only (no transposed output, no GEGLU); 44: the GEGLU projections only (16-row interleave, as 34).
-# 43 is known to the mirror but NOT in G16_TILES: it measured 5-10 % slower than tile 34 on every shape (profiles/r05/experiment_*)
-_G16_NO_TRANS = (39, 40, 42, 43)
+        39: (256, 128, 1, 3), 40: (256, 256, 1, 2), 42: (256, 256, 1, 3)}
+# 42 = 256 x 256 on the eight-phase ping-pong schedule (round 5; ring column = 3: it needs at least two K-tiles); ordinary epilogue only.
+# (The same schedule as 256 x 160 and as a 256 x 320 GEGLU tile measured slower than / equal to tiles 34 / 37: not built.)
+_G16_NO_TRANS = (39, 40, 42)
 _G16_PLAIN_ONLY = (39, 40, 42)
 USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc/gemm16.hip) in the autotune lists
 USE_GEMM_BIG = _os.environ.get("SUPIR_GEMM_BIG", "1") != "0"   # tile 37 (csrc/gemm_big.hip) in the GEGLU autotune lists
@@ -724,9 +755,7 @@ def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu1
             continue
         if M % bm or N % bn or K % (64 * ks) or (K // 64) // ks < s - 1:
             continue
-        if act == 2 and not (t in (34, 44) and geglu16):
-            continue
-        if t == 44 and act != 2:
+        if act == 2 and not (t == 34 and geglu16):
             continue
         if t in _G16_PLAIN_ONLY and (om != 0 or N % 80 == 0):
             continue
@@ -806,7 +835,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
         assert colsum is not None and colsum.numel() == N
 
     def wcb(t):
-        return alt16 if (t in (34, 37, 44) and act == 2 and alt16 is not None) else (w, colsum, bias)
+        return alt16 if (t in (34, 37) and act == 2 and alt16 is not None) else (w, colsum, bias)
 
     def launch(t, outp=None, hints=None):
         wq, cq, bq = wcb(t)
@@ -924,6 +953,7 @@ def choose(key, fns, prefer=None, margin=0.1):
     timing here is back-to-back and hot, where a launch costs ~2 us; inside a step every launch also meets its weights cold
     (+4..6 us), so near-ties go to the shorter sequence (fused q|k|v at (2048, 3840, 1280): a tie here, -0.7 ms per step there,
     profiles/r02/step_ab_fused_qkv.log, profiles/r03/step_variants_*.log)."""
+    _check_packaged_tune()
     c = _CHOICE.get(key)
     if c is not None:
         return c
@@ -1051,7 +1081,7 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
                 and (residual is None or ldr % 4 == 0) and (rowbias is None or ld_rb % 4 == 0):
             for t, (bm, bn, ks, s_) in _G16.items():   # same predicate as supir_gemm16_supported(conv)
                 if t in G16_TILES and M_ % bm == 0 and Cout % bn == 0 and Cin % (64 * ks) == 0 and (9 * Cin // 64) // ks >= s_ - 1 \
-                        and not (t in _G16_PLAIN_ONLY and Cout % 80 == 0) and not (t in (42, 43) and (OH * OW) % 256):
+                        and not (t in _G16_PLAIN_ONLY and Cout % 80 == 0) and not (t == 42 and (OH * OW) % 256):
                     cands.append(t)
         # tap-split candidates for convolutions whose tile grid is a fraction of the machine: one workgroup set per filter tap
         if USE_CONV_SPLIT and om == 0 and act in (0, 1) and residual is None and rowbias is None and alpha == 1.0 and Cin % 64 == 0 \

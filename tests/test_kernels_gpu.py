@@ -486,16 +486,16 @@ G16_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (8192,
               (384, 320, 256)]
 
 
-_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 38: (128, 80), 43: (256, 160)}   # 38: four waves, one K group (round 4)
+_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 38: (128, 80)}   # 38: four waves, one K group (round 4)
 
 
 @pytest.mark.parametrize("M,N,K", G16_SHAPES)
-@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38, 43])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
 def test_gemm16_plain_and_epilogues(M, N, K, tile):
     """128 x 80 / 128 x 160 / 256 x 160 tiles (v_mfma_f32_16x16x32_bf16; two K groups per workgroup or eight waves on a 3-deep
     ring): plain, residual + alpha, row bias + SiLU, strided operands, run-to-run bitwise equality."""
     bm, bn = _G16_TILE[tile]
-    if N % bn or M % bm or (tile == 35 and K < 256) or (tile in (38, 43) and K < 128):
+    if N % bn or M % bm or (tile == 35 and K < 256) or (tile == 38 and K < 128):
         pytest.skip("tile needs M % BM == 0, N % BN == 0 and at least ring-depth - 1 K steps per K group")
     a = rnd(M, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
@@ -504,9 +504,6 @@ def test_gemm16_plain_and_epilogues(M, N, K, tile):
     out = ops.gemm(a, w, bias, tile=tile)
     check(out, base, name=f"gemm16{(M, N, K)} tile{tile}")
     assert torch.equal(out, ops.gemm(a, w, bias, tile=tile))
-    if tile == 43:      # the eight-phase 256 x 160 form accumulates in tile 34's K order: bitwise, on every repetition (a racy LDS hand-off
-        for _ in range(3):                                                             # would differ from run to run)
-            assert torch.equal(ops.gemm(a, w, bias, tile=43), ops.gemm(a, w, bias, tile=34))
     check(ops.gemm(a, w, None, tile=tile), a.float() @ w.float().T, name="no bias")
     res = rnd(M, N, seed=3).to(BF)
     check(ops.gemm(a, w, bias, residual=res, alpha=0.5, tile=tile), 0.5 * base + res.float(), name="res+alpha")
@@ -657,40 +654,6 @@ def test_gemm_big_geglu(M, K, N2):
         ops.gemm(a[: M - 64], w16, b16, act=2, tile=37)
 
 
-@pytest.mark.parametrize("M,K,N2", [(2048, 1280, 10240), (8192, 640, 5120), (256, 128, 640), (512, 320, 1280)])
-def test_gemm16_geglu_on_the_eight_phase_256x320_tile(M, K, N2):
-    """Tile 44 (round 5): the GEGLU projections (sgm/modules/attention.py:84-91) on a 256 x 320 tile with the eight-phase ping-pong
-    schedule of csrc/gemm16.hip -- same 16-row value / gate interleave, same epilogue and same K order as tile 34: bitwise tile 34, with
-    and without the LayerNorm fold; the reference formula; shapes it does not fit are refused."""
-    from supir_amd.weights import fold_layernorm, interleave_geglu
-    a = rnd(M, K).to(BF)
-    w = rnd(N2, K, scale=K ** -0.5, seed=1).to(BF)
-    bias = rnd(N2, seed=2)
-    w16, b16 = interleave_geglu(w, bias, 16)
-    out = ops.gemm(a, w16, b16, act=2, tile=44)
-    v, g = (a.float() @ w.float().T + bias).chunk(2, dim=-1)
-    check(out, v * F.gelu(g), name="geglu 8-phase")
-    for _ in range(3):
-        assert torch.equal(ops.gemm(a, w16, b16, act=2, tile=44), ops.gemm(a, w16, b16, act=2, tile=34))
-    C = K
-    wp = rnd(C, C, scale=C ** -0.5, seed=5).to(BF)
-    x, st = ops.gemm_ln(a, wp, None, emit_stats=True)
-    gamma, beta = rnd(C, seed=6) * 0.2 + 1.0, rnd(C, seed=7) * 0.2
-    wf, cs, bf_ = fold_layernorm(w.float(), bias, gamma, beta)
-    wf16, bf16_ = interleave_geglu(wf, bf_, 16)
-    _, cs16 = interleave_geglu(wf, cs, 16)
-    o44 = ops.gemm_ln(x, wf16, bf16_, act=2, ln=st, colsum=cs16, tile=44)
-    assert torch.equal(o44, ops.gemm_ln(x, wf16, bf16_, act=2, ln=st, colsum=cs16, tile=34))
-    yr = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T + bias
-    vr, gr = yr.chunk(2, dim=-1)
-    check(o44, vr * F.gelu(gr), rel=8e-3, name="geglu 8-phase ln-fold")
-    from supir_amd._lib import SupirHipError
-    with pytest.raises(SupirHipError):
-        ops.gemm(a[: M - 64], w16, b16, act=2, tile=44)
-    with pytest.raises(SupirHipError):
-        ops.gemm(a, w, bias, tile=44)          # GEGLU only
-
-
 def _unit_sums(y, B, rows_per_batch, bm):
     """(sum, sum of squares) per (batch, tile row of bm rows, 10-channel unit) of a bf16 [B * rows, C] tensor, in fp64."""
     C = y.shape[-1]
@@ -773,12 +736,12 @@ G16_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", G16_CONV_CASES)
-@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38, 43])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
 def test_gemm16_conv3x3(case, tile):
     """Implicit-GEMM 3x3 convolution on the 16x16x32 tiles: plain, and with bias + time-embedding row bias + SiLU + residual."""
     B, H, W, Cin, Cout, stride, pad, up, out_hw = case
     bm, bn = _G16_TILE[tile]
-    ks = 1 if tile in (34, 38, 43) else 2
+    ks = 1 if tile in (34, 38) else 2
     x = rnd(B, H, W, Cin).to(BF)
     w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
     bias = rnd(Cout, seed=2)
@@ -792,16 +755,12 @@ def test_gemm16_conv3x3(case, tile):
     else:
         ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=1)
     OH, OW = ref.shape[2:]
-    if (B * OH * OW) % bm or Cout % bn or Cin % (64 * ks) or (tile == 43 and (OH * OW) % 256):
+    if (B * OH * OW) % bm or Cout % bn or Cin % (64 * ks):
         pytest.skip("not an exact fit for this tile")
     ref = ref.permute(0, 2, 3, 1)
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile)
     check(out, ref, name=f"conv16 {case} tile{tile}")
     assert torch.equal(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile))
-    if tile == 43:
-        for _ in range(3):
-            assert torch.equal(ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=43),
-                               ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=34))
     rb = rnd(B, Cout, seed=4).to(BF)
     res = rnd(B, OH, OW, Cout, seed=5).to(BF)
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, rowbias=rb, residual=res, act=1, alpha=0.5,
@@ -947,7 +906,7 @@ def test_gemm_qkv_fused(B, T, C):
         from supir_amd import _lib
         lib, got = _lib.load(BF), []
         try:
-            for width in (1, 2, 3, 3, 3):   # 3: the 256 x 160 tile on the eight-phase schedule (round 5; the default from M = 8192 on), repeated
+            for width in (1, 2):
                 lib.supir_debug_knob(4, width)
                 got.append(ops.gemm_qkv(x, wf, bf_, B, T, 2 * inner, ln=st, colsum=cs))
         finally:
