@@ -89,7 +89,8 @@ typedef struct supir_launch_hints {
  * 32..35: the exact-fit tiles of csrc/gemm16.hip (128x80, 128x160, 256x160, 128x80 with 3-deep rings); 37: the 256x320 GEGLU tile of
  * csrc/gemm_big.hip (act = GEGLU, W rows interleaved [16 value | 16 gate], M % 256 == 0, N % 320 == 0); 38: 128x80 with FOUR waves
  * and 78 KB of LDS (two workgroups per CU; round 4); 39 / 40: 256x128 and 256x256 of csrc/gemm16.hip (M % 256 == 0, N % 128 / 256 == 0,
- * ordinary epilogue only: the VAE's 128 / 256 / 512-channel layers).  Forced tiles that do not fit the shape return SUPIR_ERR_SHAPE. */
+ * ordinary epilogue only: the VAE's 128 / 256 / 512-channel layers); 42: 256x256 on the eight-phase ping-pong schedule (round 5: K >= 128,
+ * convolutions additionally OH * OW % 256 == 0; bitwise the results of tile 40).  Forced tiles that do not fit the shape return SUPIR_ERR_SHAPE. */
 int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream);
@@ -348,7 +349,7 @@ int supir_splitk_finalize(const float* partials, int ksplit, int M, int N, const
 /* ---- Grouped launches: n (1 or 2) independent problems of identical shape in ONE kernel launch ------------------------------------
  * EXPERIMENTAL (round 3; declared only under -DSUPIR_EXPERIMENTAL, exported by the library either way): correct and tested (bitwise equal to the single launches, tests/test_grouped_gpu.py), but NOT used by the
  * product's default path -- on the 1024^2 step two free-running chains of single launches measured faster than grouped launches
- * (every grouped launch is a join of the two chains: DESIGN.md section 3).  The entry points and struct layouts may change.
+ * (every grouped launch is a join of the two chains: docs/roundlog.md section 3).  The entry points and struct layouts may change.
  * SUPIR runs two networks of identical architecture on independent data inside every sampling step: GLVControl (the control
  * branch, SUPIR/modules/SUPIR_v0.py:499-540) and the encoder half of LightGLVUNet (:600-625) -- the same ResBlock /
  * SpatialTransformer stack, layer for layer the same shapes, different weights and inputs.  With the CFG-doubled batch of one

@@ -36,26 +36,31 @@ def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), pay
     and an fp16 compute scope loses the three mantissa bits it would have kept.  Not used by bench.py."""
     if not collectives_active():
         return 0
-    # floating tensors travel in dtype buckets; the few integer buffers (none on SUPIR's path today) would travel one by one below
+    # floating tensors travel in dtype buckets; the few integer buffers (none on SUPIR's path today) would travel one by one.  Bucket
+    # composition depends on names, shapes and dtypes only -- never on where a rank happens to keep a tensor (rank 0 builds the
+    # denoiser's sigma table on the HOST, a meta-constructed replica has it on the device): every payload is staged on ONE
+    # communication device (RCCL moves device memory only) and copied back to wherever the rank keeps the tensor
+    comm = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     state = {k: t for k, t in module.state_dict().items() if not any(k.endswith(s) for s in skip)}
-    tensors = [t for t in state.values() if t.is_floating_point()]
     for t in state.values():
         if not t.is_floating_point():
-            dist.broadcast(t, src=src)
-    groups = {}
-    for t in tensors:
-        groups.setdefault((t.dtype, t.device), []).append(t)
+            w = t.to(comm)
+            dist.broadcast(w, src=src)
+            if w is not t:
+                with torch.no_grad():
+                    t.copy_(w)
     sent = 0
     split = {}
-    for (dt, dev), ts in groups.items():
-        for t in ts:
-            rounded = payload_dtype is not None and dt == torch.float32 and t.dim() >= 2 and t.numel() >= round_min_elems
-            split.setdefault((dt, dev, payload_dtype if rounded else dt), []).append(t)
-    for (dt, _, wire), ts in split.items():
+    for t in state.values():
+        if not t.is_floating_point():
+            continue
+        rounded = payload_dtype is not None and t.dtype == torch.float32 and t.dim() >= 2 and t.numel() >= round_min_elems
+        split.setdefault((t.dtype, payload_dtype if rounded else t.dtype), []).append(t)
+    for (dt, wire_dt), ts in split.items():
         bucket, size = [], 0
         for t in ts + [None]:
             if t is None or (bucket and size + t.numel() > bucket_elems):
-                flat = torch.cat([b.reshape(-1).to(wire) for b in bucket])
+                flat = torch.cat([b.reshape(-1).to(device=comm, dtype=wire_dt) for b in bucket])
                 dist.broadcast(flat, src=src)
                 o = 0
                 with torch.no_grad():

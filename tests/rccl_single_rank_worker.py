@@ -81,6 +81,34 @@ def main():
     res["sync_autotune_changed"] = parallel.sync_autotune()
     res["sync_autotune_identity"] = (dict(ops._TUNE), dict(ops._CHOICE)) == tune_before
     res["max_over_ranks"] = parallel.max_over_ranks(1.25, device=dev)
+    # replica start-up as bench.py does it for N > 1 (round 5): a module constructed on META + to_empty, every parameter AND buffer
+    # received; here the "received" values are copied from the materialised model (a one-rank group has no second rank), then a
+    # receive-everything broadcast runs through RCCL on it with one buffer kept on the HOST (rank 0 of the real job builds the denoiser's
+    # sigma table there: RCCL cannot move host memory, the payload is staged on the device).  The replica must compute the same bits.
+    from tests.helpers import SUPIR_NET
+    from supir_amd.modules.supir_v0 import GLVControl, LightGLVUNet
+    from supir_amd.modules.wrappers import ControlWrapper
+
+    def factory():
+        net = dict(SUPIR_NET, transformer_depth=[1, 1, 2])
+        ctl = {k: v for k, v in net.items() if k not in ("mode", "project_type", "project_channel_scale")}
+        w2 = ControlWrapper(LightGLVUNet(**net), dtype=torch.bfloat16)
+        w2.load_control_model(GLVControl(**ctl, input_upscale=1))
+        return w2
+
+    rep = parallel.construct_replica(factory, dev, materialize=False)
+    res["replica_on_device"] = all(v.is_cuda for v in rep.state_dict().values())
+    with torch.no_grad():
+        src_sd = wrap.state_dict()
+        for k, v in rep.state_dict().items():
+            v.copy_(src_sd[k])
+    den_host = DiscreteDenoiserWithControl()                      # its sigma table lives on the host
+    sig_before = den_host.sigmas.clone()
+    res["host_buffer_buckets"] = parallel.broadcast_module_(den_host, src=0, skip=()) + parallel.broadcast_module_(rep, src=0, skip=(), bucket_elems=1 << 26)
+    res["host_buffer_identity"] = bool((not den_host.sigmas.is_cuda) and torch.equal(den_host.sigmas, sig_before))
+    with torch.no_grad():
+        res["replica_equal"] = bool(torch.equal(rep(x, t, cond, 1.0), eager))
+    del rep
     # hipGraph capture + replay with the NCCL watchdog alive
     with torch.no_grad():
         e2 = wrap(x, t, cond, 1.0).clone()

@@ -28,3 +28,5 @@ def test_collectives_and_graph_capture_under_a_one_rank_nccl_group():
     assert r["sync_autotune_changed"] == 0 and r["sync_autotune_identity"] and r["max_over_ranks"] == 1.25
     assert r["eager_equal_after_broadcast"] and r["graph_equal_eager"]
     assert r["tile_parallel_sampler_equal"] and r["tile_parallel_vae_equal"]
+    # round 5: a meta-constructed replica that received its state computes the same bits; a host-resident buffer survives the broadcast
+    assert r["replica_on_device"] and r["replica_equal"] and r["host_buffer_buckets"] >= 2 and r["host_buffer_identity"]
