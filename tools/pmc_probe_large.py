@@ -28,7 +28,7 @@ def want(tile):
 
 
 # VAE convolutions (sgm/modules/diffusionmodules/model.py:55-148 at 1024^2): Cin -> Cout at H x W
-for (H, Cin, Cout, tiles) in [(256, 512, 512, (40, 39, 41)), (512, 256, 256, (40, 39, 41)), (512, 256, 128, (39,)), (1024, 128, 128, (39,))]:
+for (H, Cin, Cout, tiles) in [(256, 512, 512, (40, 39, 42)), (512, 256, 256, (40, 39, 42)), (512, 256, 128, (39,)), (1024, 128, 128, (39,))]:
     x = torch.randn(1, H, H, Cin, device=dev).to(BF)
     w = (torch.randn(Cout, 3, 3, Cin, device=dev) * (9 * Cin) ** -0.5).to(BF)
     for tile in tiles:

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from supir_amd.ops import gemm_tile_name  # noqa: E402
 
 cases, summ, out_path, note = json.load(open(sys.argv[1])), json.load(open(sys.argv[2])), sys.argv[3], sys.argv[4]
-G16 = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320)}
+G16 = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320), 39: (256, 128), 40: (256, 256), 42: (256, 256)}
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 out["note"] = note
 
@@ -40,7 +40,8 @@ for c in cases:
             M, N = (int(t[1:]) for t in shape.split()[:2])
         bm, bn = G16[tile]
         grid = (M // bm) * (N // bn) * 512
-        targs = {32: "128, 80, 4, 1, 2, 2", 33: "128, 160, 2, 2, 2, 2", 34: "256, 160, 8, 1, 1, 3", 35: "128, 80, 4, 1, 2, 3"}
+        targs = {32: "128, 80, 4, 1, 2, 2", 33: "128, 160, 2, 2, 2, 2", 34: "256, 160, 8, 1, 1, 3", 35: "128, 80, 4, 1, 2, 3",
+                 39: "256, 128, 4, 2, 1, 3", 40: "256, 256, 4, 2, 1, 2", 42: "256, 256, 2, 4, 1, 8"}
         if tile == 34 and (kind == "conv3x3" or (kind == "gemm" and M >= 8192)):
             targs[34] = "256, 160, 4, 2, 1, 3"     # round 4: the eight waves as 4 x 2 for convolutions and M >= 8192
         e = find("geglu_big_kernel", grid) if tile == 37 else \
@@ -77,6 +78,16 @@ for c in cases:
         rec["mfma_busy_frac"] = round(e["mfma_busy_over_sq_busy"] / 32.0, 3)
     if e.get("SQ_LDS_IDX_ACTIVE"):
         rec["lds_bank_conflict_over_idx_active"] = round(e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"], 3)
+    if e.get("SQ_WAVE_CYCLES"):      # shares of the resident wave-cycles (SQ_WAVE_CYCLES counts quad-cycles, like the SQ_WAIT_* / SQ_ACTIVE_* counters)
+        for cname, key in (("SQ_WAIT_ANY", "wait_any_over_wave_cycles"), ("SQ_WAIT_INST_ANY", "wait_inst_any_over_wave_cycles"),
+                           ("SQ_ACTIVE_INST_ANY", "active_inst_any_over_wave_cycles"), ("SQ_WAIT_INST_LDS", "wait_inst_lds_over_wave_cycles")):
+            if cname in e:
+                rec[key] = round(e[cname] / e["SQ_WAVE_CYCLES"], 3)
+    if e.get("GRBM_GUI_ACTIVE") and e.get("profiled_launch_us"):
+        # GRBM_GUI_ACTIVE = cycles the graphics engine was busy during the dispatch: / its duration = the effective shader clock under this
+        # kernel's load (MI355X_MICROARCH.md, DVFS give-back); summed over the 8 XCDs' instances by rocprofv3 -> / 8
+        rec["effective_clock_ghz"] = round(e["GRBM_GUI_ACTIVE"] / 8.0 / e["profiled_launch_us"] / 1e3, 3)
+        rec["profiled_launch_us"] = round(e["profiled_launch_us"], 1)
     lst = [x for x in out.get(name, []) if isinstance(x, dict) and x.get("shape") != rec["shape"]] if isinstance(out.get(name), list) else []
     out[name] = lst + [rec]
 # GroupNorm apply kernel: conflict ratio per grid (no traffic model needed: read + write once)
