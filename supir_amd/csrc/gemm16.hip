@@ -274,7 +274,21 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     //        one interval later, i.e. before the barrier that ends interval 8u + 7, and the first read of K-tile u + 1 is in interval 8u + 8.
     // Every wave issues the same number of loads per half-tile (a W part with fewer than 16 chunks: the second instruction of the waves
     // beyond it re-loads their first chunk), so one count is right for all of them.
-    int ph8_kw0 = 64, ph8_kw1 = 0, ph8_ka = 0;   // K offsets (elements) of the next WA / WB / A half-tiles to stage
+    int ph8_wt0 = 1, ph8_wt1 = 0, ph8_ka = 0;    // K-tile indices of the next WA / WB half-tiles to stage; K offset (elements) of the next A half-tiles
+    // K-tile index -> K offset of the weight rows.  Convolutions, korder = 1 (round 5): the K loop runs (64-channel chunk, tap) instead
+    // of (tap, chunk) -- the nine taps of one channel chunk back to back.  A tile's nine taps read three input rows shifted by a pixel:
+    // tap-major, 32 workgroups of an XCD stream 32 x 262 KB through a 4 MB L2 between two taps of the same row and every tap re-fetches
+    // it (512 -> 512 @ 256^2: 607 MB fetched for 139 MB of operands, profiles/pmc_traffic.json); chunk-major, a workgroup's nine taps
+    // touch 3 rows x 258 px x 128 B = 99 KB, 3.2 MB per XCD
+    auto ph8_koff = [&](int t) {
+        if constexpr (CONV) {
+            if (p.korder) {
+                const int ch = t / 9, tap = t - ch * 9;
+                return tap * p.Cin + ch * 64;
+            }
+        }
+        return t * 64;
+    };
     // addresses as (wave-uniform 64-bit base) + (per-lane 32-bit byte offset, constant over the loop): the loads take the scalar-base form
     // and the loop keeps ONE offset register per operand instead of a strength-reduced 64-bit pointer per load (10 loads = 20 VGPRs on
     // the 256 x 320 tile, which spilled)
@@ -302,11 +316,22 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     };
     auto ph8_adv_a = [&]() {
         if constexpr (CONV) {
-            c_cin0 += 64;
-            if (c_cin0 >= p.Cin) {
-                c_cin0 -= p.Cin;
-                if (++c_kx == 3) { c_kx = 0; ++c_ky; }
+            if (p.korder) {          // next tap of the same channel chunk; after the ninth, the next chunk
+                if (++c_kx == 3) {
+                    c_kx = 0;
+                    if (++c_ky == 3) {
+                        c_ky = 0;
+                        c_cin0 += 64;
+                    }
+                }
                 conv_set_tap();
+            } else {
+                c_cin0 += 64;
+                if (c_cin0 >= p.Cin) {
+                    c_cin0 -= p.Cin;
+                    if (++c_kx == 3) { c_kx = 0; ++c_ky; }
+                    conv_set_tap();
+                }
             }
         } else {
             ph8_ka += 64;
@@ -336,10 +361,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         ph8_stage_a(0, 1);
         ph8_adv_a();
         ph8_stage_a(1, 0);
-        ph8_stage_w(1, PI1{}, 64);
+        ph8_stage_w(1, PI1{}, ph8_koff(1));
         ph8_stage_a(1, 1);
         ph8_adv_a();
-        ph8_kw1 = 128;
+        ph8_wt1 = 2;
     } else {
 #pragma unroll
         for (int s = 0; s < S - 1; ++s) {
@@ -541,7 +566,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             // phase 0
             read_w(PI0{});
             read_a(0);
-            if constexpr (SW0) ph8_stage_w(cur ^ 1, PI0{}, ph8_kw0);
+            if constexpr (SW0) ph8_stage_w(cur ^ 1, PI0{}, ph8_koff(ph8_wt0));
             mid();
             mma(PI0{}, PI0{});
             // phase 1
@@ -551,7 +576,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             mma(PI0{}, PI1{});
             // phase 2
             read_a(1);
-            if constexpr (SA) ph8_stage_w(cur, PI1{}, ph8_kw1);
+            if constexpr (SA) ph8_stage_w(cur, PI1{}, ph8_koff(ph8_wt1));
             mid();
             mma(PI1{}, PI1{});
             // phase 3
@@ -563,8 +588,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             if constexpr (WAITN >= 0) g16_wait_vmcnt<WAITN>();
             mid();
             mma(PI1{}, PI0{});
-            ph8_kw0 += 64;
-            ph8_kw1 += 64;
+            ++ph8_wt0;
+            ++ph8_wt1;
             cur ^= 1;
         };
         g16_wait_vmcnt<PH_INFLIGHT>();
@@ -936,6 +961,7 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     for (int q = 0; q < NP; ++q) {
         pp.p[q] = a_in[q];
         pp.p[q].fast_gelu = supir_debug_knob_value(0) ? 0 : 1;   // one switch for every GEGLU epilogue (tile 37 reads the same knob)
+        pp.p[q].korder = (CONV && S == 8 && supir_debug_knob_value(6) != 1) ? 1 : 0;   // tile 42 convolutions: chunk-major K order (knob 6 = 1: tap-major)
     }
     GemmArgs& a = pp.p[0];
     const int tiles = (a.M / BM) * (a.N / BN);

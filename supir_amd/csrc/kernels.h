@@ -14,6 +14,7 @@ struct GemmArgs {
     int rows_per_batch;     // rows (tokens) per batch element
     int H, W, Cin, OH, OW, stride, pad_t, pad_l, up;  // conv geometry (virtual input = 2H x 2W when up)
     int act;                // 0 none, 1 SiLU, 2 GEGLU (value/gate interleaved per 32 columns)
+    int korder;             // convolutions on the eight-phase tile: 1 = K loop as (channel chunk, tap), 0 = (tap, channel chunk) (set by the launcher)
     int fast_gelu;          // GEGLU epilogues: 1 = the fitted GELU (gelu_fast_f, |error| <= 2.5e-5), 0 = erf; set by the launchers from ONE
                             // switch for every GEGLU tile (supir_debug_knob 0), so a layer's arithmetic does not depend on the tile that ran it
     int out_mode;           // 0 bf16 [M][ldc], 1 fp32 [M][ldc], 2 bf16 transposed [batch][N][ldc]
@@ -138,6 +139,7 @@ int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st);
 // knob 2: GroupNorm apply with n row batches per workgroup instead of ~32 KB per workgroup (measured: no gain; csrc/norm.hip)
 // knob 3: flash attention d64: 0 = product policy, 1 = the round-3 kernel, 2 = always eight waves, 3 = always four waves (round-4 form)
 // knob 4: fused q|k|v tile: 0 = product policy, 1 = 256 x 160, 2 = 256 x 128
+// knob 6: K order of tile 42's convolutions: 0 = (channel chunk, tap) (product), 1 = (tap, channel chunk) as every other tile
 // knob 5: xattn_q workgroup order: 0 = 2-D XCD grid (product), 1 = 1-D ranges with the heads fastest (round 4)
 int supir_debug_knob_value(int which);
 bool supir_gemm_big_supported(const GemmArgs& a);

@@ -37,9 +37,8 @@ def ab(fns, iters):
 
 
 rows = []
-CONVS = [(1, 256, 256, 512, 512, False), (1, 512, 512, 256, 256, False), (1, 256, 256, 256, 256, True),
-         (8, 32, 32, 1280, 1280, False), (8, 64, 64, 640, 640, False), (8, 128, 128, 320, 320, False), (2, 128, 128, 320, 320, False),
-         (2, 64, 64, 640, 640, False)]
+CONVS = [(1, 256, 256, 512, 512, False), (1, 128, 128, 512, 512, True), (1, 512, 512, 256, 256, False), (1, 256, 256, 256, 256, True),
+         (1, 256, 256, 256, 512, False), (1, 256, 256, 512, 256, False), (1, 512, 512, 128, 256, False)]
 for (B, H, W, Cin, Cout, up) in CONVS:
     x = torch.randn(B, H, W, Cin, device=dev).to(BF)
     w = (torch.randn(Cout, 3, 3, Cin, device=dev) * (9 * Cin) ** -0.5).to(BF)
@@ -47,29 +46,41 @@ for (B, H, W, Cin, Cout, up) in CONVS:
     OH, OW = (2 * H, 2 * W) if up else (H, W)
     M = B * OH * OW
     fl = 2.0 * M * Cout * 9 * Cin
-    tiles = [t for t in (40, 42, 39, 34, 43, 5) if not (t in (40, 42) and Cout % 256) and not (t == 39 and Cout % 128) and not (t in (34, 43) and Cout % 160)
+    tiles = [t for t in (40, 42, 39, 5) if not (t in (40, 42) and Cout % 256) and not (t == 39 and Cout % 128) and not (t in (34, 43) and Cout % 160)
              and not (t in (42, 43) and (OH * OW) % 256)]
     fns = {f"tile{t}": (lambda t=t: ops.conv3x3(x, w, bias, upsample=up, tile=t)) for t in tiles}
+    if 42 in tiles:      # tile 42 with the tap-major K order of every other tile (tools knob 6 = 1) beside its chunk-major default
+        from supir_amd import _lib
+        _l = _lib.load(BF)
+
+        def tapmajor():
+            _l.supir_debug_knob(6, 1)
+            try:
+                return ops.conv3x3(x, w, bias, upsample=up, tile=42)
+            finally:
+                _l.supir_debug_knob(6, 0)
+        fns["tile42_tapmajor"] = tapmajor
     r = ab(fns, max(3, int(2000.0 / (fl / 1e9))))   # fl / 1e9 = microseconds at 1 PFLOP/s: ~2 ms of launches per round
     row = {"kind": "conv3x3", "shape": [B, H, W, Cin, Cout, int(up)], "M": M}
     for k, (med, mn) in r.items():
         row[k] = {"us_median": round(med, 1), "us_min": round(mn, 1), "tflops_median": round(fl / med / 1e6, 1)}
     if 40 in tiles and 42 in tiles:
-        row["tile42_bitwise_tile40"] = bool(torch.equal(ops.conv3x3(x, w, bias, upsample=up, tile=42), ops.conv3x3(x, w, bias, upsample=up, tile=40)))
+        row["tile42_tapmajor_bitwise_tile40"] = bool(torch.equal(fns["tile42_tapmajor"](), ops.conv3x3(x, w, bias, upsample=up, tile=40)))
+        a_, b_ = ops.conv3x3(x, w, bias, upsample=up, tile=42).float(), ops.conv3x3(x, w, bias, upsample=up, tile=40).float()
+        row["tile42_rel_l2_vs_tile40"] = float(((a_ - b_).norm() / b_.norm()).item())
     if 34 in tiles and 43 in tiles:
         row["tile43_bitwise_tile34"] = bool(torch.equal(ops.conv3x3(x, w, bias, upsample=up, tile=43), ops.conv3x3(x, w, bias, upsample=up, tile=34)))
     rows.append(row)
     print(json.dumps(row), flush=True)
     del x, w
     torch.cuda.empty_cache()
-GEMMS = [(8192, 1280, 1280), (8192, 1280, 5120), (8192, 2560, 1280), (16384, 1280, 1280), (32768, 640, 640), (32768, 640, 2560),
-         (8192, 8192, 8192), (4096, 4096, 4096), (8192, 640, 2560), (8192, 640, 640)]
+GEMMS = [(8192, 8192, 8192), (4096, 4096, 4096)]
 for (M, N, K) in GEMMS:
     a = torch.randn(M, K, device=dev).to(BF)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
     res = torch.randn(M, N, device=dev).to(BF)
     fl = 2.0 * M * N * K
-    tiles = [t for t in (40, 42, 39, 34, 43, 33, 5) if not (t in (40, 42) and N % 256) and not (t == 39 and N % 128) and not (t in (33, 34, 43) and N % 160)
+    tiles = [t for t in (40, 42, 39, 5) if not (t in (40, 42) and N % 256) and not (t == 39 and N % 128) and not (t in (33, 34, 43) and N % 160)
              and not (t == 33 and K % 128)]
     fns = {f"tile{t}": (lambda t=t: ops.gemm(a, w, None, residual=res, tile=t)) for t in tiles}
     r = ab(fns, max(3, int(2000.0 / (fl / 1e9))))
