@@ -314,24 +314,29 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             }
         }
     };
+    // Advance the A stream to the next K-tile.  Convolutions: BRANCH-FREE (scalar selects for the tap / chunk state in either K order,
+    // `&` and selects for the halo test) -- it is issued inside an MFMA segment (below), and a branch would split that segment's basic
+    // block and put all of this in front of the MFMAs instead of beside them
     auto ph8_adv_a = [&]() {
         if constexpr (CONV) {
-            if (p.korder) {          // next tap of the same channel chunk; after the ninth, the next chunk
-                if (++c_kx == 3) {
-                    c_kx = 0;
-                    if (++c_ky == 3) {
-                        c_ky = 0;
-                        c_cin0 += 64;
-                    }
-                }
-                conv_set_tap();
-            } else {
-                c_cin0 += 64;
-                if (c_cin0 >= p.Cin) {
-                    c_cin0 -= p.Cin;
-                    if (++c_kx == 3) { c_kx = 0; ++c_ky; }
-                    conv_set_tap();
-                }
+            const int ko = p.korder;
+            // chunk-major: next tap; after the ninth, the next 64-channel chunk.  tap-major: next chunk; after the last, the next tap
+            const int a_kx1 = c_kx + 1, a_w1 = a_kx1 == 3, a_ky1 = c_ky + a_w1, a_w2 = a_ky1 == 3;
+            const int b_c1 = c_cin0 + 64, b_w0 = b_c1 >= p.Cin, b_kx1 = c_kx + b_w0, b_w1 = b_kx1 == 3;
+            const int n_kx = ko ? (a_w1 ? 0 : a_kx1) : (b_w1 ? 0 : b_kx1);
+            const int n_ky = ko ? (a_w2 ? 0 : a_ky1) : c_ky + b_w1;
+            const int n_cin = ko ? c_cin0 + (a_w2 ? 64 : 0) : (b_w0 ? b_c1 - p.Cin : b_c1);
+            c_kx = n_kx;
+            c_ky = n_ky;
+            c_cin0 = n_cin;
+            const int sh = p.up ? 1 : 0;
+            const unsigned wl = (unsigned)(p.W * p.lda);      // < 2^24 (dispatcher): the 24-bit multiplier is full rate, the 32-bit one is not
+#pragma unroll
+            for (int q = 0; q < A_Q; ++q) {
+                const int iy = c_iy0[q] + c_ky, ix = c_ix0[q] + c_kx;
+                const int ok = ((unsigned)iy < (unsigned)VH) & ((unsigned)ix < (unsigned)VW);
+                const unsigned off = __umul24((unsigned)(iy >> sh), wl) + __umul24((unsigned)(ix >> sh), (unsigned)p.lda);
+                ph8_toff[q] = ok ? (int)off : -1;
             }
         } else {
             ph8_ka += 64;
@@ -544,9 +549,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto mma = [&](auto ah_c, auto part_c) {
+            // shadow_c: the A stream's advance to the next K-tile (convolutions: the tap addresses of this lane's four rows, ~40 VALU
+            // instructions -- every K-tile in the chunk-major order) issued INSIDE this MFMA segment, three VALU per MFMA: the matrix pipe
+            // takes an instruction every ~16 cycles and the vector pipe is free beside it; in the read segment the same work held up
+            // the barrier the partner wave's MFMAs wait behind (first version: -16 %, profiles/r05/experiment_tile42_conv_chunk_major_*)
+            auto mma = [&](auto ah_c, auto part_c, auto shadow_c) {
                 constexpr int AH = decltype(ah_c)::value, PART = decltype(part_c)::value;
+                constexpr bool SHADOW = decltype(shadow_c)::value;
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (SHADOW) ph8_adv_a();
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -557,6 +568,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                             if constexpr (TR) c = SUPIR_MFMA_16x16x32(af[kk][i], wf[kk][j], c, 0, 0, 0);
                             else c = SUPIR_MFMA_16x16x32(wf[kk][j], af[kk][i], c, 0, 0, 0);
                         }
+                if constexpr (SHADOW && CONV) {
+#pragma unroll
+                    for (int g = 0; g < 2 * PH_AI * (PART ? PH_NB : PH_NA); ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);    // up to two SALU (the tap / chunk state) ...
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // ... and three VALU (the four rows' tap offsets) behind it
+                    }
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -568,26 +587,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             read_a(0);
             if constexpr (SW0) ph8_stage_w(cur ^ 1, PI0{}, ph8_koff(ph8_wt0));
             mid();
-            mma(PI0{}, PI0{});
+            mma(PI0{}, PI0{}, F_{});
             // phase 1
             read_w(PI1{});
             if constexpr (SA) ph8_stage_a(cur, 0);
             mid();
-            mma(PI0{}, PI1{});
+            mma(PI0{}, PI1{}, F_{});
             // phase 2
             read_a(1);
             if constexpr (SA) ph8_stage_w(cur, PI1{}, ph8_koff(ph8_wt1));
             mid();
-            mma(PI1{}, PI1{});
+            mma(PI1{}, PI1{}, F_{});
             // phase 3
             read_w(PI0{});
-            if constexpr (SA) {
-                ph8_stage_a(cur, 1);
-                ph8_adv_a();
-            }
+            if constexpr (SA) ph8_stage_a(cur, 1);
             if constexpr (WAITN >= 0) g16_wait_vmcnt<WAITN>();
             mid();
-            mma(PI1{}, PI0{});
+            mma(PI1{}, PI0{}, std::integral_constant<bool, SA>{});
             ++ph8_wt0;
             ++ph8_wt1;
             cur ^= 1;
@@ -999,7 +1015,7 @@ bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
     if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % (bn % 10 == 0 ? 10 : 4))) return false;
     if (conv) {
         // tile 42 keeps 32-bit tap offsets against ONE image base per tile: rows of a tile in one batch element, the image below 2^31 elements
-        if (tile == 42 && (a.rows_per_batch % 256 || (long)a.H * a.W * a.lda >= (1L << 31))) return false;
+        if (tile == 42 && (a.rows_per_batch % 256 || (long)a.H * a.W * a.lda >= (1L << 31) || (long)a.W * a.lda >= (1L << 24) || a.H >= (1 << 23))) return false;
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }
     if (a.act == 2)
