@@ -90,7 +90,9 @@ typedef struct supir_launch_hints {
  * csrc/gemm_big.hip (act = GEGLU, W rows interleaved [16 value | 16 gate], M % 256 == 0, N % 320 == 0); 38: 128x80 with FOUR waves
  * and 78 KB of LDS (two workgroups per CU; round 4); 39 / 40: 256x128 and 256x256 of csrc/gemm16.hip (M % 256 == 0, N % 128 / 256 == 0,
  * ordinary epilogue only: the VAE's 128 / 256 / 512-channel layers); 42: 256x256 on the eight-phase ping-pong schedule (round 5: K >= 128,
- * convolutions additionally OH * OW % 256 == 0; bitwise the results of tile 40).  Forced tiles that do not fit the shape return SUPIR_ERR_SHAPE. */
+ * convolutions additionally OH * OW % 256 == 0; bitwise the results of tile 40; its convolutions walk K chunk-major, see csrc/gemm16.hip);
+ * 45: 512x128 on the same schedule (M % 512 == 0, N % 128 == 0, convolutions OH * OW % 512 == 0: the VAE's 128-channel layers at
+ * 512^2 / 1024^2 pixels, where a 256-row tile cannot be fed from L2 fast enough).  Forced tiles that do not fit the shape return SUPIR_ERR_SHAPE. */
 int supir_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
                     const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                     int out_mode, float alpha, int tile, void* stream);

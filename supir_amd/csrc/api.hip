@@ -46,7 +46,7 @@ int supir_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int 
                        const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                        int out_mode, float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 42 || tile == 36 || tile == 41) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 45 || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
@@ -72,7 +72,7 @@ int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, i
                           float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                           const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 42 || tile == 36 || tile == 41) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 45 || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
     if (rowstats_out && (out_mode != 0 || act == 2 || rs_ld <= 0)) return SUPIR_ERR_ARG;
@@ -87,7 +87,7 @@ int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, i
     if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0))) return SUPIR_ERR_SHAPE;
     if (rowstats_out) {  // the slot index is tile_n * waves_n + wave_n: the caller's rs_ld must cover the tile actually used
         const int sel = supir_gemm_select_tile(M, N, act, tile < 0 ? -1 : (tile & 7));
-        const int bn = (tile == 32 || tile == 35 || tile == 38) ? 80 : (tile == 33 || tile == 34) ? 160 : tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
+        const int bn = (tile == 32 || tile == 35 || tile == 38) ? 80 : (tile == 33 || tile == 34) ? 160 : (tile == 39 || tile == 45) ? 128 : (tile == 40 || tile == 42) ? 256 : (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
         if ((N + bn - 1) / bn > rs_ld || (rs_ld & 1)) return SUPIR_ERR_ARG;
     }
     if (const int rc = apply_hints(a, hints)) return rc;
@@ -138,7 +138,7 @@ int supir_conv3x3_bf16_ex(const void* X, const void* W, void* Y, int B, int H, i
                           float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!X || !W || !Y) return SUPIR_ERR_ARG;
     if (B <= 0 || H <= 0 || Wd <= 0 || OH <= 0 || OW <= 0) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || (tile > 35 && (tile < 38 || tile > 40) && tile != 42)) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || (tile > 35 && (tile < 38 || tile > 40) && tile != 42 && tile != 45)) return SUPIR_ERR_ARG;
     if (stride != 1 && stride != 2) return SUPIR_ERR_SHAPE;
     if (upsample && stride != 1) return SUPIR_ERR_SHAPE;
     if (ldy % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)) return SUPIR_ERR_SHAPE;

@@ -22,6 +22,9 @@
 //   40   256 x 256  4x2               1       2   128 KB   256 / 512-channel outputs of the VAE (32 B/clk of fill per CU: the one tile
 //                                                          of the family under the 38 B/clk the loops sustain); one 32-wide K slice of
 //                                                          fragments in registers at a time (128 accumulator registers)
+//   45   512 x 128  4x2  8-phase      1       2   160 KB   the 128-channel outputs on the same schedule: the 256 x 128 tile needs 48 B/clk of fill per
+//                                                          CU for its MFMAs (fill-bound: its K step ran 3222 cycles for 1024 of MFMA on 128 -> 128
+//                                                          at 1024^2), 512 x 128 needs 40
 //   42   256 x 256  2x4  8-phase      1       2   128 KB   the same outputs on the eight-phase ping-pong schedule (round 5, below): half-tile
 //                                                          staging with three half-tiles in flight across the barriers, the two waves of
 //                                                          every SIMD alternating between a fragment-read / load-issue segment and a
@@ -101,16 +104,18 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     // as 256 x 160 (4 x 2 waves, 3 + 2) and as 256 x 320 for the GEGLU projections (4 x 2, 5 + 5): bitwise the one-barrier tiles' results,
     // 5-10 % slower than tile 34 resp. equal to tile 37 -- phases of 8-12 MFMAs are too short for two barriers each, and 216 live registers
     // spill (profiles/r05/experiment_*); those instantiations are not built
-    static_assert(!PH8 || (BM == 256 && KS == 1 && !TRANS && NP == 1 && NWT == 8 && (MI & 1) == 0 && NI >= 2 && (!MIXED || !CONV)), "eight-phase schedule");
+    static_assert(!PH8 || ((BM == 256 || BM == 512) && KS == 1 && !TRANS && NP == 1 && NWT == 8 && (MI & 1) == 0 && NI >= 2 && (!MIXED || !CONV)), "eight-phase schedule");
     constexpr int PH_HR = WTM / 2;                       // token rows of one wave in an A half-tile
     constexpr int PH_AI = MI / 2;                        // token fragments per A half
     constexpr int PH_NA = (NI + 1) / 2, PH_NB = NI - PH_NA;   // channel fragments per wave in W part 0 / part 1
     constexpr int PH_WA_ROWS = WN * PH_NA * 16, PH_WB_ROWS = WN * PH_NB * 16;
     constexpr int PH_WA_CH = PH_WA_ROWS / 8, PH_WB_CH = PH_WB_ROWS / 8;          // 8-row chunks per W part
     constexpr int PH_WA_Q = (PH_WA_CH + 7) / 8, PH_WB_Q = (PH_WB_CH + 7) / 8;    // global -> LDS instructions per wave (the last may repeat chunk `wave`)
-    constexpr int PH_OFF_W = 32768, PH_OFF_WB = PH_OFF_W + PH_WA_ROWS * 128;     // LDS map of a K-tile buffer: [A0 16K | A1 16K | WA | WB]
-    constexpr int PH_INFLIGHT = 2 + PH_WB_Q + 2;        // loads per wave behind W part 0 of the next K-tile: A0, WB, A1 of the one after
-    static_assert(!PH8 || (PH_WA_CH <= 24 && PH_WB_CH <= 24 && (PH_HR == 64 || PH_HR == 32) && PH_OFF_WB + PH_WB_ROWS * 128 == STAGE_BYTES), "half-tile map");
+    constexpr int PH_A_HALF = BM * 64;                   // bytes of one A half-tile (BM / 2 rows of 128 B): 16 KB, 32 KB for the 512-row tile
+    constexpr int PH_A_Q = BM / 128;                     // global -> LDS instructions per wave and A half-tile (8-row chunks wave + 8 q)
+    constexpr int PH_OFF_W = 2 * PH_A_HALF, PH_OFF_WB = PH_OFF_W + PH_WA_ROWS * 128;   // LDS map of a K-tile buffer: [A0 | A1 | WA | WB]
+    constexpr int PH_INFLIGHT = PH_A_Q + PH_WB_Q + PH_A_Q;   // loads per wave behind W part 0 of the next K-tile: A0, WB, A1 of the one after
+    static_assert(!PH8 || (PH_WA_CH <= 24 && PH_WB_CH <= 24 && (PH_HR == 64 || (PH_HR == 32 && BM == 256)) && PH_OFF_WB + PH_WB_ROWS * 128 == STAGE_BYTES), "half-tile map");
     static_assert(!(CONV && TRANS) && !(MIXED && (TRANS || CONV || KS != 1)), "the implicit-GEMM loader has no transposed epilogue");
     // epilogue LDS map (the rings are idle by then): [0, XCH) K-group exchange, then per-wave C staging, bias / column sums,
     // row-statistics scratch
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     constexpr int C_STAGE = 16 * C_RS;                         // one 16-token block per wave
     constexpr int OFF_CST = XCH, OFF_BIAS = OFF_CST + NWT * C_STAGE, OFF_RED = OFF_BIAS + 2 * BN * 4;
     constexpr int OFF_GN = OFF_RED + WN * BM * 8;               // GroupNorm column partials: [wave 0..NWT-1][WTN][2] fp32
-    static_assert(OFF_GN + NWT * WTN * 8 <= KS * RING, "epilogue scratch must fit the LDS rings");
+    static_assert(OFF_GN + NWT * WTN * 8 <= KS * RING - (PH8 ? 256 : 0), "epilogue scratch must fit the LDS rings");
 
     // wave-uniform ids as scalars (readfirstlane): LDS destinations / branches on them stay on the scalar unit
     const int bwave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // wave inside the workgroup, 0..7
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
             // eight-phase schedule: q = 2 h + qq is this lane's row of A-half h (token fragments [4h, 4h + 4) of both wave rows), wave row qq
-            const int m = PH8 ? m0 + (q & 1) * 128 + (q >> 1) * PH_HR + (PH_HR == 64 ? wave * 8 : (wave >> 2) * WTM + (wave & 3) * 8) + lrow
+            const int m = PH8 ? m0 + (q % PH_A_Q) * 128 + (q / PH_A_Q) * PH_HR + (PH_HR == 64 ? wave * 8 : (wave >> 2) * WTM + (wave & 3) * 8) + lrow
                               : m0 + (wave + NW * q) * 8 + lrow;
             const int b = m / p.rows_per_batch, r = m - b * p.rows_per_batch;
             const int oy = r / p.OW, ox = r - oy * p.OW;
@@ -302,11 +307,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         ph8_w_lane = (unsigned)(lrow * p.K + lchunk * 8) * 2u;
     }
     auto ph8_stage_a = [&](int buf, int h) {
-        char* dst = smem + buf * STAGE_BYTES + h * 16384 + wave * 1024;
+        char* dst = smem + buf * STAGE_BYTES + h * PH_A_HALF + wave * 1024;
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
+        for (int qq = 0; qq < PH_A_Q; ++qq) {
             if constexpr (CONV) {
-                const int off = ph8_toff[2 * h + qq];
+                const int off = ph8_toff[PH_A_Q * h + qq];
                 const bf16_t* src = off >= 0 ? ph8_cbase + (off + c_cin0) : (const bf16_t*)g16_zero_page;
                 glds16(src, dst + qq * 8192);
             } else {
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int i = 0; i < PH_AI; ++i) af[kk][i] = *(const bf16x8*)(sT + h * 16384 + fa_off + i * 2048 + (((4 * kk + quad) ^ sw) * 16));
+                    for (int i = 0; i < PH_AI; ++i) af[kk][i] = *(const bf16x8*)(sT + h * PH_A_HALF + fa_off + i * 2048 + (((4 * kk + quad) ^ sw) * 16));
             };
             auto read_w = [&](auto part_c) {
                 constexpr int PART = decltype(part_c)::value;
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             unsigned line = i * 64 + lane;
             line = line < pf_lines ? line : pf_lines - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.pf_ptr + (size_t)line * 128),
-                                             (__attribute__((address_space(3))) void*)(smem + KS * RING), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + (PH8 ? RING - 256 : KS * RING)), 4, 0, 0);
         }
     };
     using K0_ = std::integral_constant<int, 0>;
@@ -977,7 +982,7 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     for (int q = 0; q < NP; ++q) {
         pp.p[q] = a_in[q];
         pp.p[q].fast_gelu = supir_debug_knob_value(0) ? 0 : 1;   // one switch for every GEGLU epilogue (tile 37 reads the same knob)
-        pp.p[q].korder = (CONV && S == 8 && supir_debug_knob_value(6) != 1) ? 1 : 0;   // tile 42 convolutions: chunk-major K order (knob 6 = 1: tap-major)
+        pp.p[q].korder = (CONV && S == 8 && supir_debug_knob_value(6) != 1) ? 1 : 0;   // tile 42 / 45 convolutions: chunk-major K order (knob 6 = 1: tap-major)
     }
     GemmArgs& a = pp.p[0];
     const int tiles = (a.M / BM) * (a.N / BN);
@@ -989,7 +994,9 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
         pp.p[q].gn = a.gn;
         pp.p[q].order = a.order;
     }
-    constexpr int smem = KS * (S == 8 ? 2 : S) * (BM + BN) * 128 + 256;   // the ring(s) + the prefetch scratch row
+    // the ring(s) + the prefetch scratch row (the eight-phase tiles dump the prefetch into the last 256 bytes of their ring, which the
+    // epilogue scratch never reaches: the 512 x 128 tile uses all 160 KB)
+    constexpr int smem = KS * (S == 8 ? 2 : S) * (BM + BN) * 128 + (S == 8 ? 0 : 256);
     static_assert(smem <= 163840, "LDS");
     auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED, NP>;
     static bool attr_set = false;
@@ -1003,19 +1010,20 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42) return false;
-    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42;
-    const int bm = wide ? 256 : 128, bn = tile == 39 ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
-    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tile 42: at least two K-tiles
+    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42 && tile != 45) return false;
+    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42 || tile == 45;
+    const int bm = tile == 45 ? 512 : wide ? 256 : 128;
+    const int bn = (tile == 39 || tile == 45) ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
+    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tiles 42 / 45: at least two K-tiles
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
     // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU); their GroupNorm
     // partials come in 4-channel units (channel counts 128 / 256 / 512: 4 / 8 / 16 channels per group)
-    if ((tile == 39 || tile == 40 || tile == 42) && (a.out_mode != 0 || a.act == 2)) return false;
+    if ((tile == 39 || tile == 40 || tile == 42 || tile == 45) && (a.out_mode != 0 || a.act == 2)) return false;
     if (a.gn_part_out && (a.out_mode != 0 || a.act == 2 || a.rows_per_batch <= 0 || a.rows_per_batch % bm || a.N % (bn % 10 == 0 ? 10 : 4))) return false;
     if (conv) {
         // tile 42 keeps 32-bit tap offsets against ONE image base per tile: rows of a tile in one batch element, the image below 2^31 elements
-        if (tile == 42 && (a.rows_per_batch % 256 || (long)a.H * a.W * a.lda >= (1L << 31) || (long)a.W * a.lda >= (1L << 24) || a.H >= (1 << 23))) return false;
+        if ((tile == 42 || tile == 45) && (a.rows_per_batch % bm || (long)a.H * a.W * a.lda >= (1L << 31) || (long)a.W * a.lda >= (1L << 24) || a.H >= (1 << 23))) return false;
         if (a.Cin % (64 * ks) || a.K != 9 * a.Cin || a.out_mode != 0 || a.act == 2 || a.ln_stats || a.rowstats_out) return false;
     }
     if (a.act == 2)
@@ -1041,6 +1049,7 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
             case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false, true>(&a, st);
             case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false, true>(&a, st);
             case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false, true>(&a, st);
+            case 45: return launch_gemm16<512, 128, 4, 2, 1, 8, false, true>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
@@ -1049,6 +1058,7 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
         case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false>(&a, st);
         case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false>(&a, st);
         case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false>(&a, st);
+        case 45: return launch_gemm16<512, 128, 4, 2, 1, 8, false>(&a, st);
         case 38: return t ? launch_gemm16<128, 80, 4, 1, 1, 3, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 1, 3, false>(&a, st);
         case 32: return t ? launch_gemm16<128, 80, 4, 1, 2, 2, true>(&a, st) : launch_gemm16<128, 80, 4, 1, 2, 2, false>(&a, st);
         case 33: return t ? launch_gemm16<128, 160, 2, 2, 2, 2, true>(&a, st) : launch_gemm16<128, 160, 2, 2, 2, 2, false>(&a, st);

@@ -769,6 +769,7 @@ def test_gemm16_conv3x3(case, tile):
 
 
 G16_VAE_CONV_CASES = [
+    (1, 64, 128, 128, 128, 1, (1, 1), False, None),         # 8192 rows: sixteen 512-row tiles (tile 45)
     # B, H, W, Cin, Cout, stride, pad(top,left), upsample, out_hw      (sgm/modules/diffusionmodules/model.py:55-148, 571-743)
     (1, 64, 64, 128, 128, 1, (1, 1), False, None),          # ResnetBlock at the full-resolution level (1024^2 in production)
     (1, 32, 32, 256, 256, 1, (1, 1), False, None),
@@ -780,13 +781,14 @@ G16_VAE_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", G16_VAE_CONV_CASES)
-@pytest.mark.parametrize("tile", [39, 40, 42])
+@pytest.mark.parametrize("tile", [39, 40, 42, 45])
 def test_gemm16_vae_tiles_conv3x3(case, tile):
     """Tiles 39 (256 x 128) / 40 (256 x 256, one K slice of fragments in registers at a time) / 42 (256 x 256 on the eight-phase
     ping-pong schedule, round 5) of csrc/gemm16.hip on the VAE's convolution shapes: against torch fp32, against the gemm.hip tile that
     ran them before, repeatable, epilogue terms; tile 42 accumulates in tile 40's K order: BITWISE tile 40."""
     B, H, W, Cin, Cout, stride, pad, up, out_hw = case
-    bn = 128 if tile == 39 else 256
+    bn = 128 if tile in (39, 45) else 256
+    bm = 512 if tile == 45 else 256          # tile 45 (round 5): 512 x 128 on the eight-phase schedule, the 128-channel layers
     x = rnd(B, H, W, Cin).to(BF)
     w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)
     bias = rnd(Cout, seed=2)
@@ -799,30 +801,30 @@ def test_gemm16_vae_tiles_conv3x3(case, tile):
     else:
         ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=1)
     OH, OW = ref.shape[2:]
-    if (B * OH * OW) % 256 or Cout % bn:
+    if (B * OH * OW) % bm or Cout % bn or (tile in (42, 45) and (OH * OW) % bm):
         pytest.skip("not an exact fit for this tile")
     ref = ref.permute(0, 2, 3, 1)
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile)
     check(out, ref, name=f"conv16 {case} tile{tile}")
     assert torch.equal(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile))
     check(out, ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=4).float(), rel=3e-3, name="vs gemm.hip tile 4")
-    if tile == 42:
-        # tile 42's convolutions run their K loop as (channel chunk, tap) -- the nine taps of a 64-channel chunk back to back, so that a
+    if tile in (42, 45):
+        # tile 42's / 45's convolutions run their K loop as (channel chunk, tap) -- the nine taps of a 64-channel chunk back to back, so that a
         # tile's three input rows stay in L2 -- where every other tile runs (tap, chunk): another fp32 summation order, equal to rounding.
         # With the tap-major order forced (tools knob 6) it accumulates exactly as tile 40: BITWISE, on every repetition (a racy hand-off
         # -- LDS-DMA landing late, a half-tile restaged early -- shows up as run-to-run differences)
         from supir_amd import _lib
         lib = _lib.load(BF)
-        o40 = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=40)
+        o40 = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=40 if tile == 42 else 39)
         check(out, o40.float(), rel=2e-3, name="chunk-major vs tap-major K order")
         try:
             lib.supir_debug_knob(6, 1)
             for _ in range(3):
-                assert torch.equal(ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=42), o40)
+                assert torch.equal(ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile), o40)
         finally:
             lib.supir_debug_knob(6, 0)
         for _ in range(3):
-            assert torch.equal(ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=42), out)
+            assert torch.equal(ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, tile=tile), out)
     res = rnd(B, OH, OW, Cout, seed=5).to(BF)
     out = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, residual=res, act=1, alpha=0.5, tile=tile)
     check(out, 0.5 * F.silu(ref) + res.float(), name="conv16 epilogue")
@@ -832,7 +834,7 @@ def test_gemm16_vae_tiles_conv3x3(case, tile):
     y = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, residual=res, tile=tile)
     y2, part = ops.conv3x3(x, wk, bias, stride=stride, pad=pad, upsample=up, out_hw=out_hw, residual=res, tile=tile, gn_part=True)
     assert part is not None and part.unit == 4 and part.C == Cout and torch.equal(y, y2)
-    yf = y.double().view(B, OH * OW // 256, 256, Cout // 4, 4)
+    yf = y.double().view(B, OH * OW // bm, bm, Cout // 4, 4)
     ref_part = torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
     assert part.buf.shape == ref_part.shape
     assert torch.allclose(part.buf.double(), ref_part, rtol=2e-5, atol=2e-3), (part.buf.double() - ref_part).abs().max()
@@ -849,11 +851,11 @@ def test_gemm16_vae_tiles_conv3x3(case, tile):
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (1024, 256, 128), (512, 128, 256), (16384, 512, 512), (8192, 1280, 5120), (65536, 256, 192)])
-@pytest.mark.parametrize("tile", [39, 40, 42])
+@pytest.mark.parametrize("tile", [39, 40, 42, 45])
 def test_gemm16_vae_tiles_plain(M, N, K, tile):
     """The same tiles as plain GEMMs (the VAE's 1x1 convolutions: nin_shortcut model.py:124, attention q / k / v / proj_out :164-175)."""
-    bn = 128 if tile == 39 else 256
-    if N % bn or (tile == 39 and K < 128):
+    bn = 128 if tile in (39, 45) else 256
+    if N % bn or (tile in (39, 45) and K < 128) or (tile == 45 and M % 512):
         pytest.skip("not an exact fit for this tile")
     a = rnd(M, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
@@ -862,18 +864,21 @@ def test_gemm16_vae_tiles_plain(M, N, K, tile):
     out = ops.gemm(a, w, bias, tile=tile)
     check(out, base, name=f"gemm16{(M, N, K)} tile{tile}")
     assert torch.equal(out, ops.gemm(a, w, bias, tile=tile))
-    if tile == 42:       # same MFMA, same K order as tile 40: bitwise, on every repetition (a racy LDS hand-off would differ run to run)
+    if tile in (42, 45):       # same MFMA, same K order as tile 40 / 39: bitwise, on every repetition (a racy LDS hand-off would differ run to run)
         for _ in range(3):
-            assert torch.equal(ops.gemm(a, w, bias, tile=42), ops.gemm(a, w, bias, tile=40))
+            assert torch.equal(ops.gemm(a, w, bias, tile=tile), ops.gemm(a, w, bias, tile=40 if tile == 42 else 39))
     res = rnd(M, N, seed=3).to(BF)
     check(ops.gemm(a, w, bias, residual=res, alpha=0.5, tile=tile), 0.5 * base + res.float(), name="res+alpha")
     acc = res.clone()
     ops.gemm(a, w, bias, residual=acc, out=acc, tile=tile)                          # in-place residual (x += f(x))
     check(acc, base + res.float(), name="in-place residual")
     if N % 128 == 0 and M % 512 == 0:   # partials from a plain GEMM (AttnBlock.proj_out + residual, model.py:192), two batch elements
+        bm_ = 512 if tile == 45 else 256
+        if (M // 2) % bm_:
+            return
         y, part = ops.gemm(a, w, bias, residual=res, rows_per_batch=M // 2, tile=tile, gn_part=True)
-        assert part is not None and part.unit == 4 and part.nchunk == M // 2 // 256
-        yf = y.double().view(2, M // 2 // 256, 256, N // 4, 4)
+        assert part is not None and part.unit == 4 and part.nchunk == M // 2 // bm_
+        yf = y.double().view(2, M // 2 // bm_, bm_, N // 4, 4)
         assert torch.allclose(part.buf.double(), torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1), rtol=2e-5, atol=2e-3)
         g, b_ = rnd(N, seed=6) * 0.2 + 1.0, rnd(N, seed=7) * 0.2
         yv = y.view(2, M // 2, N)

@@ -38,7 +38,8 @@ def ab(fns, iters):
 
 rows = []
 CONVS = [(1, 256, 256, 512, 512, False), (1, 128, 128, 512, 512, True), (1, 512, 512, 256, 256, False), (1, 256, 256, 256, 256, True),
-         (1, 256, 256, 256, 512, False), (1, 256, 256, 512, 256, False), (1, 512, 512, 128, 256, False)]
+         (1, 256, 256, 256, 512, False), (1, 256, 256, 512, 256, False), (1, 512, 512, 128, 256, False),
+         (1, 1024, 1024, 128, 128, False), (1, 512, 512, 256, 128, False), (1, 512, 512, 256, 256, True), (1, 1024, 1024, 256, 128, False)]
 for (B, H, W, Cin, Cout, up) in CONVS:
     x = torch.randn(B, H, W, Cin, device=dev).to(BF)
     w = (torch.randn(Cout, 3, 3, Cin, device=dev) * (9 * Cin) ** -0.5).to(BF)
@@ -46,8 +47,8 @@ for (B, H, W, Cin, Cout, up) in CONVS:
     OH, OW = (2 * H, 2 * W) if up else (H, W)
     M = B * OH * OW
     fl = 2.0 * M * Cout * 9 * Cin
-    tiles = [t for t in (40, 42, 39, 5) if not (t in (40, 42) and Cout % 256) and not (t == 39 and Cout % 128) and not (t in (34, 43) and Cout % 160)
-             and not (t in (42, 43) and (OH * OW) % 256)]
+    tiles = [t for t in (40, 42, 39, 45, 5) if not (t in (40, 42) and Cout % 256) and not (t in (39, 45) and Cout % 128)
+             and not (t == 42 and (OH * OW) % 256) and not (t == 45 and (OH * OW) % 512)]
     fns = {f"tile{t}": (lambda t=t: ops.conv3x3(x, w, bias, upsample=up, tile=t)) for t in tiles}
     if 42 in tiles:      # tile 42 with the tap-major K order of every other tile (tools knob 6 = 1) beside its chunk-major default
         from supir_amd import _lib
@@ -68,19 +69,20 @@ for (B, H, W, Cin, Cout, up) in CONVS:
         row["tile42_tapmajor_bitwise_tile40"] = bool(torch.equal(fns["tile42_tapmajor"](), ops.conv3x3(x, w, bias, upsample=up, tile=40)))
         a_, b_ = ops.conv3x3(x, w, bias, upsample=up, tile=42).float(), ops.conv3x3(x, w, bias, upsample=up, tile=40).float()
         row["tile42_rel_l2_vs_tile40"] = float(((a_ - b_).norm() / b_.norm()).item())
-    if 34 in tiles and 43 in tiles:
-        row["tile43_bitwise_tile34"] = bool(torch.equal(ops.conv3x3(x, w, bias, upsample=up, tile=43), ops.conv3x3(x, w, bias, upsample=up, tile=34)))
+    if 39 in tiles and 45 in tiles:
+        a_, b_ = ops.conv3x3(x, w, bias, upsample=up, tile=45).float(), ops.conv3x3(x, w, bias, upsample=up, tile=39).float()
+        row["tile45_rel_l2_vs_tile39"] = float(((a_ - b_).norm() / b_.norm()).item())
     rows.append(row)
     print(json.dumps(row), flush=True)
     del x, w
     torch.cuda.empty_cache()
-GEMMS = [(8192, 8192, 8192), (4096, 4096, 4096)]
+GEMMS = [(8192, 8192, 8192), (4096, 4096, 4096), (1048576, 128, 256)]
 for (M, N, K) in GEMMS:
     a = torch.randn(M, K, device=dev).to(BF)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
     res = torch.randn(M, N, device=dev).to(BF)
     fl = 2.0 * M * N * K
-    tiles = [t for t in (40, 42, 39, 5) if not (t in (40, 42) and N % 256) and not (t == 39 and N % 128) and not (t in (33, 34, 43) and N % 160)
+    tiles = [t for t in (40, 42, 39, 45, 5) if not (t in (40, 42) and N % 256) and not (t in (39, 45) and N % 128) and not (t == 45 and M % 512)
              and not (t == 33 and K % 128)]
     fns = {f"tile{t}": (lambda t=t: ops.gemm(a, w, None, residual=res, tile=t)) for t in tiles}
     r = ab(fns, max(3, int(2000.0 / (fl / 1e9))))
@@ -89,8 +91,8 @@ for (M, N, K) in GEMMS:
         row[k] = {"us_median": round(med, 1), "us_min": round(mn, 1), "tflops_median": round(fl / med / 1e6, 1)}
     if 40 in tiles and 42 in tiles:
         row["tile42_bitwise_tile40"] = bool(torch.equal(ops.gemm(a, w, None, residual=res, tile=42), ops.gemm(a, w, None, residual=res, tile=40)))
-    if 34 in tiles and 43 in tiles:
-        row["tile43_bitwise_tile34"] = bool(torch.equal(ops.gemm(a, w, None, residual=res, tile=43), ops.gemm(a, w, None, residual=res, tile=34)))
+    if 39 in tiles and 45 in tiles:
+        row["tile45_bitwise_tile39"] = bool(torch.equal(ops.gemm(a, w, None, residual=res, tile=45), ops.gemm(a, w, None, residual=res, tile=39)))
     rows.append(row)
     print(json.dumps(row), flush=True)
     del a, w, res

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from supir_amd.ops import gemm_tile_name  # noqa: E402
 
 cases, summ, out_path, note = json.load(open(sys.argv[1])), json.load(open(sys.argv[2])), sys.argv[3], sys.argv[4]
-G16 = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320), 39: (256, 128), 40: (256, 256), 42: (256, 256)}
+G16 = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320), 39: (256, 128), 40: (256, 256), 42: (256, 256), 45: (512, 128)}
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 out["note"] = note
 
@@ -41,7 +41,7 @@ for c in cases:
         bm, bn = G16[tile]
         grid = (M // bm) * (N // bn) * 512
         targs = {32: "128, 80, 4, 1, 2, 2", 33: "128, 160, 2, 2, 2, 2", 34: "256, 160, 8, 1, 1, 3", 35: "128, 80, 4, 1, 2, 3",
-                 39: "256, 128, 4, 2, 1, 3", 40: "256, 256, 4, 2, 1, 2", 42: "256, 256, 2, 4, 1, 8"}
+                 39: "256, 128, 4, 2, 1, 3", 40: "256, 256, 4, 2, 1, 2", 42: "256, 256, 2, 4, 1, 8", 45: "512, 128, 4, 2, 1, 8"}
         if tile == 34 and (kind == "conv3x3" or (kind == "gemm" and M >= 8192)):
             targs[34] = "256, 160, 4, 2, 1, 3"     # round 4: the eight waves as 4 x 2 for convolutions and M >= 8192
         e = find("geglu_big_kernel", grid) if tile == 37 else \

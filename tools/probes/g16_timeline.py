@@ -30,8 +30,8 @@ lib.supir_big_tl_set.argtypes = [P]
 BF = torch.bfloat16
 CASES = [(2048, 1280, 1280, 35), (2048, 1280, 1280, 32), (2048, 1280, 5120, 35), (2048, 2560, 1280, 33), (2048, 10240, 1280, 34)]
 if len(sys.argv) > 1 and sys.argv[1] == "large":   # round 5: the large-M regime (tile batches / --num_samples, VAE-sized GEMMs)
-    CASES = [(8192, 1280, 1280, 34), (8192, 1280, 1280, 43), (8192, 1280, 5120, 34), (8192, 1280, 5120, 43), (65536, 512, 4608, 40),
-             (65536, 512, 4608, 42), (262144, 256, 2304, 42), (1048576, 128, 1152, 39)]
+    CASES = [(8192, 1280, 1280, 34), (8192, 1280, 5120, 34), (65536, 512, 4608, 40),
+             (65536, 512, 4608, 42), (262144, 256, 2304, 42), (1048576, 128, 1152, 39), (1048576, 128, 1152, 45), (262144, 256, 2304, 45)]
 if len(sys.argv) > 1 and sys.argv[1] == "geglu":   # the GEGLU projection on the 256 x 160 and the 256 x 320 tile, several K and M
     CASES = [(2048, 10240, 1280, 34), (2048, 10240, 1280, 37), (2048, 10240, 640, 37), (2048, 10240, 2560, 37), (4096, 10240, 1280, 37),
              (8192, 5120, 640, 37)]
@@ -42,7 +42,7 @@ for (M, N, K, tile) in CASES:
     bias = torch.randn(N, device="cuda")
     out = torch.empty(M, N, device="cuda", dtype=BF)
     geglu = len(sys.argv) > 1 and sys.argv[1] == "geglu"
-    bm, bn = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320), 39: (256, 128), 40: (256, 256), 42: (256, 256), 43: (256, 160)}[tile]
+    bm, bn = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320), 39: (256, 128), 40: (256, 256), 42: (256, 256), 45: (512, 128)}[tile]
     nwg = (M // bm) * (N // bn)
     buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device="cuda")
     (lib.supir_big_tl_set if tile == 37 else lib.supir_g16_tl_set)(buf.data_ptr())
@@ -65,7 +65,7 @@ for (M, N, K, tile) in CASES:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     t = buf.view(nwg * 8, 8).cpu().double()
-    nk = (K // 64) // (1 if tile in (34, 37, 39, 40, 42, 43) else 2)
+    nk = (K // 64) // (1 if tile in (34, 37, 39, 40, 42, 45) else 2)
     print(f"M={M} N={N} K={K} tile={tile} wgs={nwg} | event {us:.1f} us | per wave (cycles): prologue "
           f"{t[:, 1].mean():.0f}  loop {t[:, 2].mean():.0f} ({t[:, 2].mean() / nk:.0f} per K step x {nk})  exchange {t[:, 3].mean():.0f}  "
           f"epilogue {t[:, 4].mean():.0f}  total {t[:, 5].mean():.0f} (max {t[:, 5].max():.0f})", flush=True)
