@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsupir_hip.so")
 # the same sources built with -DSUPIR_F16: every 16-bit buffer of the ABI holds IEEE binary16, MFMA operands are fp16 (csrc/common.h)
 LIB_PATH_F16 = os.path.join(_HERE, "libsupir_hip_f16.so")
+# the fp32 service (csrc/f32, include/supir_hip_f32.h): its own, much smaller, entry-point table
+LIB_PATH_F32 = os.path.join(_HERE, "libsupir_hip_f32.so")
 
 _ERR = {-1: "SUPIR_ERR_ARG (null pointer / bad size)", -2: "SUPIR_ERR_SHAPE (unsupported shape or alignment)",
         -3: "SUPIR_ERR_HIP (launch failed)"}
@@ -103,9 +105,30 @@ SIGNATURES.update({
 # entry points that return a byte count (size_t) instead of a status
 SIZE_SIGNATURES = {"supir_flash_attn_d512_workspace": [I, I, I, I]}
 
+class F32GemmDesc(ctypes.Structure):
+    """supir_f32_gemm_desc (include/supir_hip_f32.h), field for field."""
+    _fields_ = [("A", P), ("W", P), ("C", P), ("bias", P), ("rowbias", P), ("residual", P),
+                ("kind", I), ("M", I), ("N", I), ("K", I),
+                ("lda", I), ("ldw", I), ("ldc", I), ("ldr", I), ("ld_rowbias", I), ("rows_per_batch", I),
+                ("act", I), ("out_mode", I), ("alpha", F), ("nz0", I), ("nz1", I),
+                ("a_s0", L), ("a_s1", L), ("w_s0", L), ("w_s1", L), ("c_s0", L), ("c_s1", L),
+                ("B", I), ("H", I), ("Wd", I), ("Cin", I), ("OH", I), ("OW", I), ("stride", I), ("pad_t", I), ("pad_l", I), ("upsample", I)]
+
+
+F32_GEMM, F32_CONV3X3 = 0, 1
+# libsupir_hip_f32.so: name -> argtypes; mirrors include/supir_hip_f32.h one to one (tests/test_abi.py cross-checks)
+SIGNATURES_F32 = {
+    "supir_f32_gemm": [P, P],
+    "supir_f32_geglu": [P, P, I, I, I, I, I, P],
+    "supir_f32_softmax_rows": [P, P, L, I, I, L, L, F, P],
+    "supir_f32_groupnorm": [P, P, P, P, I, I, I, I, I, I, P, P, F, I, P, P, I, F, P, I, P, c_size_t, P],
+    "supir_f32_layernorm": [P, P, P, P, I, I, I, I, F, P],
+}
+
 ABI_VERSION = 2   # include/supir_hip.h: round 5 removed the thread-local one-shot setters, added the tiled-sampler edges
 _lib = None       # the bf16 library (the product default)
 _lib_f16 = None   # the fp16 build, loaded on first use
+_lib_f32 = None   # the fp32 service, loaded on first use
 
 
 class SupirHipError(RuntimeError):
@@ -117,6 +140,8 @@ def load(dtype=None):
     dtype: element type of the 16-bit operands the caller is about to pass -- torch.float16 selects libsupir_hip_f16.so,
     anything else (None, torch.bfloat16) the bf16 library."""
     global _lib, _lib_f16
+    if dtype is torch.float32:
+        return load_f32()
     f16 = dtype is torch.float16
     cur = _lib_f16 if f16 else _lib
     if cur is not None:
@@ -157,9 +182,37 @@ def load(dtype=None):
     return lib
 
 
+def load_f32():
+    """libsupir_hip_f32.so (include/supir_hip_f32.h): what fp32 operands reach.  Same rules: built by supir_amd.build, no fallback."""
+    global _lib_f32
+    if _lib_f32 is not None:
+        return _lib_f32
+    if not os.path.exists(LIB_PATH_F32):
+        raise SupirHipError(
+            f"{LIB_PATH_F32} not found: run `python -m supir_amd.build` (hipcc, gfx950). The HIP extension is mandatory; "
+            "there is no CPU / PyTorch fallback on the product path.")
+    lib = ctypes.CDLL(LIB_PATH_F32)
+    for name, restype in (("supir_abi_version", c_int), ("supir_target_arch", c_char_p), ("supir_elem_type", c_char_p),
+                          ("supir_last_hip_error", c_int)):
+        getattr(lib, name).restype = restype
+        getattr(lib, name).argtypes = []
+    lib.supir_hip_error_string.restype = c_char_p
+    lib.supir_hip_error_string.argtypes = [c_int]
+    for name, argtypes in SIGNATURES_F32.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    if lib.supir_abi_version() != ABI_VERSION:
+        raise SupirHipError("libsupir_hip_f32.so ABI version mismatch")
+    if lib.supir_elem_type() != b"f32":
+        raise SupirHipError(f"libsupir_hip_f32.so was built for {lib.supir_elem_type()!r} elements, expected b'f32'")
+    _lib_f32 = lib
+    return lib
+
+
 def loaded():
     """The libraries this process has dlopen'ed so far (bf16 first)."""
-    return [lib for lib in (_lib, _lib_f16) if lib is not None]
+    return [lib for lib in (_lib, _lib_f16, _lib_f32) if lib is not None]
 
 
 def check(rc, name, lib=None):

@@ -1,5 +1,6 @@
-"""Build libsupir_hip.so (bf16 elements, the product default) and libsupir_hip_f16.so (the same sources with -DSUPIR_F16: fp16
-elements and MFMA operands, for callers that request the reference's default diff_dtype) in-tree with hipcc for gfx950
+"""Build libsupir_hip.so (bf16 elements, the product default), libsupir_hip_f16.so (the same sources with -DSUPIR_F16: fp16
+elements and MFMA operands, for callers that request the reference's default diff_dtype) and libsupir_hip_f32.so (csrc/f32: the
+fp32 service of `--diff_dtype fp32` / `--ae_dtype fp32` requests, include/supir_hip_f32.h) in-tree with hipcc for gfx950
 (cross-compiles without a GPU).
 
 The .so files are git-ignored but travel to the GPU box with the working-tree snapshot; nothing is JIT-compiled at run time.
@@ -14,16 +15,20 @@ SOURCES = ["gemm.hip", "gemm16.hip", "gemm_big.hip", "attention.hip", "xattn.hip
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "supir_hip.h")]
 LIB = os.path.join(HERE, "libsupir_hip.so")
 LIB_F16 = os.path.join(HERE, "libsupir_hip_f16.so")
-# (library, object sub-directory, extra compile flags, extra link flags).  -Bsymbolic on the fp16 build: both libraries define the
-# same C++ symbols; each must bind to its own even if a host application loads them RTLD_GLOBAL.
-VARIANTS = [(LIB, "", [], []), (LIB_F16, "f16", ["-DSUPIR_F16"], ["-Wl,-Bsymbolic"])]
+LIB_F32 = os.path.join(HERE, "libsupir_hip_f32.so")
+SOURCES_F32 = [os.path.join("f32", "f32.hip")]
+HEADERS_F32 = [os.path.join("..", "..", "include", "supir_hip.h"), os.path.join("..", "..", "include", "supir_hip_f32.h")]
+# (library, object sub-directory, extra compile flags, extra link flags, sources, headers).  -Bsymbolic on the fp16 / fp32 builds: the
+# libraries define the same symbols; each must bind to its own even if a host application loads them RTLD_GLOBAL.
+VARIANTS = [(LIB, "", [], [], SOURCES, HEADERS), (LIB_F16, "f16", ["-DSUPIR_F16"], ["-Wl,-Bsymbolic"], SOURCES, HEADERS),
+            (LIB_F32, "f32", [], ["-Wl,-Bsymbolic"], SOURCES_F32, HEADERS_F32)]
 
 
-def _stale(lib=LIB):
+def _stale(lib=LIB, sources=SOURCES, headers=HEADERS):
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in sources + headers)
 
 
 # per-source extra flags.  attention.hip: keep the MFMA accumulators in architectural VGPRs -- the default allocation put
@@ -31,30 +36,30 @@ def _stale(lib=LIB):
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "xattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def _obj_stale(src, obj):
+def _obj_stale(src, obj, headers=HEADERS):
     """An object is rebuilt when its source or any shared header is newer (headers are few and included everywhere)."""
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in [src] + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in [src] + headers)
 
 
 def build(force=False, verbose=True):
     """Compile every stale translation unit of every stale variant (in parallel), link, return the bf16 library's path."""
-    todo = [v for v in VARIANTS if force or _stale(v[0])]
+    todo = [v for v in VARIANTS if force or _stale(v[0], v[4], v[5])]
     if not todo:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
     procs, objs = [], {}
-    for lib, sub, cflags, _ in todo:
+    for lib, sub, cflags, _, sources, headers in todo:
         objdir = os.path.join(CSRC, "_obj", sub)
         os.makedirs(objdir, exist_ok=True)
         objs[lib] = []
-        for src in SOURCES:
-            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        for src in sources:
+            obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
             objs[lib].append(obj)
-            if not force and not _obj_stale(src, obj):
+            if not force and not _obj_stale(src, obj, headers):
                 continue
             cmd = base + cflags + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
@@ -63,7 +68,7 @@ def build(force=False, verbose=True):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    for lib, _, _, lflags in todo:
+    for lib, _, _, lflags, _, _ in todo:
         link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + lflags + objs[lib] + ["-o", lib + ".tmp"]
         if verbose:
             print("[supir_amd.build]", " ".join(link), flush=True)

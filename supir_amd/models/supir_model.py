@@ -67,19 +67,21 @@ class SUPIRModel(nn.Module):
         """The reference runs the three VAE entry points under `torch.autocast("cuda", dtype=self.ae_dtype)` (SUPIR_model.py:41-69;
         `model.ae_dtype = ...` is part of test.py's attribute protocol, test.py:67).  Here `ae_dtype` selects the element type of
         the VAE kernels for the call: torch.bfloat16 (test.py's default) -> bf16, the reference's own arithmetic for that request.
-        torch.float32 (`--ae_dtype fp32`) is computed by the reference in TRUE fp32 (autocast disables itself for float32); this
-        path has no fp32 kernels and serves it in bf16 -- said once per request with a RuntimeWarning, a RuntimeError under
-        SUPIR_STRICT_DTYPE=1.  torch.float16 is refused like the reference's constructor refuses it (SUPIR_model.py:23-24)."""
+        torch.float32 (`--ae_dtype fp32`) is computed by the reference in TRUE fp32 (autocast disables itself for float32) -> the fp32
+        service (libsupir_hip_f32.so, supir_amd/ops_f32.py); with weights.FP32_NATIVE off (SUPIR_FP32_NATIVE=0) it is served in bf16 --
+        said once per request with a RuntimeWarning, a RuntimeError under SUPIR_STRICT_DTYPE=1.  torch.float16 is refused like the
+        reference's constructor refuses it (SUPIR_model.py:23-24)."""
         dt = self.ae_dtype
         if dt == torch.float16:
             raise RuntimeError("fp16 cause NaN in AE")
-        if dt != torch.bfloat16 and self._ae_dtype_noted != dt:
+        served = Wt.as_compute_dtype(dt)
+        if served != dt and dt != torch.bfloat16 and self._ae_dtype_noted != dt:
             self._ae_dtype_noted = dt
             Wt.note_downgrade("SUPIRModel.ae_dtype", f"{dt} (test.py --ae_dtype fp32)", "torch.bfloat16",
                               "the reference computes this request in true fp32 (torch.autocast disables itself for float32, "
-                              "SUPIR/models/SUPIR_model.py:41-69); this path has bf16 VAE kernels only (decoder rel-L2 vs fp32 "
-                              "~1e-2 at 512 px).", stacklevel=5)
-        with Wt.compute_dtype(torch.bfloat16):
+                              "SUPIR/models/SUPIR_model.py:41-69); SUPIR_FP32_NATIVE=0 keeps fp32 requests off the fp32 service "
+                              "(decoder rel-L2 vs fp32 ~1e-2 at 512 px).", stacklevel=5)
+        with Wt.compute_dtype(served):
             yield
 
     @torch.no_grad()

@@ -265,7 +265,7 @@ class SpatialTransformer(nn.Module):
         xh = to_nhwc(x)
         B, H, W, C = xh.shape
         n = ops.groupnorm(xh, self.norm.g32(), self.norm.b32(), self.norm.eps, part=gn_part_of(x))
-        fused = FOLD_LAYERNORM and context is not None and all(
+        fused = FOLD_LAYERNORM and ops.has_fused(cdt()) and context is not None and all(
             (not b.disable_self_attn) and (not b.attn2.is_self) for b in self.transformer_blocks)
         if fused:
             t, stats = ops.gemm_ln(n.view(B, H * W, C), self.proj_in.w(), self.proj_in.b32(), emit_stats=True)

@@ -8,11 +8,13 @@
     (libsupir_hip_f16.so: fp16 MFMA operands and activations, fp32 accumulation and epilogues), again the reference's own precision.
     FP16_NATIVE = False (env SUPIR_FP16_NATIVE=0) serves fp16 requests by bf16 instead -- never silently (RuntimeWarning on the
     first call; SUPIR_STRICT_DTYPE=1 turns it into an error);
-  * torch.float32 (`test.py --diff_dtype fp32`; also the constructor default) -> served in **bf16**, which is NARROWER than what the
-    reference computes for that request: `torch.autocast("cuda", dtype=torch.float32)` disables itself ("In CUDA autocast, but the
-    target dtype is not supported. Disabling autocast.") and the reference's networks then run in plain fp32.  There are no fp32
-    kernels on this path (bf16 / fp16 MFMA only), so the first call says so with a RuntimeWarning and SUPIR_STRICT_DTYPE=1 makes
-    it a RuntimeError: a caller that needs true fp32 network arithmetic must use the reference's modules.
+  * torch.float32 (`test.py --diff_dtype fp32`; also the constructor default): the reference computes this request in plain fp32
+    (`torch.autocast("cuda", dtype=torch.float32)` disables itself: "In CUDA autocast, but the target dtype is not supported.
+    Disabling autocast.") -> the fp32 service (libsupir_hip_f32.so, supir_amd/ops_f32.py: exact-fp32 MFMA, fp32 activations, the
+    reference's own weights): the same module code, the plain operator sequence (no LayerNorm folding / fused q|k|v / GroupNorm
+    partials), eager launches only (no hipGraph replay).  A correctness service at 1/16 of the bf16 MFMA rate.
+    weights.FP32_NATIVE = False (env SUPIR_FP32_NATIVE=0) serves fp32 requests by bf16 instead -- never silently (RuntimeWarning on
+    the first call; SUPIR_STRICT_DTYPE=1 turns it into an error).
 
 Optional hipGraph replay: one CFG-doubled step is ~1700 kernel launches issued from Python; `enable_graph()` captures
 them once per (shape, control_scale) and replays the graph on later steps (inputs copied into static buffers).
@@ -83,6 +85,8 @@ class ControlWrapper(nn.Module):
     @property
     def effective_dtype(self):
         """What the kernels compute in for the current `dtype` request."""
+        if self.dtype == torch.float32 and Wt.FP32_NATIVE:
+            return torch.float32
         return torch.float16 if (self.dtype == torch.float16 and FP16_NATIVE) else torch.bfloat16
 
     def load_control_model(self, control_model):
@@ -285,11 +289,11 @@ class ControlWrapper(nn.Module):
             Wt.note_downgrade("ControlWrapper.dtype", "torch.float16 (the reference's default diff_dtype)", "torch.bfloat16",
                               "SUPIR_FP16_NATIVE=0 keeps fp16 requests off the fp16 build of the kernels; bf16 has 7 mantissa bits "
                               "instead of fp16's 10 (per-call rel-L2 vs fp32 ~7e-3 instead of ~1e-3).", stacklevel=4)
-        elif self.dtype not in (torch.float16, torch.bfloat16):
+        elif self.dtype not in (torch.float16, torch.bfloat16) and self.effective_dtype != self.dtype:
             Wt.note_downgrade("ControlWrapper.dtype", f"{self.dtype} (test.py --diff_dtype fp32)", "torch.bfloat16",
                               "the reference computes this request in true fp32 (torch.autocast disables itself for float32, "
-                              "sgm/modules/diffusionmodules/wrappers.py:87); this path has bf16 / fp16 kernels only "
-                              "(per-call rel-L2 vs fp32 ~7e-3).", stacklevel=4)
+                              "sgm/modules/diffusionmodules/wrappers.py:87); SUPIR_FP32_NATIVE=0 keeps fp32 requests off the fp32 "
+                              "service (per-call rel-L2 vs fp32 ~7e-3).", stacklevel=4)
 
     def forward(self, x, t, c, control_scale=1, **kwargs):
         self._note_dtype()
@@ -304,6 +308,6 @@ class ControlWrapper(nn.Module):
         vec = c.get("vector", None) if isinstance(c, dict) else None
         sched = self._use_schedule(kwargs, None if vec is None else int(vec.shape[0]))   # the schedule entry serving this call, or None
         with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
-            if self._graph_on and not kwargs and x.is_cuda:
+            if self._graph_on and not kwargs and x.is_cuda and self.effective_dtype != torch.float32:
                 return self._forward_graph(x, t, c, control_scale, sched)
             return self._forward_eager(x, t, c, control_scale, **kwargs)

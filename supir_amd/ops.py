@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from .weights import HALF_TYPES
+from . import ops_f32 as _f32   # the fp32 forms (libsupir_hip_f32.so): every operator below hands fp32 operands to its namesake there
 
 BF16 = torch.bfloat16
 
@@ -18,7 +19,7 @@ BF16 = torch.bfloat16
 def _k(dtype):
     """Suffix for autotune / choice keys: the fp16 library's kernels are timed and cached separately from the bf16 ones (the bf16
     keys stay exactly what they were)."""
-    return () if dtype == BF16 else ("f16",)
+    return () if dtype == BF16 else ("f32",) if dtype == torch.float32 else ("f16",)
 
 # --------------------------------------------------------------------------------------------- op trace (bench / roofline)
 _TRACE = None
@@ -647,6 +648,9 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
     gn_part=True: returns (out, GnPart or None) -- GroupNorm statistics of `out` per batch of `rows_per_batch` rows, when the tile
     that runs can emit them.  The element type (bf16 or fp16) is that of `a`; every 16-bit operand must share it."""
     DT = a.dtype
+    if DT == torch.float32:
+        return _f32.gemm(a, w, bias, rowbias=rowbias, rows_per_batch=rows_per_batch, residual=residual, act=act, alpha=alpha, out=out,
+                         out_dtype=out_dtype, gn_part=gn_part)
     lib = _lib.load(DT)
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
@@ -891,6 +895,12 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
 USE_QKV = _os.environ.get("SUPIR_FUSED_QKV", "1") != "0"
 
 
+def has_fused(dtype):
+    """Whether the fused forms (LayerNorm folded into its consumers, fused q|k|v, fused cross-attention, GroupNorm partials) exist for this
+    element type: the 16-bit libraries have them, the fp32 service (ops_f32.py) is the plain operator sequence."""
+    return dtype in HALF_TYPES
+
+
 def gemm_qkv_supported(M, N, n_split, K, T):
     """Shape predicate of supir_gemm_bf16_qkv (256 x 160 or 256 x 128 tile of csrc/gemm16.hip)."""
     fits = (N % 160 == 0 and n_split % 160 == 0) or (N % 128 == 0 and n_split % 128 == 0)
@@ -981,6 +991,8 @@ def choose(key, fns, prefer=None, margin=0.1):
 def gemm_t(a, w, bias, B, T, Tpad, out=None, tile=-1):
     """Transposed projection: out[b][n][t] = (a[b*T+t] @ w[n]) (+bias); out is [B, N, Tpad] (zero padded)."""
     DT = a.dtype
+    if DT == torch.float32:
+        return _f32.gemm_t(a, w, bias, B, T, Tpad, out=out)
     lib = _lib.load(DT)
     _check_dev(a, w)
     M, K, lda = _rows_ld(a)
@@ -1025,6 +1037,9 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
     """x [B,H,W,Cin(ld)] bf16 -> [B,OH,OW,Cout]. w [Cout,3,3,Cin] bf16. pad=(top,left); bottom/right implied by out_hw.
     gn_part=True: returns (out, GnPart or None) -- GroupNorm statistics of `out` from the epilogue, when the tile that runs can emit them."""
     DT = x.dtype
+    if DT == torch.float32:
+        return _f32.conv3x3(x, w, bias, stride=stride, pad=pad, upsample=upsample, out_hw=out_hw, rowbias=rowbias, residual=residual, act=act,
+                            alpha=alpha, out=out, gn_part=gn_part)
     lib = _lib.load(DT)
     _check_dev(x, w)
     B, H, W, Cin = x.shape
@@ -1123,6 +1138,8 @@ def flash_attn(q, k, vt, B, H, Tq, Tk, out=None, causal=False):
     """q [B,Tq,>=H*64] k [B,Tk,>=H*64] (views with row stride), vt [B,H*64,Tpad]; returns [B,Tq,H*64].
     causal=True (text towers): query i sees keys j <= i."""
     DT = q.dtype
+    if DT == torch.float32:
+        return _f32.flash_attn(q, k, vt, B, H, Tq, Tk, out=out, causal=causal)
     lib = _lib.load(DT)
     _check_dev(q, k, vt)
     assert DT in HALF_TYPES and k.dtype == DT and vt.dtype == DT
@@ -1218,6 +1235,8 @@ def flash_attn_d512(q, k, vt, Tk, out=None, splits=0):
     splits: key splits of supir_flash_attn_d512_split (0 = the library's choice: enough to fill the 256 CUs -- 2 at 16 384 tokens, 8 at
     4096; 1 = one pass over all keys per workgroup)."""
     DT = q.dtype
+    if DT == torch.float32:
+        return _f32.flash_attn_d512(q, k, vt, Tk, out=out)
     lib = _lib.load(DT)
     _check_dev(q, k, vt)
     assert DT in HALF_TYPES and k.dtype == DT and vt.dtype == DT
@@ -1244,6 +1263,8 @@ def softmax_rows(s, scale, out=None, valid=None, dtype=None):
     """softmax over the first `valid` columns of fp32 scores [rows, Tpad]; remaining columns of the 16-bit output (`dtype`,
     default: that of `out`, else bf16) are zero."""
     DT = out.dtype if out is not None else (BF16 if dtype is None else dtype)
+    if DT == torch.float32:
+        return _f32.softmax_rows(s, scale, out=out, valid=valid)
     lib = _lib.load(DT)
     _check_dev(s)
     rows, Tp = s.shape
@@ -1281,6 +1302,9 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
     """GroupNorm(32) over channels-last x (optionally the channel concat [x | x2]); see supir_groupnorm_nhwc.
     part / part2 = GnPart of x / x2 from their producers: one launch, no statistics pass (supir_groupnorm_nhwc_parts)."""
     DT = x.dtype
+    if DT == torch.float32:
+        return _f32.groupnorm(x, gamma, beta, eps, silu=silu, x2=x2, mod_g=mod_g, mod_b=mod_b, control_scale=control_scale, x1raw=x1raw,
+                              x2raw=x2raw, out=out, given=given)
     lib = _lib.load(DT)
     _check_dev(x, gamma, beta)
     assert DT in HALF_TYPES and all(t is None or t.dtype == DT for t in (x2, mod_g, mod_b, x1raw, x2raw, out))
@@ -1354,6 +1378,8 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
     DT = x.dtype
+    if DT == torch.float32:
+        return _f32.layernorm(x, gamma, beta, eps, out=out)
     lib = _lib.load(DT)
     _check_dev(x, gamma, beta)
     assert DT in HALF_TYPES and (out is None or out.dtype == DT)
@@ -1374,6 +1400,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 def conv3x3_smallcin(x_nchw, w, bias, add=None, out=None, dtype=None):
     """fp32 NCHW [B,Cin<=8,H,W] -> 16-bit [B,H,W,Cout] (`dtype`; default: that of `out` / `add`, else bf16); w fp32 [Cout,Cin,3,3]."""
     DT = out.dtype if out is not None else add.dtype if add is not None else (BF16 if dtype is None else dtype)
+    if DT == torch.float32:
+        return _f32.conv3x3_smallcin(x_nchw, w, bias, add=add, out=out)
     lib = _lib.load(DT)
     assert DT in HALF_TYPES and (add is None or add.dtype == DT)
     _check_dev(x_nchw, w)
@@ -1399,6 +1427,8 @@ def conv3x3_smallcin(x_nchw, w, bias, add=None, out=None, dtype=None):
 def conv3x3_smallcout(x, w9, bias, out=None):
     """bf16 [B,H,W,Cin] -> fp32 NCHW [B,Cout,H,W]; w9 bf16 [9,Cout,Cin]."""
     DT = x.dtype
+    if DT == torch.float32:
+        return _f32.conv3x3_smallcout(x, w9, bias, out=out)
     lib = _lib.load(DT)
     _check_dev(x, w9)
     B, H, W, Cin = x.shape

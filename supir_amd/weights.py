@@ -11,9 +11,10 @@ import torch
 BF16 = torch.bfloat16
 HALF_TYPES = (torch.bfloat16, torch.float16)
 
-# The 16-bit element type the kernels run in ("compute dtype").  bf16 is the product default (libsupir_hip.so); torch.float16
+# The element type the kernels run in ("compute dtype").  bf16 is the product default (libsupir_hip.so); torch.float16
 # selects libsupir_hip_f16.so -- the same kernels built with fp16 MFMA operands (csrc/common.h, SUPIR_F16) -- for callers that ask
-# for the reference's default diff_dtype (options/SUPIR_v0.yaml:5, test.py:67-68: model.model.dtype = torch.float16).  The value
+# for the reference's default diff_dtype (options/SUPIR_v0.yaml:5, test.py:67-68: model.model.dtype = torch.float16); torch.float32
+# selects the fp32 service (libsupir_hip_f32.so) for `--diff_dtype fp32` / `--ae_dtype fp32` requests.  The value
 # is a per-call scope set by the module that owns the request (ControlWrapper / the VAE entry points), never a process global
 # that outlives a call: activations created inside the scope, the derived weight layouts (Prep caches key on it) and the library
 # an op dispatches to (by the dtype of its operands) all follow it.
@@ -25,10 +26,18 @@ def cdt():
     return _CDT[-1]
 
 
+# fp32 requests (`--diff_dtype fp32` / `--ae_dtype fp32`; the reference's constructor defaults) run on the fp32 service
+# (libsupir_hip_f32.so, ops_f32.py: exact-fp32 MFMA, the reference's own arithmetic for that request) when True; SUPIR_FP32_NATIVE=0
+# serves them by bf16 instead -- never silently (note_downgrade).
+FP32_NATIVE = __import__("os").environ.get("SUPIR_FP32_NATIVE", "1") == "1"
+
+
 def as_compute_dtype(dtype):
-    """Map a requested module dtype to the kernel element type: fp16 stays fp16, everything else (bf16, fp32) is served by bf16.
-    An fp32 request is a DOWNGRADE (the reference computes such a request in fp32, see note_downgrade): callers that own a
-    request say so through note_downgrade before opening the scope."""
+    """Map a requested module dtype to the kernel element type: fp16 stays fp16, fp32 stays fp32 (FP32_NATIVE), everything else is bf16.
+    With FP32_NATIVE off an fp32 request is a DOWNGRADE (the reference computes such a request in fp32, see note_downgrade): callers
+    that own a request say so through note_downgrade before opening the scope."""
+    if dtype == torch.float32 and FP32_NATIVE:
+        return torch.float32
     return torch.float16 if dtype == torch.float16 else BF16
 
 

@@ -8,8 +8,8 @@ from supir_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "supir_hip.h")).read()
+def _header_functions(name="supir_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     fns = {}
     for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(supir_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
@@ -42,6 +42,44 @@ def test_f16_library_exports_the_same_surface():
     assert lib16.supir_gemm_bf16(None, None, None, 64, 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 0, 1.0, -1, None) == -1
     fake = 0x10000
     assert lib16.supir_gemm_bf16(fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, None, 0, 0, 0, 1.0, 32, None) == -2
+
+
+def test_f32_library_exports_its_own_table():
+    """libsupir_hip_f32.so (csrc/f32, include/supir_hip_f32.h): loads next to the other two, exports every symbol its header declares with
+    the argument counts of the ctypes mirror, the struct mirror has the C struct's size, and arguments are validated before any launch."""
+    import ctypes
+    import torch
+    lib32 = _lib.load(torch.float32)
+    assert lib32 is _lib.load_f32() and lib32 is not _lib.load() and lib32 in _lib.loaded()
+    fns = _header_functions("supir_hip_f32.h")
+    assert set(fns) == set(_lib.SIGNATURES_F32) | {"supir_abi_version", "supir_target_arch", "supir_elem_type", "supir_last_hip_error",
+                                                   "supir_hip_error_string"}
+    for name, n in fns.items():
+        assert hasattr(lib32, name), f"{name} declared in supir_hip_f32.h but not exported"
+        if name in _lib.SIGNATURES_F32:
+            assert len(_lib.SIGNATURES_F32[name]) == n, (name, n)
+    assert lib32.supir_abi_version() == _lib.ABI_VERSION and lib32.supir_target_arch() == b"gfx950" and lib32.supir_elem_type() == b"f32"
+    assert not hasattr(lib32, "supir_gemm_bf16")              # the 16-bit table is not here: nothing can reach it with fp32 buffers
+    # struct layout: 6 pointers, 10 ints, 2 ints + float + 2 ints, 6 longs, 10 ints  (natural alignment)
+    assert ctypes.sizeof(_lib.F32GemmDesc) == 6 * 8 + 10 * 4 + 5 * 4 + 4 + 6 * 8 + 10 * 4
+    fake = 0x10000
+    d = _lib.F32GemmDesc(A=fake, W=fake, C=fake, kind=0, M=64, N=64, K=64, lda=64, ldw=64, ldc=64, nz0=1, nz1=1, alpha=1.0)
+    d.K = 0
+    assert lib32.supir_f32_gemm(ctypes.byref(d), None) == -1
+    d.K, d.lda = 64, 32
+    assert lib32.supir_f32_gemm(ctypes.byref(d), None) == -2            # leading dimension below K
+    d.lda, d.act = 64, 2
+    assert lib32.supir_f32_gemm(ctypes.byref(d), None) == -1            # GEGLU is supir_f32_geglu, not an epilogue
+    d.act, d.nz0, d.bias = 0, 2, fake
+    assert lib32.supir_f32_gemm(ctypes.byref(d), None) == -1            # batched launches take no bias / residual
+    assert lib32.supir_f32_gemm(None, None) == -1
+    assert lib32.supir_f32_geglu(fake, fake, 8, 130, 130, 65, 32, None) == -2
+    assert lib32.supir_f32_softmax_rows(fake, fake, 4, 100, 64, 128, 128, 1.0, None) == -1
+    assert lib32.supir_f32_layernorm(None, None, None, None, 4, 64, 64, 64, 1e-5, None) == -1
+    assert lib32.supir_f32_groupnorm(fake, None, None, None, 1, 16, 48, 48, 48, 0, fake, fake, 1e-5, 0, None, None, 0, 1.0, fake, 48, fake, 1 << 20,
+                                     None) == -2                          # C % 32
+    assert lib32.supir_f32_groupnorm(fake, None, None, None, 1, 16, 64, 64, 64, 0, fake, fake, 1e-5, 0, None, None, 0, 1.0, fake, 64, fake, 64,
+                                     None) == -1                          # workspace too small
 
 
 def test_ctypes_signatures_match_header():

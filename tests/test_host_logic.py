@@ -386,8 +386,8 @@ def test_fp16_request_is_not_silently_served_by_bf16(monkeypatch):
 def test_fp16_request_runs_in_an_fp16_compute_scope(monkeypatch):
     """With the fp16 build enabled, a ControlWrapper whose dtype is torch.float16 runs its networks inside an fp16 compute scope
     (weights.compute_dtype): activations / derived weight layouts are fp16 and ops dispatch to libsupir_hip_f16.so by operand dtype;
-    no warning; bf16 and fp32 requests keep the bf16 scope (the fp32 one with a RuntimeWarning: it is a downgrade); the scope ends with
-    the call."""
+    no warning; an fp32 request runs in an fp32 scope (the fp32 service), or -- with that service switched off -- in the bf16 scope with
+    a RuntimeWarning (it is then a downgrade); the scope ends with the call."""
     import warnings
     from supir_amd import weights as Wt
     from supir_amd.modules import wrappers
@@ -413,7 +413,7 @@ def test_fp16_request_runs_in_an_fp16_compute_scope(monkeypatch):
 
     x, t = torch.ones(2, 4, 8, 8), torch.zeros(2, dtype=torch.int64)
     c = {"crossattn": torch.zeros(2, 77, 8), "vector": torch.zeros(2, 16), "control": torch.ones(2, 4, 8, 8)}
-    for req, want in ((torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)):
+    def run(req, want):
         del seen[:]
         w = ControlWrapper(Net(), dtype=req)
         w.load_control_model(Ctl())
@@ -422,20 +422,25 @@ def test_fp16_request_runs_in_an_fp16_compute_scope(monkeypatch):
             warnings.simplefilter("always")
             out = w(x, t, c)
         assert out.dtype == torch.float32
-        if req == torch.float32:
-            # an fp32 request is computed by the reference in TRUE fp32 (autocast disables itself for float32): bf16 is a downgrade
-            # and is announced, once per request
-            assert len(rec) == 1 and issubclass(rec[0].category, RuntimeWarning) and "torch.float32" in str(rec[0].message)
-            with warnings.catch_warnings(record=True) as again:
-                warnings.simplefilter("always")
-                w(x, t, c)
-            assert not again
-            del seen[2:]
-        else:
-            assert not rec
+        return w, rec
+
+    # fp32 is honoured too (weights.FP32_NATIVE: the fp32 service, libsupir_hip_f32.so): the scope is fp32, nothing to announce
+    for req, want in ((torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)):
+        w, rec = run(req, want)
+        assert not rec
         assert seen == [("ctl", want), ("net", want, want, want)]
         assert Wt.cdt() == torch.bfloat16                      # scope closed
         assert list(w._resident) == [((2, 77, 8), (2, 16), want)]
+    # with the fp32 service switched off (SUPIR_FP32_NATIVE=0) an fp32 request is computed in bf16: a downgrade of what the reference
+    # computes for it (autocast disables itself for float32), announced once per request
+    monkeypatch.setattr(Wt, "FP32_NATIVE", False)
+    w, rec = run(torch.float32, torch.bfloat16)
+    assert len(rec) == 1 and issubclass(rec[0].category, RuntimeWarning) and "torch.float32" in str(rec[0].message)
+    with warnings.catch_warnings(record=True) as again:
+        warnings.simplefilter("always")
+        w(x, t, c)
+    assert not again
+    assert seen[:2] == [("ctl", torch.bfloat16), ("net", torch.bfloat16, torch.bfloat16, torch.bfloat16)]
     # one module driven under both scopes keeps separate derived layouts (Prep keys on the compute dtype)
     lin = Linear(8, 8)
     torch.nn.init.normal_(lin.weight)

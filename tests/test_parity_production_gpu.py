@@ -180,6 +180,44 @@ def test_batchify_sample_config1_vs_oracle(model, restoration_scale):
     assert errs["image_psnr_db"] >= 40.0
 
 
+def test_batchify_sample_config1_fp32_service_vs_oracle(model):
+    """`--ae_dtype fp32 --diff_dtype fp32` (test.py:66-67; the reference then computes in plain fp32, SUPIR_model.py:41-69 and
+    wrappers.py:87): BASELINE config 1 end to end on the fp32 service (libsupir_hip_f32.so) at FULL depth against the fp32 oracle, every
+    stage.  No ATen-bf16 floor to measure against here: the bars are absolute and three orders of magnitude below the bf16 ones."""
+    import warnings
+    from oracle import supir_oracle as O
+    P, lat, steps = 512, 64, 2
+    x = T("cfg1.img", (1, 3, P, P), scale=0.5).clamp(-1, 1)
+    c, uc = _cond()
+    noises = {"posterior": T("cfg1.post", (1, 4, lat, lat)), "init": T("cfg1.init", (1, 4, lat, lat)),
+              "steps": [T(f"cfg1.eps{i}", (1, 4, lat, lat)) for i in range(steps)]}
+    model.model.enable_graph(False)
+    saved = (model.ae_dtype, model.model.dtype)
+    model.ae_dtype = model.model.dtype = torch.float32
+    try:
+        with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            out, mid = model.batchify_sample(x, cond=(c, uc), num_steps=steps, restoration_scale=4.0, s_churn=5, s_noise=1.01, cfg_scale=4.0,
+                                             control_scale=1.0, seed=1234, color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=1.0,
+                                             noises=dict(noises), return_intermediates=True)
+        assert not [r for r in rec if issubclass(r.category, RuntimeWarning)], [str(r.message) for r in rec]
+    finally:
+        model.ae_dtype, model.model.dtype = saved
+    with torch.no_grad():
+        ref, rmid = O.batchify_sample(_model_sd(model), x, c, uc, {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v])
+                                                                  for k, v in noises.items()}, num_steps=steps, s_churn=5, s_noise=1.01,
+                                      restoration_scale=4.0, cfg_scale=4.0, cfg_scale_start=1.0, table=model.denoiser.sigmas.to(DEV))
+        ref = O.wavelet_reconstruction(ref, rmid["x_stage1"])
+    errs = dict(z=rel_l2(mid["z"], rmid["z"]), x_stage1=rel_l2(mid["x_stage1"], rmid["x_stage1"]),
+                z_stage1=rel_l2(mid["z_stage1"], rmid["z_stage1"]), latent=rel_l2(mid["samples"], rmid["samples"]),
+                image=rel_l2(out, ref), image_psnr_db=psnr(out, ref))
+    record("batchify_sample_config1_512px_2steps_fp32_service", **errs)
+    assert out.shape == (1, 3, P, P) and out.dtype == torch.float32 and torch.isfinite(out).all()
+    for k in ("z", "x_stage1", "z_stage1", "latent", "image"):
+        assert errs[k] <= 2e-5, (k, errs[k])
+    assert errs["image_psnr_db"] >= 90.0
+
+
 def test_batchify_sample_config2_50_steps_vs_oracle_bf16(model):
     """BASELINE config 2 (1024^2, 50 EDM steps, the bench workload) with every noise injected: the product path against the
     oracle under torch.autocast(bf16) -- the reference's own arithmetic on this GPU -- and both against the

@@ -233,9 +233,12 @@ def test_reference_test_py_verbatim_loading_half_params(launcher, tmp_path):
     assert all(p.dtype == torch.float16 for p in model.parameters() if p.is_floating_point())
 
 
-def test_fp32_requests_are_not_served_silently(launcher, tmp_path):
-    """`--diff_dtype fp32 --ae_dtype fp32` (test.py:52-53): the reference computes those in true fp32 (autocast disables itself);
-    this path serves bf16 and must say so -- RuntimeWarning by default, RuntimeError under SUPIR_STRICT_DTYPE=1."""
+def test_fp32_requests_are_not_served_silently(launcher, tmp_path, monkeypatch):
+    """`--diff_dtype fp32 --ae_dtype fp32` (test.py:52-53): the reference computes those in true fp32 (autocast disables itself).  With
+    the fp32 service switched off (SUPIR_FP32_NATIVE=0) this path serves bf16 and must say so -- RuntimeWarning by default, RuntimeError
+    under SUPIR_STRICT_DTYPE=1.  (Switched on -- the default -- the request is honoured: tests/test_fp32_gpu.py.)"""
+    from supir_amd import weights as Wt
+    monkeypatch.setattr(Wt, "FP32_NATIVE", False)
     with pytest.warns(RuntimeWarning) as rec:
         g, save_dir, direct, _ = _run_test_py(launcher, tmp_path, ["--diff_dtype", "fp32", "--ae_dtype", "fp32"])
     msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]

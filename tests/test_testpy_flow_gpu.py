@@ -161,6 +161,9 @@ def test_testpy_call_sequence_on_the_gpu(tok, tmp_path):
 
 
 def test_fp32_requests_warn_or_raise_on_the_gpu(tok, tmp_path, monkeypatch):
+    """With the fp32 service switched off (SUPIR_FP32_NATIVE=0); the honoured form is tests/test_fp32_gpu.py."""
+    from supir_amd import weights as Wt
+    monkeypatch.setattr(Wt, "FP32_NATIVE", False)
     with pytest.warns(RuntimeWarning) as rec:
         _flow(tmp_path, "fp32", ae_dtype=torch.float32, diff_dtype=torch.float32, steps=2)
     msgs = [str(w.message) for w in rec]

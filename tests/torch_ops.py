@@ -145,6 +145,10 @@ def gemm_qkv(a, w, bias, B, T, n_split, *, ln=None, colsum=None, ln_eps=1e-5, ou
     return qk, _transposed(y[:, n_split:], B, T, T, DT, out_vt)
 
 
+def has_fused(dtype):
+    return True
+
+
 def choose(key, fns, prefer=None, margin=0.1):
     return prefer if (prefer is not None and PREFER_FUSED_QKV) else 0
 
@@ -368,7 +372,7 @@ def bicubic_resize_f32(x, h0, w0, want_u8=True):
 _NAMES = ["gemm", "gemm_ln", "gemm_qkv", "gemm_qkv_supported", "choose", "gemm_t", "rowstats_finalize", "conv3x3", "flash_attn",
           "xattn_q", "xattn_q_supported", "use_flash_d512", "flash_attn_d512", "softmax_rows", "groupnorm_stats", "groupnorm", "layernorm", "conv3x3_smallcin",
           "conv3x3_smallcout", "pointwise_nchw", "edm_step_pre", "edm_step_post", "wavelet_decomposition", "WeightPrefetch",
-          "set_prefetch", "paired_run", "start_trace", "stop_trace", "RowStats"]
+          "set_prefetch", "paired_run", "start_trace", "stop_trace", "RowStats", "has_fused"]
 
 
 @contextlib.contextmanager
