@@ -7,7 +7,7 @@
  * matrix instruction of gfx950 (v_mfma_f32_16x16x4_f32: fp32 operands, fp32 accumulation, bitwise an fmaf chain; 157 TFLOP/s
  * dense, 1/16 of the bf16 rate).  It is a CORRECTNESS path: one general tile kernel instead of the tuned families of the 16-bit
  * libraries, activations in fp32 NHWC, weights in the reference's own fp32 values.  The host mirror (supir_amd/ops_f32.py) builds every
- * operator of the path from the five launches below; attention is batched GEMM -> row softmax -> batched GEMM with the fp32 score matrix
+ * operator of the path from the launches below; attention is batched GEMM -> row softmax -> batched GEMM with the fp32 score matrix
  * materialised in HBM (1.3 GB for the largest SDXL self-attention at a 1024^2 image; 288 GB per GPU).
  *
  * Conventions: as include/supir_hip.h (device pointers unless said otherwise, `stream` = hipStream_t, every call returns SUPIR_OK or a
@@ -70,10 +70,18 @@ int supir_f32_softmax_rows(const float* S, float* P, long rows, int T, int Tpad,
 /* GroupNorm(32) over NHWC fp32: the argument list and semantics of supir_groupnorm_nhwc (include/supir_hip.h) -- optional SiLU (act = 1),
  * optional channel concat of two sources (C1 channels from x1, C - C1 from x2; a group may straddle the seam), optional ZeroSFT modulation
  * out = GN(x) * (mod_g + 1) + mod_b and control_scale lerp against the raw concat (x1raw / x2raw, NULL -> x1 / x2).  Statistics in fp64.
- * workspace: B * 32 * 64 * 2 doubles (contents undefined before and after). */
+ * workspace: (B * 32 * 64 * 2 + B * 32 * 2) doubles (contents undefined before and after).
+ * given_mean_var: NULL (this tensor's own statistics) or externally pooled (mean, biased variance) per batch element and group, fp32
+ * [B][32][2] -- the tiled VAE's pooled GroupNorm (SUPIR/utils/tilevae.py:524-553, 610-640). */
 int supir_f32_groupnorm(const float* x1, const float* x2, const float* x1raw, const float* x2raw, int B, int HW, int C, int C1, int ld1,
                         int ld2, const float* gamma, const float* beta, float eps, int act, const float* mod_g, const float* mod_b,
-                        int ldm, float control_scale, float* out, int ldo, double* workspace, size_t workspace_bytes, void* stream);
+                        int ldm, float control_scale, float* out, int ldo, double* workspace, size_t workspace_bytes,
+                        const float* given_mean_var, void* stream);
+
+/* (sum, sum of squares) per batch element and group of an NHWC fp32 tensor, fp64 [B][32][2]: the per-tile statistics the tiled VAE pools
+ * (supir_groupnorm_stats of the 16-bit header, in fp64).  workspace as supir_f32_groupnorm. */
+int supir_f32_groupnorm_stats(const float* x, int B, int HW, int C, int ld, double* sums, double* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* LayerNorm over the last dimension (attention.py:376-486 norm1..3; two-pass mean / variance in fp32). y may alias x. */
 int supir_f32_layernorm(const float* x, float* y, const float* gamma, const float* beta, int rows, int C, int ldx, int ldy, float eps,

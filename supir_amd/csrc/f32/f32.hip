@@ -325,8 +325,10 @@ extern "C" int supir_f32_layernorm(const float* x, float* y, const float* gamma,
 #define GN_SLICES 64
 struct GnP {
     const float *x1, *x2, *x1raw, *x2raw, *gamma, *beta, *mod_g, *mod_b;
+    const float* given;      // externally pooled (mean, biased variance) per (batch, group), or NULL
     float* out;
     double* ws;
+    double* sums_out;        // supir_f32_groupnorm_stats: (sum, sum of squares) per (batch, group) instead of (mean, rstd)
     int B, HW, C, C1, ld1, ld2, ldm, ldo, act, ns;
     float eps, control_scale;
 };
@@ -360,14 +362,26 @@ __global__ __launch_bounds__(256) void f32_gn_stats_kernel(const GnP p) {
 __global__ void f32_gn_finalize_kernel(const GnP p) {
     const int bg = blockIdx.x * blockDim.x + threadIdx.x;
     if (bg >= p.B * 32) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < p.ns; ++i) {
-        s += p.ws[((size_t)bg * GN_SLICES + i) * 2];
-        q += p.ws[((size_t)bg * GN_SLICES + i) * 2 + 1];
+    double mean, var;
+    if (p.given) {
+        mean = (double)p.given[bg * 2];
+        var = (double)p.given[bg * 2 + 1];
+    } else {
+        double s = 0.0, q = 0.0;
+        for (int i = 0; i < p.ns; ++i) {
+            s += p.ws[((size_t)bg * GN_SLICES + i) * 2];
+            q += p.ws[((size_t)bg * GN_SLICES + i) * 2 + 1];
+        }
+        if (p.sums_out) {
+            p.sums_out[bg * 2] = s;
+            p.sums_out[bg * 2 + 1] = q;
+            return;
+        }
+        const double n = (double)p.HW * (p.C / 32);
+        mean = s / n;
+        var = q / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
     }
-    const double n = (double)p.HW * (p.C / 32), mean = s / n;
-    double var = q / n - mean * mean;
-    var = var > 0.0 ? var : 0.0;
     double* mr = p.ws + (size_t)p.B * 32 * GN_SLICES * 2 + (size_t)bg * 2;
     mr[0] = mean;
     mr[1] = 1.0 / sqrt(var + (double)p.eps);
@@ -395,14 +409,15 @@ __global__ __launch_bounds__(256) void f32_gn_apply_kernel(const GnP p) {
 
 extern "C" int supir_f32_groupnorm(const float* x1, const float* x2, const float* x1raw, const float* x2raw, int B, int HW, int C, int C1, int ld1,
                                    int ld2, const float* gamma, const float* beta, float eps, int act, const float* mod_g, const float* mod_b,
-                                   int ldm, float control_scale, float* out, int ldo, double* workspace, size_t workspace_bytes, void* stream) {
+                                   int ldm, float control_scale, float* out, int ldo, double* workspace, size_t workspace_bytes,
+                                   const float* given_mean_var, void* stream) {
     if (!x1 || !gamma || !beta || !out || !workspace || B <= 0 || HW <= 0 || C <= 0) return SUPIR_ERR_ARG;
     if (C % 32 || C1 <= 0 || C1 > C || (C1 < C && !x2) || ld1 < C1 || (x2 && ld2 < C - C1) || ldo < C) return SUPIR_ERR_SHAPE;
     if ((mod_g == nullptr) != (mod_b == nullptr) || (mod_g && ldm < C) || (act != 0 && act != 1)) return SUPIR_ERR_ARG;
     if (workspace_bytes < ((size_t)B * 32 * GN_SLICES * 2 + (size_t)B * 32 * 2) * sizeof(double)) return SUPIR_ERR_ARG;
     GnP p;
     p.x1 = x1; p.x2 = x2; p.x1raw = x1raw; p.x2raw = x2raw; p.gamma = gamma; p.beta = beta; p.mod_g = mod_g; p.mod_b = mod_b;
-    p.out = out; p.ws = workspace;
+    p.out = out; p.ws = workspace; p.given = given_mean_var; p.sums_out = nullptr;
     p.B = B; p.HW = HW; p.C = C; p.C1 = C1; p.ld1 = ld1; p.ld2 = ld2; p.ldm = ldm; p.ldo = ldo; p.act = act;
     p.eps = eps; p.control_scale = control_scale;
     const long per_group = (long)HW * (C / 32);
@@ -410,14 +425,37 @@ extern "C" int supir_f32_groupnorm(const float* x1, const float* x2, const float
     p.ns = p.ns < 1 ? 1 : p.ns > GN_SLICES ? GN_SLICES : p.ns;
     p.ns = p.ns > HW ? HW : p.ns;
     hipStream_t s = (hipStream_t)stream;
-    F32_LAUNCH(f32_gn_stats_kernel, dim3(B * 32, p.ns), dim3(256), 0, s, p);
-    int rc = F32_STATUS();
-    if (rc != SUPIR_OK) return rc;
+    int rc = SUPIR_OK;
+    if (!given_mean_var) {
+        F32_LAUNCH(f32_gn_stats_kernel, dim3(B * 32, p.ns), dim3(256), 0, s, p);
+        rc = F32_STATUS();
+        if (rc != SUPIR_OK) return rc;
+    }
     F32_LAUNCH(f32_gn_finalize_kernel, dim3((B * 32 + 63) / 64), dim3(64), 0, s, p);
     rc = F32_STATUS();
     if (rc != SUPIR_OK) return rc;
     const size_t total = (size_t)B * HW * C;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 262144 ? 262144 : (total + 255) / 256);
     F32_LAUNCH(f32_gn_apply_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return F32_STATUS();
+}
+
+extern "C" int supir_f32_groupnorm_stats(const float* x, int B, int HW, int C, int ld, double* sums, double* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    if (!x || !sums || !workspace || B <= 0 || HW <= 0 || C <= 0) return SUPIR_ERR_ARG;
+    if (C % 32 || ld < C) return SUPIR_ERR_SHAPE;
+    if (workspace_bytes < ((size_t)B * 32 * GN_SLICES * 2 + (size_t)B * 32 * 2) * sizeof(double)) return SUPIR_ERR_ARG;
+    GnP p = {};
+    p.x1 = x; p.ws = workspace; p.sums_out = sums;
+    p.B = B; p.HW = HW; p.C = C; p.C1 = C; p.ld1 = ld;
+    const long per_group = (long)HW * (C / 32);
+    p.ns = (int)((per_group + 16383) / 16384);
+    p.ns = p.ns < 1 ? 1 : p.ns > GN_SLICES ? GN_SLICES : p.ns;
+    p.ns = p.ns > HW ? HW : p.ns;
+    hipStream_t s = (hipStream_t)stream;
+    F32_LAUNCH(f32_gn_stats_kernel, dim3(B * 32, p.ns), dim3(256), 0, s, p);
+    const int rc = F32_STATUS();
+    if (rc != SUPIR_OK) return rc;
+    F32_LAUNCH(f32_gn_finalize_kernel, dim3((B * 32 + 63) / 64), dim3(64), 0, s, p);
     return F32_STATUS();
 }

@@ -1282,7 +1282,9 @@ def softmax_rows(s, scale, out=None, valid=None, dtype=None):
 
 # --------------------------------------------------------------------------------------------- norms
 def groupnorm_stats(x):
-    """(sum, sum of squares) per (batch, group) of a channels-last tensor: fp32 [B, 32, 2]."""
+    """(sum, sum of squares) per (batch, group) of a channels-last tensor: fp32 [B, 32, 2] (fp64 from the fp32 service)."""
+    if x.dtype == torch.float32:
+        return _f32.groupnorm_stats(x)
     lib = _lib.load(x.dtype)
     _check_dev(x)
     assert x.dtype in HALF_TYPES

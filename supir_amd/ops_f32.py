@@ -198,9 +198,10 @@ def _gn_ws(B, device):
 
 def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=None, control_scale=1.0, x1raw=None, x2raw=None, out=None,
               given=None, part=None, part2=None):
-    """ops.groupnorm in fp32 (statistics in fp64; GroupNorm partials of a producer are a 16-bit-path fusion and are ignored)."""
-    _check(x, gamma, beta, x2, mod_g, mod_b, x1raw, x2raw, out)
-    assert given is None
+    """ops.groupnorm in fp32 (statistics in fp64; GroupNorm partials of a producer are a 16-bit-path fusion and are ignored).
+    given: fp32 [B, 32, 2] externally pooled (mean, biased variance) -- the tiled VAE (utils/tilevae.py pooled_groupnorm)."""
+    _check(x, gamma, beta, x2, mod_g, mod_b, x1raw, x2raw, out, given)
+    assert given is None or (given.shape == (x.shape[0], 32, 2) and given.is_contiguous())
     lib = _lib.load_f32()
     B = x.shape[0]
     HW = int(math.prod(x.shape[1:-1]))
@@ -226,8 +227,23 @@ def groupnorm(x, gamma, beta, eps, *, silu=False, x2=None, mod_g=None, mod_b=Non
     ws = _gn_ws(B, x.device)
     rc = lib.supir_f32_groupnorm(x.data_ptr(), _p(x2), _p(x1raw), _p(x2raw), B, HW, C, C1, ld1, ld2, gamma.data_ptr(), beta.data_ptr(), eps,
                                  1 if silu else 0, _p(mod_g), _p(mod_b), ldm, float(control_scale), out.data_ptr(), ldo, ws.data_ptr(),
-                                 ws.numel() * 8, _stream())
+                                 ws.numel() * 8, _p(given), _stream())
     _lib.check(rc, "supir_f32_groupnorm", lib)
+    return out
+
+
+def groupnorm_stats(x):
+    """(sum, sum of squares) per (batch, group) of a channels-last fp32 tensor: FP64 [B, 32, 2] (utils/tilevae.py pool_statistics works in
+    fp64 either way; the 16-bit path hands it fp32 sums)."""
+    _check(x)
+    lib = _lib.load_f32()
+    B = x.shape[0]
+    HW = int(math.prod(x.shape[1:-1]))
+    _, C, ld = _rows_ld(x)
+    ws = _gn_ws(B, x.device)
+    out = torch.empty(B, 32, 2, dtype=torch.float64, device=x.device)
+    _lib.check(lib.supir_f32_groupnorm_stats(x.data_ptr(), B, HW, C, ld, out.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream()),
+               "supir_f32_groupnorm_stats", lib)
     return out
 
 

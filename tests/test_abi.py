@@ -77,9 +77,10 @@ def test_f32_library_exports_its_own_table():
     assert lib32.supir_f32_softmax_rows(fake, fake, 4, 100, 64, 128, 128, 1.0, None) == -1
     assert lib32.supir_f32_layernorm(None, None, None, None, 4, 64, 64, 64, 1e-5, None) == -1
     assert lib32.supir_f32_groupnorm(fake, None, None, None, 1, 16, 48, 48, 48, 0, fake, fake, 1e-5, 0, None, None, 0, 1.0, fake, 48, fake, 1 << 20,
-                                     None) == -2                          # C % 32
+                                     None, None) == -2                    # C % 32
     assert lib32.supir_f32_groupnorm(fake, None, None, None, 1, 16, 64, 64, 64, 0, fake, fake, 1e-5, 0, None, None, 0, 1.0, fake, 64, fake, 64,
-                                     None) == -1                          # workspace too small
+                                     None, None) == -1                    # workspace too small
+    assert lib32.supir_f32_groupnorm_stats(fake, 1, 16, 64, 32, fake, fake, 1 << 20, None) == -2     # leading dimension below C
 
 
 def test_ctypes_signatures_match_header():

@@ -325,3 +325,36 @@ def test_vae_fp32_vs_fp32_oracle():
     assert m32.dtype == F32 and d32.dtype == F32 and d32.shape == (1, 3, 320, 192)
     assert em <= 1e-5 and ed <= 1e-5, (em, ed)
     assert ebf >= 100 * em
+
+
+def test_tiled_vae_fp32_vs_oracle():
+    """`--use_tile_vae --ae_dtype fp32` (test.py:65-67): the VAEHook task queue with pooled GroupNorm statistics (SUPIR/utils/tilevae.py:524-553,
+    610-640) in an fp32 scope -- per-tile (sum, sum of squares) in fp64 from supir_f32_groupnorm_stats, the pooled (mean, variance) handed
+    back to supir_f32_groupnorm -- against the oracle's tiled forward: decoder on a 48 x 40 latent in 16-latent tiles, encoder on a
+    256 x 320 image in 128-px tiles."""
+    from oracle import supir_oracle as O
+    from supir_amd.utils.tilevae import VAEHook
+    vae = build_vae(device=DEV)
+    sd = dict(vae.state_dict())
+    z = synth_tensor("vae.tz", (1, 4, 48, 40)).to(DEV)
+    img = synth_tensor("vae.timg", (1, 3, 256, 320), scale=0.5).clamp(-1, 1).to(DEV)
+    x = rnd(3, 24, 24, 128) * 2 + 0.5
+    with torch.no_grad():
+        sums = ops.groupnorm_stats(x)
+        assert sums.dtype == F64 and sums.shape == (3, 32, 2)
+        xg = x.double().reshape(3, 576, 32, 4)
+        assert torch.allclose(sums[..., 0], xg.sum(dim=(1, 3)), rtol=1e-12) and torch.allclose(sums[..., 1], (xg * xg).sum(dim=(1, 3)), rtol=1e-12)
+        given = torch.stack([rnd(3, 32, seed=1) * 0.1, rnd(3, 32, seed=2).abs() + 0.5], -1).contiguous()
+        g, b = rnd(128, seed=3) * 0.2 + 1, rnd(128, seed=4) * 0.2
+        ref = (xg - given[:, None, :, None, 0].double()) / torch.sqrt(given[:, None, :, None, 1].double() + 1e-6)
+        ref = ref.reshape(3, 24, 24, 128) * g.double() + b.double()
+        check(ops.groupnorm(x, g, b, 1e-6, given=given), ref, name="gn with pooled statistics")
+        with Wt.compute_dtype(F32):
+            dec = VAEHook(vae.decoder, 16, is_decoder=True)(z)
+            enc = VAEHook(vae.denoise_encoder, 128, is_decoder=False)(img)
+        ref_dec = O.vae_tiled_forward(sd, z, "decoder.", 16, True)
+        ref_enc = O.vae_tiled_forward(sd, img, "denoise_encoder.", 128, False)
+    e_dec, e_enc = rel_l2(dec, ref_dec), rel_l2(enc, ref_enc)
+    _record("tiled_vae_fp32", decoder=e_dec, encoder=e_enc)
+    assert dec.dtype == F32 and tuple(dec.shape) == (1, 3, 384, 320) and tuple(enc.shape) == (1, 8, 32, 40)
+    assert e_dec <= 1e-5 and e_enc <= 1e-5, (e_dec, e_enc)
