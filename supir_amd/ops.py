@@ -1097,7 +1097,7 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
                 and (residual is None or ldr % 4 == 0) and (rowbias is None or ld_rb % 4 == 0):
             for t, (bm, bn, ks, s_) in _G16.items():   # same predicate as supir_gemm16_supported(conv)
                 if t in G16_TILES and M_ % bm == 0 and Cout % bn == 0 and Cin % (64 * ks) == 0 and (9 * Cin // 64) // ks >= s_ - 1 \
-                        and not (t in _G16_PLAIN_ONLY and Cout % 80 == 0) and not (t in (42, 45) and (OH * OW) % bm):
+                        and not (t in _G16_PLAIN_ONLY and Cout % 80 == 0) and not (t == 42 and (OH * OW) % bm) and t != 45:   # 45: plain GEMMs only (it ties or loses on every convolution measured: profiles/r05/big_tiles_tile45.json)
                     cands.append(t)
         # tap-split candidates for convolutions whose tile grid is a fraction of the machine: one workgroup set per filter tap
         if USE_CONV_SPLIT and om == 0 and act in (0, 1) and residual is None and rowbias is None and alpha == 1.0 and Cin % 64 == 0 \
