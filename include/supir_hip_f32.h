@@ -64,8 +64,11 @@ int supir_f32_gemm(const supir_f32_gemm_desc* d, void* stream);
  * weights use (supir_amd/weights.py interleave_geglu: `block` value columns, then `block` gate columns, repeated). */
 int supir_f32_geglu(const float* proj, float* out, int M, int N2, int ldp, int ldo, int block, void* stream);
 
-/* P[r][:T] = softmax(S[r][:T] * scale), P[r][T:Tpad] = 0 (model.py:177-192, attention.py:254-285). In place (P == S) allowed. */
-int supir_f32_softmax_rows(const float* S, float* P, long rows, int T, int Tpad, long ld_s, long ld_p, float scale, void* stream);
+/* P[r][:T] = softmax(S[r][:T] * scale), P[r][T:Tpad] = 0 (model.py:177-192, attention.py:254-285). In place (P == S) allowed.
+ * causal_tq > 0: the rows are blocks of causal_tq queries (rows % causal_tq == 0) and query i of a block sees keys j <= i only -- the text
+ * towers' causal mask (sgm/modules/encoders/modules.py:445-609: transformers' CLIPTextModel, open_clip's attn_mask); 0: no mask. */
+int supir_f32_softmax_rows(const float* S, float* P, long rows, int T, int Tpad, long ld_s, long ld_p, float scale, int causal_tq,
+                           void* stream);
 
 /* GroupNorm(32) over NHWC fp32: the argument list and semantics of supir_groupnorm_nhwc (include/supir_hip.h) -- optional SiLU (act = 1),
  * optional channel concat of two sources (C1 channels from x1, C - C1 from x2; a group may straddle the seam), optional ZeroSFT modulation

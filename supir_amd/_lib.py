@@ -120,7 +120,7 @@ F32_GEMM, F32_CONV3X3 = 0, 1
 SIGNATURES_F32 = {
     "supir_f32_gemm": [P, P],
     "supir_f32_geglu": [P, P, I, I, I, I, I, P],
-    "supir_f32_softmax_rows": [P, P, L, I, I, L, L, F, P],
+    "supir_f32_softmax_rows": [P, P, L, I, I, L, L, F, I, P],
     "supir_f32_groupnorm": [P, P, P, P, I, I, I, I, I, I, P, P, F, I, P, P, I, F, P, I, P, c_size_t, P, P],
     "supir_f32_groupnorm_stats": [P, I, I, I, I, P, P, c_size_t, P],
     "supir_f32_layernorm": [P, P, P, P, I, I, I, I, F, P],

@@ -271,10 +271,11 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 
 // ------------------------------------------------------------------------------------------------------------------- softmax
 __global__ __launch_bounds__(256) void f32_softmax_kernel(const float* __restrict__ S, float* __restrict__ P, int T, int Tpad, long ld_s,
-                                                          long ld_p, float scale) {
+                                                          long ld_p, float scale, int causal_tq, long row0) {
     __shared__ float sh[4];
     const float* s = S + (size_t)blockIdx.x * ld_s;
     float* o = P + (size_t)blockIdx.x * ld_p;
+    if (causal_tq > 0) T = min(T, (int)((row0 + blockIdx.x) % causal_tq) + 1);   // query i of its block sees keys j <= i; the rest become zeros
     float mx = -INFINITY;
     for (int t = threadIdx.x; t < T; t += 256) mx = fmaxf(mx, s[t] * scale);
     mx = block_max(mx, sh);
@@ -285,12 +286,15 @@ __global__ __launch_bounds__(256) void f32_softmax_kernel(const float* __restric
     for (int t = threadIdx.x; t < Tpad; t += 256) o[t] = t < T ? expf(s[t] * scale - mx) * inv : 0.f;
 }
 
-extern "C" int supir_f32_softmax_rows(const float* S, float* P, long rows, int T, int Tpad, long ld_s, long ld_p, float scale, void* stream) {
-    if (!S || !P || rows <= 0 || T <= 0 || Tpad < T || ld_s < T || ld_p < Tpad) return SUPIR_ERR_ARG;
+extern "C" int supir_f32_softmax_rows(const float* S, float* P, long rows, int T, int Tpad, long ld_s, long ld_p, float scale, int causal_tq,
+                                      void* stream) {
+    if (!S || !P || rows <= 0 || T <= 0 || Tpad < T || ld_s < T || ld_p < Tpad || causal_tq < 0) return SUPIR_ERR_ARG;
+    if (causal_tq > 0 && rows % causal_tq) return SUPIR_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     for (long r0 = 0; r0 < rows; r0 += 1 << 30) {       // grid.x limit
         const long n = rows - r0 < (1L << 30) ? rows - r0 : (1L << 30);
-        F32_LAUNCH(f32_softmax_kernel, dim3((unsigned)n), dim3(256), 0, s, S + (size_t)r0 * ld_s, P + (size_t)r0 * ld_p, T, Tpad, ld_s, ld_p, scale);
+        F32_LAUNCH(f32_softmax_kernel, dim3((unsigned)n), dim3(256), 0, s, S + (size_t)r0 * ld_s, P + (size_t)r0 * ld_p, T, Tpad, ld_s, ld_p, scale,
+                   causal_tq, r0);
         const int rc = F32_STATUS();
         if (rc != SUPIR_OK) return rc;
     }

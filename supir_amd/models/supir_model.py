@@ -190,17 +190,21 @@ class SUPIRModel(nn.Module):
                  "aesthetic_score": torch.tensor([9.0]).repeat(N, 1).to(_z.device), "control": _z}
         batch_uc = copy.deepcopy(batch)
         batch_uc["txt"] = [n_p for _ in p]
+        # the reference runs the conditioner under autocast(ae_dtype) (SUPIR_model.py:165,174): the text towers follow the VAE's request --
+        # bf16 by test.py's default, true fp32 for `--ae_dtype fp32`
         if not isinstance(p[0], list):
             batch["txt"] = ["".join([_p, p_p]) for _p in p]
-            return self.conditioner.get_unconditional_conditioning(batch, batch_uc)
+            with self._ae_scope():
+                return self.conditioner.get_unconditional_conditioning(batch, batch_uc)
         # local (per-tile) prompts, SUPIR_model.py:168-178: one cond per tile, a single uc (the tiled samplers' `cond` list)
         assert len(p) == 1, "Support bs=1 only for local prompt conditioning."
         c, uc = [], None
         for i, p_tile in enumerate(p[0]):
             batch["txt"] = ["".join([p_tile, p_p])]
-            if i == 0:
-                _c, uc = self.conditioner.get_unconditional_conditioning(batch, batch_uc)
-            else:
-                _c, _ = self.conditioner.get_unconditional_conditioning(batch, None)
+            with self._ae_scope():
+                if i == 0:
+                    _c, uc = self.conditioner.get_unconditional_conditioning(batch, batch_uc)
+                else:
+                    _c, _ = self.conditioner.get_unconditional_conditioning(batch, None)
             c.append(_c)
         return c, uc

@@ -120,7 +120,7 @@ class GLVControl(UNetModel):
         elementwise ops with kernel launches (it cannot be recorded by ops.paired_run)."""
         emb = self._embed(timesteps, y)
         sch = self._schedule
-        if sch is not None and sch["active"] and sch.get("hint") is not None and sch["hint"].shape[0] == x.shape[0]:
+        if sch is not None and sch["active"] and sch["cdt"] == cdt() and sch.get("hint") is not None and sch["hint"].shape[0] == x.shape[0]:
             guided_hint = sch["hint"]          # input_hint_block(LQ latent): the same every step of an image (prepare_schedule)
         else:
             guided_hint = self._guided_hint(x)

@@ -306,8 +306,9 @@ class ControlWrapper(nn.Module):
             self._resident.clear()
             self._last_cdt = self.effective_dtype
         vec = c.get("vector", None) if isinstance(c, dict) else None
-        sched = self._use_schedule(kwargs, None if vec is None else int(vec.shape[0]))   # the schedule entry serving this call, or None
         with torch.no_grad(), Wt.compute_dtype(self.effective_dtype):
+            # (inside the scope: the networks keep one table per element type and look theirs up by the scope's)
+            sched = self._use_schedule(kwargs, None if vec is None else int(vec.shape[0]))   # the schedule entry serving this call, or None
             if self._graph_on and not kwargs and x.is_cuda and self.effective_dtype != torch.float32:
                 return self._forward_graph(x, t, c, control_scale, sched)
             return self._forward_eager(x, t, c, control_scale, **kwargs)

@@ -141,21 +141,22 @@ def softmax_rows(s, scale, out=None, valid=None, dtype=None):
     assert s.stride(1) == 1
     if out is None:
         out = torch.empty(rows, Tp, dtype=F32, device=s.device)
-    _lib.check(lib.supir_f32_softmax_rows(s.data_ptr(), out.data_ptr(), rows, T, Tp, s.stride(0), out.stride(0), scale, _stream()),
+    _lib.check(lib.supir_f32_softmax_rows(s.data_ptr(), out.data_ptr(), rows, T, Tp, s.stride(0), out.stride(0), scale, 0, _stream()),
                "supir_f32_softmax_rows", lib)
     return out
 
 
 def _attention(q, k, vt, B, H, D, Tq, Tk, ldq, ldk, ldvt, out, ldo, scale, causal=False):
-    """softmax(scale q_h k_h^T) v_h for every (batch, head): scores [B, H, Tq, Tkp] in HBM, three launches."""
-    assert not causal, "causal attention (text towers) has no fp32 form on this path"
+    """softmax(scale q_h k_h^T) v_h for every (batch, head): scores [B, H, Tq, Tkp] in HBM, three launches.
+    causal (text towers): query i sees keys j <= i -- the mask is applied by the softmax (masked probabilities are exact zeros)."""
+    assert not causal or Tq == Tk
     lib = _lib.load_f32()
     Tkp = ldvt
     s = torch.empty(B, H, Tq, Tkp, dtype=F32, device=q.device)
     # S[b, h] = q[b, :, h D:(h + 1) D] . k[b, :, h D:(h + 1) D]^T   (z0 = head, z1 = batch element)
     _gemm_call(A=q.data_ptr(), W=k.data_ptr(), C=s.data_ptr(), kind=_lib.F32_GEMM, M=Tq, N=Tk, K=D, lda=ldq, ldw=ldk, ldc=Tkp, nz0=H, nz1=B,
                a_s0=D, a_s1=Tq * ldq, w_s0=D, w_s1=Tk * ldk, c_s0=Tq * Tkp, c_s1=H * Tq * Tkp)
-    _lib.check(lib.supir_f32_softmax_rows(s.data_ptr(), s.data_ptr(), B * H * Tq, Tk, Tkp, Tkp, Tkp, scale, _stream()),
+    _lib.check(lib.supir_f32_softmax_rows(s.data_ptr(), s.data_ptr(), B * H * Tq, Tk, Tkp, Tkp, Tkp, scale, Tq if causal else 0, _stream()),
                "supir_f32_softmax_rows", lib)
     # O[b, :, h D:(h + 1) D] = P[b, h] . (V^T[b, h D:(h + 1) D, :])^T   (padding columns: P is zero there, V^T is zero there)
     _gemm_call(A=s.data_ptr(), W=vt.data_ptr(), C=out.data_ptr(), kind=_lib.F32_GEMM, M=Tq, N=D, K=Tkp, lda=Tkp, ldw=ldvt, ldc=ldo, nz0=H, nz1=B,

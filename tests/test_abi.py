@@ -74,7 +74,8 @@ def test_f32_library_exports_its_own_table():
     assert lib32.supir_f32_gemm(ctypes.byref(d), None) == -1            # batched launches take no bias / residual
     assert lib32.supir_f32_gemm(None, None) == -1
     assert lib32.supir_f32_geglu(fake, fake, 8, 130, 130, 65, 32, None) == -2
-    assert lib32.supir_f32_softmax_rows(fake, fake, 4, 100, 64, 128, 128, 1.0, None) == -1
+    assert lib32.supir_f32_softmax_rows(fake, fake, 4, 100, 64, 128, 128, 1.0, 0, None) == -1
+    assert lib32.supir_f32_softmax_rows(fake, fake, 10, 64, 64, 64, 64, 1.0, 4, None) == -2    # causal: whole blocks of queries
     assert lib32.supir_f32_layernorm(None, None, None, None, 4, 64, 64, 64, 1e-5, None) == -1
     assert lib32.supir_f32_groupnorm(fake, None, None, None, 1, 16, 48, 48, 48, 0, fake, fake, 1e-5, 0, None, None, 0, 1.0, fake, 48, fake, 1 << 20,
                                      None, None) == -2                    # C % 32

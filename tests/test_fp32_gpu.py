@@ -209,6 +209,21 @@ def test_attention_f32(B, H, Tq, Tk):
     check(out, ref, name="attention d64")
 
 
+def test_attention_causal_f32():
+    """The text towers' causal self-attention (77 tokens padded to 128 keys): masked probabilities are exact zeros."""
+    B, H, T = 2, 12, 77
+    C, Tp = H * 64, 128
+    qk = rnd(B, T, 2 * C)
+    v = rnd(B, T, C, seed=2)
+    vt = torch.zeros(B, C, Tp, device=DEV)
+    vt[:, :, :T] = v.transpose(1, 2)
+    out = ops.flash_attn(qk[:, :, :C], qk[:, :, C:], vt, B, H, T, T, causal=True)
+    qh, kh, vh = (t.double().reshape(B, T, H, 64).transpose(1, 2) for t in (qk[:, :, :C], qk[:, :, C:], v))
+    sc = qh @ kh.transpose(-1, -2) * 0.125
+    sc = sc.masked_fill(torch.ones(T, T, dtype=torch.bool, device=DEV).triu(1), float("-inf"))
+    check(out, (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, T, C), name="causal attention")
+
+
 def test_attention_d512_f32():
     B, T = 2, 324
     Tp = (T + 63) // 64 * 64
@@ -284,21 +299,40 @@ def test_network_call_fp32_vs_fp32_oracle(mini, control_scale):
     assert torch.equal(g32, out32) and torch.equal(bf_after, bf_before)
 
 
-def test_prepared_schedule_and_fused_sampler_step_in_fp32(mini):
-    """The per-image embedding schedule (ControlWrapper.prepare_schedule / select_step) in an fp32 scope: the same values as the plain call."""
+def test_prepared_schedule_in_fp32_after_a_bf16_image(mini):
+    """The per-image embedding schedule (ControlWrapper.prepare_schedule / select_step) in an fp32 scope, AFTER a bf16 image was sampled with
+    its own schedule at the same batch size and ANOTHER LQ latent: the fp32 steps must read the fp32 tables (and the fp32 hint of THEIR
+    control input), i.e. equal the plain fp32 calls.  (Regression: the table was once looked up outside the compute-dtype scope, which found
+    the bf16 image's table -- and its stale bf16 input_hint_block output -- for an fp32 step.)"""
     B, L = 2, 32
     x = synth_tensor("xt32", (B, 4, L, L)).to(DEV)
     cond = {"crossattn": synth_tensor("context", (B, 77, 2048)).to(DEV), "vector": synth_tensor("vector", (B, 2816)).to(DEV),
             "control": synth_tensor("lq32", (B, 4, L, L)).to(DEV)}
-    mini.dtype = F32
+    other = dict(cond, control=synth_tensor("lq32.other", (B, 4, L, L)).to(DEV))
+    tt = lambda tv: torch.full((B,), tv, dtype=torch.int64, device=DEV)
     try:
         with torch.no_grad():
-            plain = [mini(x, torch.full((B,), tv, dtype=torch.int64, device=DEV), cond, 1.0).clone() for tv in (900, 40)]
+            mini.prepare_schedule([900, 40], other["vector"], control=other["control"])      # a bf16 image, another LQ latent
+            mini.select_step(0, expect_t=900)
+            mini(x, tt(900), other, 1.0)
+            mini.end_schedule()
+            mini.dtype = F32
+            plain = [mini(x, tt(tv), cond, 1.0).clone() for tv in (900, 40)]
             mini.prepare_schedule([900, 40], cond["vector"], control=cond["control"])
             for i, tv in enumerate((900, 40)):
                 mini.select_step(i, expect_t=tv)
-                out = mini(x, torch.full((B,), tv, dtype=torch.int64, device=DEV), cond, 1.0)
+                out = mini(x, tt(tv), cond, 1.0)
+                assert mini.diffusion_model._schedule["cdt"] == F32 and mini.control_model._schedule["hint"].dtype == F32
                 assert rel_l2(out, plain[i]) <= 2e-6, (i, rel_l2(out, plain[i]))
+            # and the fp16 build, same sequence (its table, its hint)
+            mini.end_schedule()
+            mini.dtype = torch.float16
+            p16 = mini(x, tt(900), cond, 1.0).clone()
+            mini.prepare_schedule([900, 40], cond["vector"], control=cond["control"])
+            mini.select_step(0, expect_t=900)
+            o16 = mini(x, tt(900), cond, 1.0)
+            assert mini.diffusion_model._schedule["cdt"] == torch.float16 and mini.control_model._schedule["hint"].dtype == torch.float16
+            assert rel_l2(o16, p16) <= 2e-3, rel_l2(o16, p16)
     finally:
         mini.end_schedule()
         mini.dtype = torch.bfloat16
@@ -358,3 +392,29 @@ def test_tiled_vae_fp32_vs_oracle():
     _record("tiled_vae_fp32", decoder=e_dec, encoder=e_enc)
     assert dec.dtype == F32 and tuple(dec.shape) == (1, 3, 384, 320) and tuple(enc.shape) == (1, 8, 32, 40)
     assert e_dec <= 1e-5 and e_enc <= 1e-5, (e_dec, e_enc)
+
+
+def test_text_towers_fp32_vs_oracle():
+    """The conditioner under `--ae_dtype fp32` (the reference runs it under autocast(ae_dtype), SUPIR_model.py:165: plain fp32 then): CLIP-L
+    hidden_states[11] and OpenCLIP bigG penultimate / pooled at full size in an fp32 scope against the oracle."""
+    from oracle import cond_oracle as CO
+    from supir_amd.modules import conditioner as C
+    from tests.test_conditioner import _fill, _tokens
+    tok = _tokens(2, seed=3)
+    with torch.device(DEV):
+        cl = C.FrozenCLIPEmbedder(layer="hidden", layer_idx=11)
+        g = C.FrozenOpenCLIPEmbedder2(arch="ViT-bigG-14", layer="penultimate", always_return_pooled=True, legacy=False)
+    _fill(cl, "conditioner.embedders.0.", DEV)
+    _fill(g, "conditioner.embedders.1.", DEV)
+    with torch.no_grad():
+        with Wt.compute_dtype(F32):
+            z = cl(tok)
+            pen, pooled = g(tok)
+        zbf = cl(tok)
+        ref_z = CO.clip_l_hidden(cl.state_dict(), tok.to(DEV), p="transformer.text_model.")
+        ref_pen, ref_pool = CO.openclip_g_penultimate_pooled(g.state_dict(), tok.to(DEV), p="model.")
+    e = dict(clip_l_hidden11=rel_l2(z, ref_z), bigg_penultimate=rel_l2(pen, ref_pen), bigg_pooled=rel_l2(pooled, ref_pool),
+             clip_l_bf16=rel_l2(zbf, ref_z))
+    _record("text_towers", **e)
+    assert max(e["clip_l_hidden11"], e["bigg_penultimate"], e["bigg_pooled"]) <= 1e-5, e
+    assert e["clip_l_bf16"] >= 100 * e["clip_l_hidden11"]

@@ -451,6 +451,35 @@ def test_fp16_request_runs_in_an_fp16_compute_scope(monkeypatch):
     assert a.dtype == torch.bfloat16 and lin.w().dtype == torch.bfloat16
 
 
+def test_schedule_tables_are_looked_up_inside_the_compute_scope():
+    """ControlWrapper.forward switches the networks' embedding tables on (use_schedule) INSIDE the compute-dtype scope: the networks keep one
+    table per element type and find theirs by `weights.cdt()`.  (Looked up outside, an fp32 / fp16 step was served the bf16 image's table.)"""
+    from supir_amd import weights as Wt
+    from supir_amd.modules.wrappers import ControlWrapper
+    seen = []
+
+    class Net(torch.nn.Module):
+        def use_schedule(self, B, on):
+            seen.append((B, on, Wt.cdt()))
+            return bool(on)
+
+        def forward(self, x=None, timesteps=None, xt=None, context=None, y=None, control=None, control_scale=1, **kw):
+            return [xt] if control is None else x
+
+    w = ControlWrapper(Net(), dtype=torch.float16)
+    w.load_control_model(Net())
+    x, t = torch.ones(2, 4, 8, 8), torch.zeros(2, dtype=torch.int64)
+    c = {"crossattn": torch.zeros(2, 77, 8), "vector": torch.zeros(2, 16), "control": torch.ones(2, 4, 8, 8)}
+    for dt in (torch.float16, torch.float32, torch.bfloat16):
+        del seen[:]
+        w.dtype = dt
+        w._scheds[2] = (1, 1, 1, w.effective_dtype, (500,))
+        w._sched_armed = True
+        w(x, t, c)
+        assert seen and all(s[2] == dt for s in seen), seen
+        assert seen[0][:2] == (2, True)
+
+
 def test_builtin_config_mirrors_the_reference_yaml_scalars():
     """supir_amd.configs.supir_v0_config (what bench.py / the GPU parity tests build from) keeps the scalar parameters of
     options/SUPIR_v0.yaml:4-8 -- a dropped `scale_factor` once made every latent 7.7x too large."""
