@@ -92,9 +92,132 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same convolution on the exact-fp32 matrix instruction (round 5): the three 4 -> 320 input convolutions of a
+// UNet step ran 67 us each in the VALU form above (0.75 GFLOP, 21 MB of output: ~2 % of any roofline), the VAE's 3 -> 128 at image
+// resolution ~ 200 us.  v_mfma_f32_16x16x4_f32 takes fp32 operands and accumulates in fp32 -- nothing is rounded that the VALU form does
+// not round -- and K = Cin * 9 (27 / 36) is KS = ceil(K / 4) steps with at most one padded column.  Operands swapped as everywhere in this
+// library: A = 16 weight rows (output channels 16 j + m of the wave's range), B = the im2col columns of 16 consecutive pixels (flat
+// b * H * W + y * W + x index: a block may straddle image rows, every lane derives its own tap addresses), so a lane ends with channels
+// 16 j + 4 g .. + 3 of pixel n (g = lane / 16, n = lane % 16).  A wave's weights live in registers for the whole launch (NBW x KS floats
+// per lane); the im2col values are gathered straight from the fp32 NCHW map (512 KB for a latent pair: L1 / L2 resident), one float per
+// lane and K step.  Output rows leave through a wave-private LDS tile (16 pixels x 32 NBW bytes, rows padded by 16 B) as 16-byte
+// row-contiguous stores, the family's usual epilogue; the optional `add` operand is applied in the accumulator layout BEFORE the one
+// rounding to 16 bits, as in the VALU form.
+//   SPLIT : the four waves of a workgroup split the channels (Cout = 64 NBW; all four gather the same pixels)   4 -> 320, 4 -> 512
+//   !SPLIT: every wave has all channels (Cout = 16 NBW) and its own pixel blocks                                3 -> 128, 4 -> 128
+// Another fp32 summation order than the VALU form (differences ~ 1e-7 relative, below the 16-bit output rounding except at ties);
+// supir_debug_knob(7, 1) selects the VALU form for in-process A/B.
+template <int NBW, int KS, bool SPLIT>
+__global__ __launch_bounds__(256) void conv3x3_smallcin_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, const bf16_t* __restrict__ add,
+                                                                    bf16_t* __restrict__ out, int B, int Cin, int H, int W, int ld_add,
+                                                                    int ldo) {
+    constexpr int ROWB = 32 * NBW + 16;               // bytes per pixel row of the stage (+16: rows start 4 banks apart)
+    __shared__ __attribute__((aligned(16))) char stage_all[4][16 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int K = Cin * 9, HW = H * W;
+    const int chw = SPLIT ? wave * 16 * NBW : 0;      // first channel of this wave's range
+    char* stage = stage_all[wave];
+    // ---- A operand: lane (n, g) holds W[channel chw + 16 j + n][k = 4 s + g]
+    float wr[NBW][KS];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const float* wrow = w + (size_t)(chw + 16 * j + n) * K;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 4 * s + g;
+            wr[j][s] = k < K ? wrow[k] : 0.f;
+        }
+    }
+    f32x4 bz[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[j][r] = bias ? bias[chw + 16 * j + 4 * g + r] : 0.f;
+    // ---- this lane's K indices: k = ci * 9 + ky * 3 + kx (the reference's [Cout][Cin][3][3] weight layout, untouched)
+    int koff[KS], ktap[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + g;
+        const int ci = k / 9, t = k - 9 * ci, ky = t / 3, kx = t - 3 * ky;
+        koff[s] = ci * HW + (ky - 1) * W + (kx - 1);
+        ktap[s] = k < K ? (ky | (kx << 2)) : -1;
+    }
+    const long total = (long)B * HW;
+    const long nblk = (total + 15) >> 4;
+    const long step = SPLIT ? (long)gridDim.x : (long)gridDim.x * 4;
+    for (long blk = SPLIT ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave; blk < nblk; blk += step) {
+        const long p = blk * 16 + n;
+        const bool valid = p < total;
+        const long pc = valid ? p : total - 1;
+        const int b = (int)(pc / HW);
+        const int rem = (int)(pc - (long)b * HW);
+        const int y = rem / W, xx = rem - y * W;
+        const float* xb = x + (size_t)b * Cin * HW + rem;
+        float xv[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int ky = ktap[s] & 3, kx = (ktap[s] >> 2) & 3;
+            const bool ok = valid && ktap[s] >= 0 && (unsigned)(y + ky - 1) < (unsigned)H && (unsigned)(xx + kx - 1) < (unsigned)W;
+            xv[s] = ok ? xb[koff[s]] : 0.f;
+        }
+        f32x4 acc[NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[j] = bz[j];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][s], xv[s], acc[j], 0, 0, 0);
+        // ---- epilogue: (+ add), one rounding, transpose through the wave's stage, 16-byte row-contiguous stores
+        const bf16_t* ap = (add && valid) ? add + (size_t)p * ld_add + chw + 4 * g : nullptr;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            f32x4 v = acc[j];
+            if (ap) {
+                const u16x4 av = *(const u16x4*)(ap + 16 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(av[e]);
+            }
+            const u32x2 o = {f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3])};
+            *(u32x2*)(stage + n * ROWB + 32 * j + 8 * g) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = lane; i < 32 * NBW; i += 64) {   // 2 NBW 16-byte pieces per pixel row
+            const int row = i / (2 * NBW), piece = i - row * (2 * NBW);
+            const long pr = blk * 16 + row;
+            if (pr < total) *(u32x4*)(out + (size_t)pr * ldo + chw + 8 * piece) = *(const u32x4*)(stage + row * ROWB + 16 * piece);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+template <int NBW, int KS, bool SPLIT>
+static int launch_smallcin_mfma(const float* x, const float* w, const float* bias, const bf16_t* add, bf16_t* out, int B, int Cin, int H,
+                                int W, int ld_add, int ldo, hipStream_t st) {
+    const long nblk = ((long)B * H * W + 15) / 16;
+    long units = SPLIT ? nblk : (nblk + 3) / 4;
+    if (units > 512) units = 512;    // two workgroups per CU, all co-resident (176-240 registers: two waves per SIMD); every shape of the path divides evenly
+    SUPIR_LAUNCH((conv3x3_smallcin_mfma_kernel<NBW, KS, SPLIT>), dim3((unsigned)units), dim3(256), 0, st, x, w, bias, add, out, B, Cin, H,
+                 W, ld_add, ldo);
+    return SUPIR_LAUNCH_STATUS();
+}
+
 int supir_conv3x3_smallcin_launch(const float* x, const float* w, const float* bias, const bf16_t* add, bf16_t* out,
                                   int B, int Cin, int H, int W, int Cout, int ld_add, int ldo, hipStream_t st) {
     if (B <= 0 || Cin <= 0 || Cin > 8 || Cout % 8 != 0 || ldo % 8 != 0 || (add && ld_add % 8 != 0)) return SUPIR_ERR_SHAPE;
+    if (supir_debug_knob_value(7) != 1 && (long)Cin * H * W < (1L << 30)) {   // the matrix-instruction form for the path's own shapes
+        if (Cin == 4 && Cout == 320) return launch_smallcin_mfma<5, 9, true>(x, w, bias, add, out, B, Cin, H, W, ld_add, ldo, st);
+        if (Cin == 4 && Cout == 512) return launch_smallcin_mfma<8, 9, true>(x, w, bias, add, out, B, Cin, H, W, ld_add, ldo, st);
+        if (Cin == 3 && Cout == 128) return launch_smallcin_mfma<8, 7, false>(x, w, bias, add, out, B, Cin, H, W, ld_add, ldo, st);
+        if (Cin == 4 && Cout == 128) return launch_smallcin_mfma<8, 9, false>(x, w, bias, add, out, B, Cin, H, W, ld_add, ldo, st);
+    }
     const size_t smem = (size_t)Cin * 9 * Cout * sizeof(float);
     if (smem > 160 * 1024) return SUPIR_ERR_SHAPE;
     static bool attr = false;

@@ -254,7 +254,12 @@ def test_layernorm(rows, C):
     check(out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), name="ln")
 
 
-@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 4, 32, 32, 320), (1, 3, 40, 24, 128), (1, 4, 16, 16, 512)])
+# (4 -> 320), (4 -> 512), (3 -> 128), (4 -> 128) take the exact-fp32 matrix-instruction form (conv3x3_smallcin_mfma_kernel: blocks of 16 flat
+# pixel indices, so ragged maps -- pixel counts that are not multiples of 16, blocks straddling image rows and batch elements, fewer than
+# 16 pixels -- are the edge cases); everything else (and tools knob 7) the VALU form.  Both accumulate in fp32 from fp32 operands.
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 4, 32, 32, 320), (1, 3, 40, 24, 128), (1, 4, 16, 16, 512), (1, 3, 37, 29, 128),
+                                           (3, 4, 9, 7, 320), (1, 4, 5, 3, 128), (2, 4, 3, 3, 512), (2, 4, 128, 128, 320),
+                                           (1, 5, 8, 8, 64), (1, 4, 7, 6, 64)])
 def test_conv_smallcin(B, Cin, H, W, Cout):
     x = rnd(B, Cin, H, W)
     w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1)
@@ -263,8 +268,23 @@ def test_conv_smallcin(B, Cin, H, W, Cout):
     out = ops.conv3x3_smallcin(x, w, bias)
     ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1)
     check(out, ref, name="smallcin")
-    out = ops.conv3x3_smallcin(x, w, bias, add=add)
-    check(out, ref + add.float(), name="smallcin+add")
+    out_add = ops.conv3x3_smallcin(x, w, bias, add=add)
+    check(out_add, ref + add.float(), name="smallcin+add")
+    check(ops.conv3x3_smallcin(x, w, None), ref - bias, name="smallcin, no bias")
+    assert torch.equal(out, ops.conv3x3_smallcin(x, w, bias))          # the wave-private stage hands over without a race
+    # a wider destination (channel slice of a concat buffer) and the VALU form: same values up to the fp32 summation order
+    wide = torch.zeros(B, H, W, Cout + 64, dtype=BF, device=x.device)
+    ops.conv3x3_smallcin(x, w, bias, out=wide[..., 32:32 + Cout])
+    assert torch.equal(wide[..., 32:32 + Cout], out) and not wide[..., :32].any() and not wide[..., 32 + Cout:].any()
+    from supir_amd import _lib
+    lib = _lib.load(BF)
+    try:
+        lib.supir_debug_knob(7, 1)
+        valu = ops.conv3x3_smallcin(x, w, bias, add=add)
+    finally:
+        lib.supir_debug_knob(7, 0)
+    check(out_add, valu.float(), rel=3e-3, name="matrix-instruction form vs VALU form")
+    assert ((out_add.float() - valu.float()).abs() > 0).float().mean().item() < 0.02   # they differ by last-bit ties only
 
 
 # Cin = 128 with Cout 3 / 4 takes the register-resident kernel (conv3x3_c128_smallcout_kernel: a 16-lane group walks 64-pixel row segments
