@@ -2,7 +2,8 @@
 
 CPU tier: the oracle restatement (oracle/cond_oracle.py) is pinned against the real transformers.CLIPTextModel (the class the
 reference instantiates for CLIP-L) and, block-wise, against torch.nn.MultiheadAttention (what open_clip's ResidualAttentionBlock
-wraps; open_clip itself is not installed: parity unpinned for that package); state-dict keys of the product classes against the
+wraps; open_clip itself is not installed), and the bigG tower -- the fixtures' and the oracle's -- against
+transformers.CLIPTextModelWithProjection, an independent implementation of the same architecture; state-dict keys of the product classes against the
 transformers / open_clip naming; the conditioner's key routing / concatenation.
 GPU tier: the HIP towers at full size (CLIP-L 12 x 768, bigG 32 x 1280) against the oracle on synthetic weights.
 """
@@ -263,3 +264,104 @@ def test_general_conditioner_with_control_on_gpu_vs_oracle():
     rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
     assert rel(c["crossattn"], ref["crossattn"]) <= 2e-2 and rel(c["vector"], ref["vector"]) <= 2e-2
     assert not torch.equal(c["crossattn"], uc["crossattn"])
+
+
+def test_bigg_tower_vs_transformers_cliptextmodelwithprojection():
+    """open_clip is not installable here, so the bigG tower of the fixtures (tests/golden/golden_cond.pt: the REFERENCE'S
+    FrozenOpenCLIPEmbedder2, sgm/modules/encoders/modules.py:513-609, run over a stand-in open_clip text tower) is held against a second,
+    independently written implementation of the same published architecture: transformers.CLIPTextModelWithProjection -- the class
+    diffusers loads SDXL's second text encoder (the same OpenCLIP ViT-bigG-14 checkpoint, converted) into.  Weights are the fixtures'
+    (supir_amd.synth by reference key name) re-keyed open_clip -> transformers: in_proj_weight split into q / k / v, c_fc / c_proj -> fc1 /
+    fc2, text_projection transposed into a bias-free Linear.  Compared: the penultimate hidden state (hidden_states[-2], no final
+    LayerNorm: modules.py:583-597 `penultimate`) and the pooled, projected eot row (modules.py:575-581) -- i.e. the block arithmetic
+    (pre-LN residual block, packed-QKV multi-head attention with the causal mask, erf-GELU MLP) that the stand-in restates, and with it the
+    oracle's and the product's towers, which the other tests hold to these fixtures."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    gold = torch.load("tests/golden/golden_cond.pt")
+    D, LAYERS, HEADS, PROJ, L_WIDTH = 320, 6, 20, 320, 192          # oracle/gen_golden_cond.py: the reduced "bigG" of the fixtures
+    cfg = CLIPTextConfig(vocab_size=49408, hidden_size=D, intermediate_size=4 * D, num_hidden_layers=LAYERS, num_attention_heads=HEADS,
+                         max_position_embeddings=77, hidden_act="gelu", projection_dim=PROJ, eos_token_id=2)   # 2: pooled row = argmax(ids)
+    hf = CLIPTextModelWithProjection(cfg).eval()
+    P = "conditioner.embedders.1.model."
+    syn = lambda name, shape: synth_param(P + name, shape)  # noqa: E731
+    new = {}
+    for k, t in hf.state_dict().items():
+        kk = k[len("text_model."):] if k.startswith("text_model.") else k
+        if kk == "embeddings.token_embedding.weight":
+            v = syn("token_embedding.weight", t.shape)
+        elif kk == "embeddings.position_embedding.weight":
+            v = syn("positional_embedding", t.shape)
+        elif kk.startswith("final_layer_norm."):
+            v = syn("ln_final." + kk.split(".")[-1], t.shape)
+        elif kk == "text_projection.weight":
+            v = syn("text_projection", (D, PROJ)).t()                   # open_clip: x @ text_projection; HF: Linear(weight = its transpose)
+        elif kk.startswith("encoder.layers."):
+            _, _, i, *rest = kk.split(".")
+            B = f"transformer.resblocks.{i}."
+            rest = ".".join(rest)
+            wb = rest.split(".")[-1]
+            if rest.startswith("self_attn.") and rest.split(".")[1] in ("q_proj", "k_proj", "v_proj"):
+                j = ("q_proj", "k_proj", "v_proj").index(rest.split(".")[1])
+                full = syn(B + "attn.in_proj_" + wb, (3 * D, D) if wb == "weight" else (3 * D,))
+                v = full[j * D:(j + 1) * D]
+            else:
+                name = {"self_attn.out_proj": "attn.out_proj", "layer_norm1": "ln_1", "layer_norm2": "ln_2", "mlp.fc1": "mlp.c_fc",
+                        "mlp.fc2": "mlp.c_proj"}[rest.rsplit(".", 1)[0]]
+                v = syn(B + name + "." + wb, t.shape)
+        else:
+            continue                                                     # position_ids buffer
+        assert v.shape == t.shape, (k, v.shape, t.shape)
+        new[k] = v.contiguous()
+    missing = [k for k, t in hf.state_dict().items() if t.is_floating_point() and k not in new]
+    assert not missing, missing
+    hf.load_state_dict(new, strict=False)
+    texts = ["a photo of a cat", "cinematic, high detail, 8k"]          # gen_golden_cond.batches(): the `c` batch
+    ids = torch.stack([gold["texts"][t] for t in texts])
+    with torch.no_grad():
+        out = hf(input_ids=ids, output_hidden_states=True)
+    pen_ref = gold["c.crossattn"][:, :, L_WIDTH:]                        # crossattn = CLIP-L hidden[11] | bigG penultimate
+    pooled_ref = gold["c.vector"][:, :PROJ]                              # vector = bigG pooled | 3 x sincos
+    pen, pooled = out.hidden_states[-2], out.text_embeds
+    d_pen, d_pool = ((pen - pen_ref).norm() / pen_ref.norm()).item(), ((pooled - pooled_ref).norm() / pooled_ref.norm()).item()
+    print(f"bigG tower, reference-over-stand-in vs transformers: penultimate {d_pen:.2e}, pooled {d_pool:.2e}")
+    assert d_pen <= 2e-5 and d_pool <= 2e-5
+    # and the legacy branch (modules.py:565-568): ln_final of the last layer == HF's last_hidden_state
+    assert ((out.last_hidden_state - gold["g_legacy_last"]).norm() / gold["g_legacy_last"].norm()).item() <= 2e-5
+
+
+def test_bigg_restatement_vs_transformers_at_the_real_head_geometry():
+    """The oracle's own bigG restatement (oracle/cond_oracle.py: openclip_g_penultimate_pooled / openclip_g_legacy) against
+    transformers.CLIPTextModelWithProjection at ViT-bigG-14's real width and head geometry (1280 wide, 20 heads of 64, MLP 5120,
+    projection 1280; 3 of the 32 layers to keep the CPU tier short), HF's own random initialisation re-keyed to open_clip's names."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    D, LAYERS, HEADS = 1280, 3, 20
+    cfg = CLIPTextConfig(vocab_size=49408, hidden_size=D, intermediate_size=4 * D, num_hidden_layers=LAYERS, num_attention_heads=HEADS,
+                         max_position_embeddings=77, hidden_act="gelu", projection_dim=D, eos_token_id=2)
+    torch.manual_seed(3)
+    hf = CLIPTextModelWithProjection(cfg).eval()
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():          # HF initialises biases / LayerNorm to 0 / 1: make every term of the arithmetic count
+            if p_.ndim == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    h = {(k[len("text_model."):] if k.startswith("text_model.") else k): v.float() for k, v in hf.state_dict().items()}
+    sd = {"model.token_embedding.weight": h["embeddings.token_embedding.weight"],
+          "model.positional_embedding": h["embeddings.position_embedding.weight"],
+          "model.ln_final.weight": h["final_layer_norm.weight"], "model.ln_final.bias": h["final_layer_norm.bias"],
+          "model.text_projection": h["text_projection.weight"].t().contiguous()}
+    for i in range(LAYERS):
+        s, q = f"encoder.layers.{i}.", f"model.transformer.resblocks.{i}."
+        sd[q + "attn.in_proj_weight"] = torch.cat([h[s + f"self_attn.{n}_proj.weight"] for n in "qkv"])
+        sd[q + "attn.in_proj_bias"] = torch.cat([h[s + f"self_attn.{n}_proj.bias"] for n in "qkv"])
+        for a, b in (("self_attn.out_proj", "attn.out_proj"), ("layer_norm1", "ln_1"), ("layer_norm2", "ln_2"), ("mlp.fc1", "mlp.c_fc"),
+                     ("mlp.fc2", "mlp.c_proj")):
+            sd[q + b + ".weight"], sd[q + b + ".bias"] = h[s + a + ".weight"], h[s + a + ".bias"]
+    tok = _tokens(2, seed=5, eot_pos=(9, 76))
+    with torch.no_grad():
+        out = hf(input_ids=tok, output_hidden_states=True)
+        pen, pooled = CO.openclip_g_penultimate_pooled(sd, tok, p="model.", heads=HEADS)
+        last = CO.openclip_g_legacy(sd, tok, "last", p="model.", heads=HEADS)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    # rows after the eot see padding tokens (id 0) in both implementations alike (causal mask only, no padding mask: modules.py:571)
+    assert rel(pen, out.hidden_states[-2]) <= 2e-5
+    assert rel(pooled, out.text_embeds) <= 2e-5
+    assert rel(last, out.last_hidden_state) <= 2e-5
