@@ -13,6 +13,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .brownian import BrownianTreeNoiseSampler
+
 SIGMA_MAX = 14.6146
 # RestoreEDMSampler: run the elementwise halves of a step as two fused kernels (csrc/sampler.hip) with host-side scalars when the
 # caller exposes its denoiser / network (SUPIRModel.batchify_sample does); off -> the generic torch-op path for every caller
@@ -571,10 +573,10 @@ def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0, device="cpu"):
 
 
 class IntervalNoiseSampler:
-    """Stand-in for k_diffusion's BrownianTreeNoiseSampler (needs torchsde, not available): the sampler queries
-    consecutive, non-overlapping sigma intervals, on which normalised Brownian increments are i.i.d. N(0, 1) -- so a
-    fresh torch.randn per call has the same distribution.  What is NOT reproduced is the tree's seed->noise mapping:
-    the noise STREAM of config 5 is parity-unpinned."""
+    """A fresh torch.randn per call: what a Brownian path gives on CONSECUTIVE, non-overlapping sigma intervals (its normalised
+    increments there are i.i.d. N(0, 1)) without the path.  The default of rounds 1-4; since round 5 the samplers construct
+    brownian.BrownianTreeNoiseSampler (a virtual Brownian tree behind k-diffusion's interface) as the reference does, and this class is
+    kept for callers that want the cheaper stream (noise_sampler_cls=IntervalNoiseSampler)."""
 
     def __init__(self, x, sigma_min=None, sigma_max=None, seed=None):
         self.shape, self.device, self.dtype = x.shape, x.device, x.dtype
@@ -598,7 +600,7 @@ class RestoreDPMPP2MSampler(BaseDiffusionSampler):
                  restore_cfg_s_tmin=0.05, eta=1.0, noise_sampler_cls=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.s_noise, self.eta = s_noise, eta
-        self.noise_sampler_cls = noise_sampler_cls or IntervalNoiseSampler
+        self.noise_sampler_cls = noise_sampler_cls or BrownianTreeNoiseSampler      # sampling.py:494, 687
 
     def denoise(self, x, denoiser, sigma, cond, uc, control_scale=1.0, cond_cat=None):
         if cond_cat is None:
