@@ -19,7 +19,9 @@ force-zero and legacy handling.  The arithmetic of both towers lives in third-pa
     architecture (pre-LN residual blocks around torch.nn.MultiheadAttention with an additive causal mask, erf-GELU MLP, ln_final,
     text_projection at the eot token) and from the reference's own call sites (:560-603).  The block restatement is checked against
     torch.nn.MultiheadAttention itself (what open_clip's ResidualAttentionBlock wraps); the assembly order comes from the reference
-    code.  open_clip proper never runs here: "parity unpinned" for that package, stated in DESIGN.md.
+    code, and the whole tower -- at ViT-bigG-14's width and head geometry -- against transformers.CLIPTextModelWithProjection, a second
+    implementation of the same architecture (the class SDXL's second text encoder, this checkpoint converted, is loaded into):
+    tests/test_conditioner.py::test_bigg_*.  open_clip proper never runs here: "parity unpinned" for that package, stated in DESIGN.md.
 """
 import math
 

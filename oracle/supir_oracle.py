@@ -7,6 +7,16 @@ reference: tests/golden/*.pt were produced by importing /root/reference (oracle/
 container where the reference is mounted) and tests/test_oracle_golden.py checks this file against them.
 
 Every function cites the reference code it restates (paths relative to the reference root).
+
+Third-party arithmetic on the path that is NOT in the reference tree and not installable in the build container -- "parity unpinned"
+against the packages themselves, restated from what they publish:
+  * k-diffusion 0.1.1.post1 (requirements.txt:41) `get_sigmas_karras`: restated below (kdiff_get_sigmas_karras), the DPM++ goldens
+    are generated with it, the product's function is held bitwise to it;
+  * k-diffusion `BrownianTreeNoiseSampler` -> torchsde `BrownianTree` (sampling.py:494, 687): no oracle counterpart -- a noise source has
+    no arithmetic to compare, only a stream; the product restates the published virtual-Brownian-tree algorithm
+    (supir_amd/modules/brownian.py) and tests/test_brownian.py holds its defining properties; the DPM++ solver is pinned with scripted noise;
+  * open_clip 2.17.1 (bigG text tower): oracle/cond_oracle.py, held against transformers.CLIPTextModelWithProjection
+    (tests/test_conditioner.py).
 The structure (depths, which blocks have transformers, channel counts) is read off the key names / tensor shapes,
 so the same code runs the full SDXL-sized model and the reduced-depth models used for CPU-sized tests.
 """
