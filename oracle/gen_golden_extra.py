@@ -1,6 +1,7 @@
 """ORACLE -- TEST INFRASTRUCTURE ONLY.  Extra fixtures from the REAL reference (/root/reference) for options of the path that
 `gen_golden.py` does not exercise: the sampler's `use_linear_control_scale` / `control_scale_start` (sampling.py:572-596) and
-the AdaIN colour fix (SUPIR/utils/colorfix.py:59-70, selected by color_fix_type='AdaIn', SUPIR_model.py:132-134).
+the AdaIN colour fix (SUPIR/utils/colorfix.py:59-70, selected by color_fix_type='AdaIn', SUPIR_model.py:132-134), and the DPM++ 2M restore
+samplers constructing / querying their Brownian-tree noise sampler themselves (sampling.py:494-499, 687-692).
 
     python -m oracle.gen_golden_extra      # seconds; writes tests/golden/golden_extra.pt
 """
@@ -52,6 +53,46 @@ def main():
         finally:
             torch.randn_like = orig
         print(name, gold["sampler_" + name].std().item())
+    # The reference's DPM++ 2M restore samplers (sampling.py:422-515, 663-730) constructing and querying the Brownian-tree noise
+    # sampler THEMSELVES (:494 / :687 `BrownianTreeNoiseSampler(x, sigmas_min, sigmas_max)`, :499 / :692 `noise_sampler(s_in * sigmas[i],
+    # s_in * sigmas[i + 1])`).  k-diffusion / torchsde are not installable: the name the reference imports is bound to the product's
+    # restatement (supir_amd/modules/brownian.py, k-diffusion's interface over a virtual Brownian tree) and the schedule to the oracle's
+    # Karras restatement.  What this fixture pins is the reference's CALL SITES -- constructor arguments (0-dim CPU tensors), query pattern,
+    # consumption of the global generator (the tree's seed is its one draw) -- against the product samplers run under the same torch seed;
+    # torchsde's own seed -> noise map stays parity-unpinned.
+    import sgm.modules.diffusionmodules.sampling as S
+    from oracle.supir_oracle import kdiff_get_sigmas_karras
+    from supir_amd.modules.brownian import BrownianTreeNoiseSampler
+    S.get_sigmas_karras = kdiff_get_sigmas_karras
+    queries = []
+
+    class Recording(BrownianTreeNoiseSampler):
+        def __call__(self, sigma, sigma_next):
+            queries.append((float(sigma.reshape(-1)[0]), float(sigma_next.reshape(-1)[0])))
+            return super().__call__(sigma, sigma_next)
+
+    S.BrownianTreeNoiseSampler = Recording
+    for steps in (8, 4):
+        dsm = S.RestoreDPMPP2MSampler(num_steps=steps, s_noise=1.003, eta=1.0, **sampler_cfg)
+        torch.manual_seed(1234)
+        gold[f"sampler_dpmpp_brownian_{steps}"] = dsm(lambda inp, sigma, cc, s_: den(fake_net, inp, sigma, cc, s_), x0.clone(),
+                                                      cond=dict(c), uc=dict(uc), control_scale=0.9).clone()
+        gold[f"sampler_dpmpp_brownian_{steps}_queries"] = torch.tensor(queries, dtype=torch.float64)
+        queries.clear()
+        print("dpmpp brownian", steps, gold[f"sampler_dpmpp_brownian_{steps}"].std().item())
+    big = (1, 4, 24, 40)
+    lqb = synth_tensor("lq_big", big)
+    orig_tensor = S.torch.tensor
+    S.torch.tensor = lambda *a_, **k: orig_tensor(*a_, **{kk: vv for kk, vv in k.items() if kk != "device"})   # gaussian_weights: device='cuda' literal (:750)
+    try:
+        tdsm = S.TiledRestoreDPMPP2MSampler(tile_size=16, tile_stride=8, num_steps=4, s_noise=1.003, eta=1.0, **sampler_cfg)
+        torch.manual_seed(4321)
+        gold["sampler_dpmpp_brownian_tiled_4"] = tdsm(lambda inp, sigma, cc, s_: den(fake_net, inp, sigma, cc, s_),
+                                                      synth_tensor("noised_big", big), cond=dict(c, control=lqb),
+                                                      uc=dict(uc, control=lqb), control_scale=1.0).clone()
+    finally:
+        S.torch.tensor = orig_tensor
+    queries.clear()
     a, b = synth_tensor("wa", (2, 3, 24, 40)), synth_tensor("wb", (2, 3, 24, 40), scale=0.5) + 0.2
     gold["adain"] = adaptive_instance_normalization(a, b).clone()
     torch.save(gold, OUT)

@@ -204,6 +204,52 @@ def test_tiled_dpmpp2m_sampler_vs_reference(g):
     assert rel_l2(out, g["sampler_dpmpp_tiled_4"]) <= 5e-5
 
 
+@pytest.mark.parametrize("steps", [8, 4])
+def test_restore_dpmpp2m_sampler_with_its_own_brownian_tree_vs_the_reference_call_sites(steps):
+    """The product sampler constructing and querying its default noise source (supir_amd/modules/brownian.py) against the REFERENCE
+    class doing so from its own call sites (sampling.py:494, :499) with the same class bound to the name it imports from k-diffusion
+    (oracle/gen_golden_extra.py), both under torch.manual_seed(1234): same constructor arguments, same queries, same consumption of
+    the global generator -> the same image.  (torchsde's own seed -> noise map: parity unpinned.)"""
+    import os
+    from supir_amd.modules.brownian import BrownianTreeNoiseSampler
+    from tests.helpers import GOLDEN_DIR
+    ge = torch.load(os.path.join(GOLDEN_DIR, "golden_extra.pt"), map_location="cpu", weights_only=False)
+    c, uc = _io()
+    queries = []
+
+    class Recording(BrownianTreeNoiseSampler):
+        def __call__(self, sigma, sigma_next):
+            queries.append((float(sigma.reshape(-1)[0]), float(sigma_next.reshape(-1)[0])))
+            return super().__call__(sigma, sigma_next)
+
+    den = S.DiscreteDenoiserWithControl()
+    for cls in (None, Recording):            # None: the sampler's own default
+        smp = S.RestoreDPMPP2MSampler(num_steps=steps, s_noise=1.003, eta=1.0, device="cpu", guider_config=S.LinearCFG(1.0, 4.0),
+                                      noise_sampler_cls=cls)
+        torch.manual_seed(1234)
+        out = smp(lambda i, s, cc, cs: den(_fake_net, i, s, cc, cs), synth_tensor("noised_z", (1, 4, 16, 16)).clone(), cond=c, uc=uc,
+                  control_scale=0.9)
+        assert rel_l2(out, ge[f"sampler_dpmpp_brownian_{steps}"]) <= 5e-5
+    want = ge[f"sampler_dpmpp_brownian_{steps}_queries"]
+    assert len(queries) == want.shape[0] and torch.allclose(torch.tensor(queries, dtype=torch.float64), want, rtol=1e-6, atol=0)
+
+
+def test_tiled_dpmpp2m_sampler_with_its_own_brownian_tree_vs_the_reference_call_sites():
+    import os
+    from tests.helpers import GOLDEN_DIR
+    ge = torch.load(os.path.join(GOLDEN_DIR, "golden_extra.pt"), map_location="cpu", weights_only=False)
+    c, uc = _io()
+    big = (1, 4, 24, 40)
+    lqb = synth_tensor("lq_big", big)
+    c, uc = dict(c, control=lqb), dict(uc, control=lqb)
+    den = S.DiscreteDenoiserWithControl()
+    smp = S.TiledRestoreDPMPP2MSampler(tile_size=16, tile_stride=8, num_steps=4, s_noise=1.003, eta=1.0, device="cpu",
+                                       guider_config=S.LinearCFG(1.0, 4.0))
+    torch.manual_seed(4321)
+    out = smp(lambda i, s, cc, cs: den(_fake_net, i, s, cc, cs), synth_tensor("noised_big", big), cond=c, uc=uc, control_scale=1.0)
+    assert rel_l2(out, ge["sampler_dpmpp_brownian_tiled_4"]) <= 5e-5
+
+
 def test_karras_schedule_vs_the_oracles_restatement():
     """The product's Karras schedule against the oracle's INDEPENDENT restatement of the published k-diffusion 0.1.1 function
     (oracle/supir_oracle.py kdiff_get_sigmas_karras), called the way the reference calls it (sampling.py:490-491: sigmas[-2].cpu(),
