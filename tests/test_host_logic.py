@@ -281,6 +281,40 @@ def test_tiled_vae_tiling_matches_oracle_and_reference_counts():
     assert len(TV.split_tiles(4096, 4096, 512, 32, False)[0]) == 64 and len(TV.split_tiles(512, 512, 64, 11, True)[0]) == 64
 
 
+def test_tile_geometry_sweep_vs_the_reference():
+    """split_tiles / get_best_tile_size (SUPIR/utils/tilevae.py:702-774) and _sliding_windows (sampling.py:753-766) over 600 + 150 ragged
+    cases -- sizes that are no multiple of tile or stride, long thin maps, encoder and decoder hooks -- against digests recorded from
+    the reference's own functions (oracle/gen_golden_tiling.py); the product and the oracle's restatement both."""
+    import hashlib
+    import json
+    import os
+    from oracle import supir_oracle as O
+    from supir_amd.utils import tilevae as TV
+    from tests.helpers import GOLDEN_DIR
+    gold = json.load(open(os.path.join(GOLDEN_DIR, "golden_tiling.json")))
+    digest = lambda obj: hashlib.sha1(repr(obj).encode()).hexdigest()  # noqa: E731
+    ints = lambda bb: [list(map(int, b)) for b in bb]  # noqa: E731
+    assert len(gold["vae"]) == 600 and len(gold["windows"]) == 150
+    for key, want in gold["vae"].items():
+        h, w, ts, dec = (int(v) for v in key.split(","))
+        pad = 11 if dec else 32
+        for fn in (TV.split_tiles, O.vae_split_tiles):
+            inb, outb = fn(h, w, ts, pad, bool(dec))
+            assert digest((ints(inb), ints(outb))) == want, (fn.__module__, key)
+        if key in gold["full"]:
+            assert [ints(b) for b in TV.split_tiles(h, w, ts, pad, bool(dec))] == gold["full"][key]
+    for key, want in gold["windows"].items():
+        h, w, t, st = (int(v) for v in key.split(","))
+        assert digest([tuple(map(int, c)) for c in S._sliding_windows(h, w, t, st)]) == want, key
+        # every pixel is covered and every window lies inside the map
+        wins = S._sliding_windows(h, w, t, st)
+        cover = torch.zeros(h, w, dtype=torch.bool)
+        for (a, b, c, d) in wins:
+            assert 0 <= a < b <= h and 0 <= c < d <= w and b - a == t and d - c == t
+            cover[a:b, c:d] = True
+        assert bool(cover.all())
+
+
 def test_plugin_install_registers_reference_paths():
     import importlib
     import sys
