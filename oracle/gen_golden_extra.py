@@ -93,6 +93,74 @@ def main():
     finally:
         S.torch.tensor = orig_tensor
     queries.clear()
+
+    # Local (per-tile) prompts: `cond` is a LIST with one conditioning dict per latent tile (SUPIR_model.py:168-178 builds it, the tiled
+    # samplers branch on isinstance(cond, list): sampling.py:609-616, 640-643 and 673-680, 705-708).  The analytic network here reads
+    # crossattn and vector, so a tile's own prompt matters.
+    def prompt_net(xin, tt, cc, cs):
+        bias = 0.3 * cc["crossattn"].mean(dim=(1, 2)).view(-1, 1, 1, 1) * 40.0 + 0.2 * cc["vector"].mean(dim=1).view(-1, 1, 1, 1) * 40.0
+        return torch.tanh(xin * 0.7 + cc["control"] * 0.1 + bias) * (1.0 + 0.001 * tt.view(-1, 1, 1, 1).float()) * cs
+
+    n_tiles = len(S._sliding_windows(24, 40, 16, 8))
+    local = [{"crossattn": synth_tensor(f"local.ctx{j}", (1, 77, 2048)), "vector": synth_tensor(f"local.vec{j}", (1, 2816)), "control": lqb}
+             for j in range(n_tiles)]
+    ucb = {"crossattn": ctx[1:], "vector": y[1:], "control": lqb}
+    S.torch.tensor = lambda *a_, **k: orig_tensor(*a_, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        tsm = S.TiledRestoreEDMSampler(tile_size=16, tile_stride=8, num_steps=3, s_churn=5, s_noise=1.01, restore_cfg=4.0, **sampler_cfg)
+        tdsm = S.TiledRestoreDPMPP2MSampler(tile_size=16, tile_stride=8, num_steps=4, s_noise=1.003, eta=1.0, **sampler_cfg)
+    finally:
+        S.torch.tensor = orig_tensor
+    it = iter([synth_tensor(f"local.eps{i}", big) for i in range(3)])
+    torch.randn_like = lambda t_, **k2: next(it).to(t_)
+    try:
+        gold["sampler_tiled_local_prompts"] = tsm(lambda inp, sigma, cc, s_: den(prompt_net, inp, sigma, cc, s_), synth_tensor("noised_big", big),
+                                                  cond=[dict(cj) for cj in local], uc=dict(ucb), x_center=synth_tensor("xc_big", big),
+                                                  control_scale=0.9).clone()
+    finally:
+        torch.randn_like = orig
+    torch.manual_seed(777)
+    gold["sampler_dpmpp_tiled_local_prompts"] = tdsm(lambda inp, sigma, cc, s_: den(prompt_net, inp, sigma, cc, s_),
+                                                     synth_tensor("noised_big", big), cond=[dict(cj) for cj in local], uc=dict(ucb),
+                                                     control_scale=1.0).clone()
+    # the same run with ONE prompt for all tiles differs: the fixture really exercises the per-tile branch
+    it = iter([synth_tensor(f"local.eps{i}", big) for i in range(3)])
+    torch.randn_like = lambda t_, **k2: next(it).to(t_)
+    try:
+        single = tsm(lambda inp, sigma, cc, s_: den(prompt_net, inp, sigma, cc, s_), synth_tensor("noised_big", big), cond=dict(local[0]),
+                     uc=dict(ucb), x_center=synth_tensor("xc_big", big), control_scale=0.9)
+    finally:
+        torch.randn_like = orig
+    print("local prompts: tiled", gold["sampler_tiled_local_prompts"].std().item(), "vs one prompt rel",
+          ((single - gold["sampler_tiled_local_prompts"]).norm() / single.norm()).item(),
+          "dpmpp tiled", gold["sampler_dpmpp_tiled_local_prompts"].std().item())
+    queries.clear()
+
+    # SUPIRModel.prepare_condition (SUPIR/models/SUPIR_model.py:152-179) run UNBOUND on a stand-in `self` whose conditioner records what
+    # it is asked: the batch keys / values it builds, the prompt concatenation, and -- for local prompts (p[0] a list) -- one conditioner
+    # call per tile with the unconditional batch on the first only.
+    import types
+    import warnings
+    from SUPIR.models.SUPIR_model import SUPIRModel
+
+    class RecordingConditioner:
+        def __init__(self):
+            self.calls = []
+
+        def get_unconditional_conditioning(self, batch, batch_uc=None):
+            rec = lambda b_: None if b_ is None else {k: (v.tolist() if torch.is_tensor(v) and v.numel() <= 8 else (list(v.shape) if torch.is_tensor(v) else v))  # noqa: E731
+                                                      for k, v in sorted(b_.items())}
+            self.calls.append((rec(batch), rec(batch_uc)))
+            n = len(self.calls)
+            return {"tag": f"c{n}"}, (None if batch_uc is None else {"tag": f"uc{n}"})
+
+    z4 = synth_tensor("lq", (2, 4, 16, 16))
+    for name, p_, n_ in (("plain", ["a cat", "a dog"], 2), ("local", [["tile zero", "tile one", "tile two"]], 1)):
+        stub = types.SimpleNamespace(conditioner=RecordingConditioner(), ae_dtype=torch.bfloat16)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c_, uc_ = SUPIRModel.prepare_condition(stub, z4[:n_], p_, ", best quality", "blurry", n_)
+        gold["prepare_condition_" + name] = {"calls": stub.conditioner.calls, "c": c_, "uc": uc_}
     a, b = synth_tensor("wa", (2, 3, 24, 40)), synth_tensor("wb", (2, 3, 24, 40), scale=0.5) + 0.2
     gold["adain"] = adaptive_instance_normalization(a, b).clone()
     torch.save(gold, OUT)

@@ -110,6 +110,74 @@ def test_tiled_sampler_vs_reference(g, tile_batch):
     assert rel_l2(out, g["sampler_tiled_fake"]) <= 5e-5
 
 
+def _prompt_net(xin, tt, cc, cs):
+    """The analytic network of the local-prompt fixtures (oracle/gen_golden_extra.py): reads crossattn and vector, so a tile's prompt matters."""
+    bias = 0.3 * cc["crossattn"].mean(dim=(1, 2)).view(-1, 1, 1, 1) * 40.0 + 0.2 * cc["vector"].mean(dim=1).view(-1, 1, 1, 1) * 40.0
+    return torch.tanh(xin * 0.7 + cc["control"] * 0.1 + bias) * (1.0 + 0.001 * tt.view(-1, 1, 1, 1).float()) * cs
+
+
+@pytest.mark.parametrize("tile_batch", [1, 4])
+def test_tiled_samplers_with_local_prompts_vs_reference(tile_batch):
+    """`cond` as a LIST of per-tile conditioning dicts (SUPIR_model.py:168-178 -> sampling.py:609-616, 640-643; DPM++: 673-680, 705-708;
+    what gradio_demo_tiled feeds): the product's tiled samplers against the reference classes run on the same per-tile prompts."""
+    import os
+    from tests.helpers import GOLDEN_DIR
+    ge = torch.load(os.path.join(GOLDEN_DIR, "golden_extra.pt"), map_location="cpu", weights_only=False)
+    _, uc = _io()
+    big = (1, 4, 24, 40)
+    lqb = synth_tensor("lq_big", big)
+    n_tiles = len(S._sliding_windows(24, 40, 16, 8))
+    local = [{"crossattn": synth_tensor(f"local.ctx{j}", (1, 77, 2048)), "vector": synth_tensor(f"local.vec{j}", (1, 2816)), "control": lqb}
+             for j in range(n_tiles)]
+    uc = dict(uc, control=lqb)
+    den = S.DiscreteDenoiserWithControl()
+    smp = S.TiledRestoreEDMSampler(tile_size=16, tile_stride=8, num_steps=3, s_churn=5, s_noise=1.01, restore_cfg=4.0, device="cpu",
+                                   guider_config=S.LinearCFG(1.0, 4.0), tile_batch=tile_batch)
+    with _Noise([synth_tensor(f"local.eps{i}", big) for i in range(3)]):
+        out = smp(lambda i, s, cc, cs: den(_prompt_net, i, s, cc, cs), synth_tensor("noised_big", big), cond=[dict(cj) for cj in local],
+                  uc=dict(uc), x_center=synth_tensor("xc_big", big), control_scale=0.9)
+    assert rel_l2(out, ge["sampler_tiled_local_prompts"]) <= 5e-5
+    with pytest.raises(AssertionError):          # "Number of local prompts should be equal to number of tiles" (sampling.py:615)
+        smp(lambda i, s, cc, cs: den(_prompt_net, i, s, cc, cs), synth_tensor("noised_big", big), cond=[dict(cj) for cj in local[:-1]],
+            uc=dict(uc), x_center=synth_tensor("xc_big", big))
+    dsm = S.TiledRestoreDPMPP2MSampler(tile_size=16, tile_stride=8, num_steps=4, s_noise=1.003, eta=1.0, device="cpu",
+                                       guider_config=S.LinearCFG(1.0, 4.0))
+    torch.manual_seed(777)
+    out = dsm(lambda i, s, cc, cs: den(_prompt_net, i, s, cc, cs), synth_tensor("noised_big", big), cond=[dict(cj) for cj in local],
+              uc=dict(uc), control_scale=1.0)
+    assert rel_l2(out, ge["sampler_dpmpp_tiled_local_prompts"]) <= 5e-5
+
+
+@pytest.mark.parametrize("name,p,n", [("plain", ["a cat", "a dog"], 2), ("local", [["tile zero", "tile one", "tile two"]], 1)])
+def test_prepare_condition_vs_the_reference_method(name, p, n):
+    """SUPIRModel.prepare_condition (SUPIR_model.py:152-179), run unbound on a stand-in `self` with a recording conditioner -- the
+    reference's method when the fixture was written (oracle/gen_golden_extra.py), the product's here: the same batches (keys, size /
+    crop / aesthetic tensors, prompt + positive-prompt concatenation, negative prompt), and for local prompts one conditioner call per
+    tile with the unconditional batch on the first call only; `c` a list, `uc` the first call's."""
+    import os
+    import types
+    from supir_amd.models.supir_model import SUPIRModel
+    from tests.helpers import GOLDEN_DIR
+    want = torch.load(os.path.join(GOLDEN_DIR, "golden_extra.pt"), map_location="cpu", weights_only=False)["prepare_condition_" + name]
+
+    class RecordingConditioner:
+        def __init__(self):
+            self.calls = []
+
+        def get_unconditional_conditioning(self, batch, batch_uc=None):
+            rec = lambda b_: None if b_ is None else {k: (v.tolist() if torch.is_tensor(v) and v.numel() <= 8 else (list(v.shape) if torch.is_tensor(v) else v))  # noqa: E731
+                                                      for k, v in sorted(b_.items())}
+            self.calls.append((rec(batch), rec(batch_uc)))
+            k = len(self.calls)
+            return {"tag": f"c{k}"}, (None if batch_uc is None else {"tag": f"uc{k}"})
+
+    import contextlib
+    stub = types.SimpleNamespace(conditioner=RecordingConditioner(), ae_dtype=torch.bfloat16, _ae_scope=contextlib.nullcontext)
+    c, uc = SUPIRModel.prepare_condition(stub, synth_tensor("lq", (2, 4, 16, 16))[:n], p, ", best quality", "blurry", n)
+    assert stub.conditioner.calls == want["calls"]
+    assert c == want["c"] and uc == want["uc"]
+
+
 def test_plugin_resolves_reference_targets():
     cfg = {"target": "sgm.modules.diffusionmodules.sampling.RestoreEDMSampler",
            "params": {"num_steps": 7, "restore_cfg": 4.0, "s_churn": 0, "s_noise": 1.003, "device": "cpu",
