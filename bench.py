@@ -387,6 +387,73 @@ def replay_profile(args, tune_path):
         shutil.rmtree(d, ignore_errors=True)
 
 
+LINE_MAX_BYTES = 4096     # the driver parses the LAST stdout line out of a tail of a few KB (BENCH_r05.json: a 20 KB line -> parsed null)
+
+_ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_graph_replay", "avg_launch_us", "avg_launch_us_graph_replay",
+                  "launches_per_unet_step", "algorithmic_gflop_per_launch", "algorithmic_mb_per_launch", "share_of_step_time", "traffic",
+                  "traffic_over_algorithmic")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "unet_step_1024px_cfg_doubled_s", "config1_end_to_end_s", "seconds_sample", "sample")
+_CONFIG_KEYS = ("workload", "edm_steps", "resolution", "images_per_gpu_per_step", "parallelism", "hip_graph")
+
+
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def compact_line(full, details_path=None):
+    """The ONE stdout line of the bench contract, built from the full record: the contract's keys, `roofline` and `cpu_baseline` reduced to
+    scalars, three supplementary scalars -- always <= LINE_MAX_BYTES (tests/test_bench_line.py).  Everything else (per-kernel breakdowns,
+    per-shape counter arrays, kernel picks) is in the side file `details` names."""
+    line = {k: _r(full.get(k), 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                         "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    line["config"] = {k: cfg[k] for k in _CONFIG_KEYS if k in cfg}
+    rf = full.get("roofline")
+    line["roofline"] = None if rf is None else {k: _r(rf.get(k)) for k in _ROOFLINE_KEYS if k in rf}
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if cb is None else {k: _r(cb.get(k), 6) for k in _CPU_KEYS if k in cb}
+    for k in ("ms_per_unet_step", "ms_per_unet_step_inside_the_sampler", "unet_step_tflops", "end_to_end_tflops_per_gpu", "output_finite"):
+        if full.get(k) is not None:
+            line[k] = _r(full[k], 3)
+    b = full.get("batched")
+    if b:
+        line["batched"] = {k: _r(v, 4) for k, v in b.items()}
+    tail = (full.get("kernel_breakdown_vae_colorfix") or {}).get("wall_ms_eager")
+    if tail is not None:
+        line["vae_colorfix_tail_ms"] = tail
+    if full.get("process_group"):
+        line["process_group"] = full["process_group"]
+    if details_path:
+        line["details"] = details_path
+    out = json.dumps(line)
+    # the free-text fields are the only unbounded ones: shorten them until the line fits
+    for obj, key in ((line.get("cpu_baseline"), "sample"), (line["config"], "workload")):
+        if len(out) <= LINE_MAX_BYTES:
+            break
+        if obj and isinstance(obj.get(key), str):
+            obj[key] = obj[key][:max(40, len(obj[key]) - (len(out) - LINE_MAX_BYTES) - 16)] + "..."
+            out = json.dumps(line)
+    assert len(out) <= LINE_MAX_BYTES, len(out)
+    return out
+
+
+def write_details(full):
+    """Full record -> gpurun_out/bench_details.json (merged back by gpurun) or, without that directory, the temp dir.  Returns the path."""
+    go = os.path.join(ROOT, "gpurun_out")
+    try:
+        try:
+            os.makedirs(go, exist_ok=True)
+            path = os.path.join(go, "bench_details.json")
+        except OSError:
+            import tempfile
+            path = os.path.join(tempfile.gettempdir(), "supir_bench_details.json")
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError:
+        return None
+
+
 def _fused_step_on():
     from supir_amd.modules import sampling
     return bool(sampling.FUSED_EDM_STEP)
@@ -708,7 +775,7 @@ def main():
 
     if rank == 0:
         n_img = args.steps * world * ipg
-        line = {
+        full = {
             "metric": "1024px 50-step EDM denoise images/sec", "value": n_img / dt, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.diff_dtype, "data": "synthetic",
@@ -726,11 +793,14 @@ def main():
             "end_to_end_tflops_per_gpu": IMAGE_TFLOP_1024 * args.steps * ipg / dt if P == 1024 and args.edm_steps == 50 else None,
             "kernel_breakdown_unet_step": breakdown, "kernel_picks": picks,
         }
-        line.update(extra)
+        full.update(extra)
         if dist_on:
-            line["process_group"] = {"backend": dist.get_backend(), "world_size": world,
+            full["process_group"] = {"backend": dist.get_backend(), "world_size": world,
                                      "collectives_forced_on_one_rank": bool(world == 1)}
-        print(json.dumps(line), flush=True)
+        # everything measured goes to a side file; stdout carries ONE short line (the driver keeps only a few KB of the tail, and a
+        # 20 KB line left round 5 without a parsed record).  Nothing is printed after it, on either stream.
+        details = write_details(full)
+        print(compact_line(full, details), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
