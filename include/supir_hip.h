@@ -8,7 +8,8 @@
  * Conventions
  *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
  *   - caller owns every buffer (including workspaces); the library allocates nothing.  Its only mutable state is the per-thread
- *     last-HIP-error code read by supir_last_hip_error.  Optional per-launch requests (next-weight prefetch, GroupNorm partials
+ *     last-HIP-error code read by supir_last_hip_error (the process-global kernel-variant switches of the measurement tools,
+ *     `supir_debug_knob`, exist only in libsupir_hip_tools.so, built with -DSUPIR_TOOLS; the product libraries do not export the symbol).  Optional per-launch requests (next-weight prefetch, GroupNorm partials
  *     from the producer) are an ARGUMENT: the *_ex entry points take a `const supir_launch_hints*` (may be NULL) and the entry
  *     points without it carry no request (ABI 2 removed the thread-local one-shot setters of ABI 1); results never depend on a
  *     prefetch request;
@@ -36,9 +37,14 @@ extern "C" {
 /* activation codes */
 #define SUPIR_ACT_NONE 0
 #define SUPIR_ACT_SILU 1
-#define SUPIR_ACT_GEGLU 2 /* W rows interleaved [32 value | 32 gate] per 64; output has N/2 columns */
+#define SUPIR_ACT_GEGLU 2 /* x * gelu(gate), W rows interleaved [32 value | 32 gate] per 64; output has N/2 columns.  gelu is a FITTED form
+                           * g * sigmoid(g * poly(g^2)), |error| <= 2.5e-5 against erf (below bf16 resolution): the speed default */
 #define SUPIR_ACT_GELU 3  /* erf GELU (OpenCLIP text tower MLP) */
 #define SUPIR_ACT_QUICKGELU 4 /* x * sigmoid(1.702 x) (OpenAI CLIP text tower MLP) */
+#define SUPIR_ACT_GEGLU_ERF 5 /* SUPIR_ACT_GEGLU with the reference's own arithmetic: F.gelu = 0.5 g (1 + erf(g / sqrt 2)),
+                               * sgm/modules/attention.py:89-91.  Same layouts, same tiles; the choice is THIS ARGUMENT of each launch
+                               * (every GEGLU-capable tile honours it) -- the library has no switch that changes arithmetic.
+                               * Host mirror: SUPIR_EXACT_GELU=1 / supir_amd.ops.EXACT_GELU routes every GEGLU launch here. */
 
 /* output modes */
 #define SUPIR_OUT_BF16 0

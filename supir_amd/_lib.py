@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libsupir_hip.so")
 LIB_PATH_F16 = os.path.join(_HERE, "libsupir_hip_f16.so")
 # the fp32 service (csrc/f32, include/supir_hip_f32.h): its own, much smaller, entry-point table
 LIB_PATH_F32 = os.path.join(_HERE, "libsupir_hip_f32.so")
+# the bf16 sources with -DSUPIR_TOOLS: the only build that contains `supir_debug_knob` (process-global kernel-VARIANT switches for A/B
+# measurements and variant-vs-variant tests).  Never loaded by the product path; `tools_knob` swaps it in for the duration of a block.
+LIB_PATH_TOOLS = os.path.join(_HERE, "libsupir_hip_tools.so")
 
 _ERR = {-1: "SUPIR_ERR_ARG (null pointer / bad size)", -2: "SUPIR_ERR_SHAPE (unsupported shape or alignment)",
         -3: "SUPIR_ERR_HIP (launch failed)"}
@@ -130,29 +133,15 @@ ABI_VERSION = 2   # include/supir_hip.h: round 5 removed the thread-local one-sh
 _lib = None       # the bf16 library (the product default)
 _lib_f16 = None   # the fp16 build, loaded on first use
 _lib_f32 = None   # the fp32 service, loaded on first use
+_lib_tools = None  # the tools build (tests / tools only)
 
 
 class SupirHipError(RuntimeError):
     pass
 
 
-def load(dtype=None):
-    """Load the library (building is __graft_entry__.build()'s / supir_amd.build's job, never done implicitly).
-    dtype: element type of the 16-bit operands the caller is about to pass -- torch.float16 selects libsupir_hip_f16.so,
-    anything else (None, torch.bfloat16) the bf16 library."""
-    global _lib, _lib_f16
-    if dtype is torch.float32:
-        return load_f32()
-    f16 = dtype is torch.float16
-    cur = _lib_f16 if f16 else _lib
-    if cur is not None:
-        return cur
-    path = LIB_PATH_F16 if f16 else LIB_PATH
-    if not os.path.exists(path):
-        raise SupirHipError(
-            f"{path} not found: run `python -m supir_amd.build` (hipcc, gfx950). The HIP extension is mandatory; "
-            "there is no CPU / PyTorch fallback on the product path.")
-    lib = ctypes.CDLL(path)   # RTLD_LOCAL: the two builds export the same names and must not see each other's symbols
+def _bind(path, want):
+    lib = ctypes.CDLL(path)   # RTLD_LOCAL: the builds export the same names and must not see each other's symbols
     lib.supir_abi_version.restype = c_int
     lib.supir_abi_version.argtypes = []
     lib.supir_target_arch.restype = c_char_p
@@ -173,9 +162,61 @@ def load(dtype=None):
     lib.supir_elem_type.argtypes = []
     if lib.supir_abi_version() != ABI_VERSION:
         raise SupirHipError(f"{os.path.basename(path)} ABI version mismatch")
-    want = b"f16" if f16 else b"bf16"
     if lib.supir_elem_type() != want:
         raise SupirHipError(f"{os.path.basename(path)} was built for {lib.supir_elem_type()!r} elements, expected {want!r}")
+    return lib
+
+
+def load_tools():
+    """libsupir_hip_tools.so: the bf16 sources + `supir_debug_knob(which, value)` (-DSUPIR_TOOLS).  Tests and tools only."""
+    global _lib_tools
+    if _lib_tools is None:
+        if not os.path.exists(LIB_PATH_TOOLS):
+            raise SupirHipError(f"{LIB_PATH_TOOLS} not found: run `python -m supir_amd.build`")
+        _lib_tools = _bind(LIB_PATH_TOOLS, b"bf16")
+        _lib_tools.supir_debug_knob.argtypes = [c_int, c_int]
+        _lib_tools.supir_debug_knob.restype = c_int
+    return _lib_tools
+
+
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def tools_knob(which=None, value=0):
+    """Inside the block, bf16 operands reach the TOOLS build (`load()` returns it) with variant switch `which` set to `value`; on exit the
+    switch is cleared and the product library is back.  Yields the tools library (for direct entry-point calls / further knob calls)."""
+    global _lib
+    load()
+    tools = load_tools()
+    prev, _lib = _lib, tools
+    try:
+        if which is not None:
+            check(tools.supir_debug_knob(which, value), "supir_debug_knob", tools)
+        yield tools
+    finally:
+        for k in range(8):
+            tools.supir_debug_knob(k, 0)
+        _lib = prev
+
+
+def load(dtype=None):
+    """Load the library (building is __graft_entry__.build()'s / supir_amd.build's job, never done implicitly).
+    dtype: element type of the 16-bit operands the caller is about to pass -- torch.float16 selects libsupir_hip_f16.so,
+    anything else (None, torch.bfloat16) the bf16 library."""
+    global _lib, _lib_f16
+    if dtype is torch.float32:
+        return load_f32()
+    f16 = dtype is torch.float16
+    cur = _lib_f16 if f16 else _lib
+    if cur is not None:
+        return cur
+    path = LIB_PATH_F16 if f16 else LIB_PATH
+    if not os.path.exists(path):
+        raise SupirHipError(
+            f"{path} not found: run `python -m supir_amd.build` (hipcc, gfx950). The HIP extension is mandatory; "
+            "there is no CPU / PyTorch fallback on the product path.")
+    lib = _bind(path, b"f16" if f16 else b"bf16")
     if f16:
         _lib_f16 = lib
     else:

@@ -16,12 +16,15 @@ HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "supir_h
 LIB = os.path.join(HERE, "libsupir_hip.so")
 LIB_F16 = os.path.join(HERE, "libsupir_hip_f16.so")
 LIB_F32 = os.path.join(HERE, "libsupir_hip_f32.so")
+LIB_TOOLS = os.path.join(HERE, "libsupir_hip_tools.so")   # the bf16 sources with -DSUPIR_TOOLS: adds supir_debug_knob (kernel-variant switches for
+                                                          # A/B measurements and variant-vs-variant tests); never loaded by the product path
 SOURCES_F32 = [os.path.join("f32", "f32.hip")]
 HEADERS_F32 = [os.path.join("..", "..", "include", "supir_hip.h"), os.path.join("..", "..", "include", "supir_hip_f32.h")]
 # (library, object sub-directory, extra compile flags, extra link flags, sources, headers).  -Bsymbolic on the fp16 / fp32 builds: the
 # libraries define the same symbols; each must bind to its own even if a host application loads them RTLD_GLOBAL.
 VARIANTS = [(LIB, "", [], [], SOURCES, HEADERS), (LIB_F16, "f16", ["-DSUPIR_F16"], ["-Wl,-Bsymbolic"], SOURCES, HEADERS),
-            (LIB_F32, "f32", [], ["-Wl,-Bsymbolic"], SOURCES_F32, HEADERS_F32)]
+            (LIB_F32, "f32", [], ["-Wl,-Bsymbolic"], SOURCES_F32, HEADERS_F32),
+            (LIB_TOOLS, "tools", ["-DSUPIR_TOOLS"], ["-Wl,-Bsymbolic"], SOURCES, HEADERS)]
 
 
 def _stale(lib=LIB, sources=SOURCES, headers=HEADERS):

@@ -22,17 +22,30 @@ static int apply_hints(GemmArgs& a, const supir_launch_hints* h) {
     return SUPIR_OK;
 }
 
+// The activation code of the ABI -> the kernels' (act, fast_gelu): SUPIR_ACT_GEGLU is the fitted GELU (|error| <= 2.5e-5), SUPIR_ACT_GEGLU_ERF
+// the reference's erf (sgm/modules/attention.py:89-91).  An ARGUMENT of every launch: no process state selects arithmetic.
+static void set_act(GemmArgs& a, int act) {
+    a.act = act == SUPIR_ACT_GEGLU_ERF ? SUPIR_ACT_GEGLU : act;
+    a.fast_gelu = act == SUPIR_ACT_GEGLU ? 1 : 0;
+}
+
+#ifdef SUPIR_TOOLS
+// libsupir_hip_tools.so only (-DSUPIR_TOOLS; A/B measurements and the tests that hold kernel variants against each other): process-global
+// switches that select kernel VARIANTS.  The product libraries do not contain this state or the symbol: supir_debug_knob_value is the
+// constant 0 there (kernels.h).
 static int g_debug_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 int supir_debug_knob_value(int which) { return (which >= 0 && which < 8) ? g_debug_knobs[which] : 0; }
+#endif
 
 extern "C" {
 
-// tools-only measurement switch (kernels.h); deliberately not in include/supir_hip.h
+#ifdef SUPIR_TOOLS
 int supir_debug_knob(int which, int value) {
     if (which < 0 || which >= 8) return SUPIR_ERR_ARG;
     g_debug_knobs[which] = value;
     return SUPIR_OK;
 }
+#endif
 
 int supir_last_hip_error(void) { return g_last_hip_error; }
 const char* supir_hip_error_string(int code) { return hipGetErrorString((hipError_t)code); }
@@ -40,20 +53,20 @@ const char* supir_hip_error_string(int code) { return hipGetErrorString((hipErro
 int supir_abi_version(void) { return 2; }
 const char* supir_target_arch(void) { return "gfx950"; }
 const char* supir_elem_type(void) { return SUPIR_ELEM_NAME; }
-int supir_gemm_tile_for(int M, int N, int act) { return supir_gemm_select_tile(M, N, act, -1); }
+int supir_gemm_tile_for(int M, int N, int act) { return supir_gemm_select_tile(M, N, act == SUPIR_ACT_GEGLU_ERF ? SUPIR_ACT_GEGLU : act, -1); }
 
 int supir_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, const float* bias,
                        const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                        int out_mode, float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 45 || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
+    if (act < 0 || act > SUPIR_ACT_GEGLU_ERF || out_mode < 0 || out_mode > 2 || tile > 45 || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
     a.bias = bias; a.rowbias = (const bf16_t*)rowbias; a.res = (const bf16_t*)residual;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.ld_rb = ld_rowbias;
     a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
-    a.act = act; a.out_mode = out_mode; a.alpha = alpha;
+    set_act(a, act); a.out_mode = out_mode; a.alpha = alpha;
     if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)))
         return SUPIR_ERR_SHAPE;
     if (const int rc = apply_hints(a, hints)) return rc;
@@ -72,21 +85,21 @@ int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, i
                           float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                           const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 4 || out_mode < 0 || out_mode > 2 || tile > 45 || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
+    if (act < 0 || act > SUPIR_ACT_GEGLU_ERF || out_mode < 0 || out_mode > 2 || tile > 45 || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
-    if (rowstats_out && (out_mode != 0 || act == 2 || rs_ld <= 0)) return SUPIR_ERR_ARG;
+    if (rowstats_out && (out_mode != 0 || act == SUPIR_ACT_GEGLU || act == SUPIR_ACT_GEGLU_ERF || rs_ld <= 0)) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
     a.bias = bias; a.res = (const bf16_t*)residual;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr;
     a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
-    a.act = act; a.out_mode = out_mode; a.alpha = alpha;
+    set_act(a, act); a.out_mode = out_mode; a.alpha = alpha;
     a.rowstats_out = rowstats_out; a.rs_ld = rs_ld;
     a.ln_stats = ln_stats; a.ln_ld = ln_ld; a.ln_slots = ln_slots; a.ln_colsum = ln_colsum; a.ln_eps = ln_eps;
     if (out_mode != 2 && (ldc % 4 != 0 || (residual && ldr % 4 != 0))) return SUPIR_ERR_SHAPE;
     if (rowstats_out) {  // the slot index is tile_n * waves_n + wave_n: the caller's rs_ld must cover the tile actually used
-        const int sel = supir_gemm_select_tile(M, N, act, tile < 0 ? -1 : (tile & 7));
+        const int sel = supir_gemm_select_tile(M, N, a.act, tile < 0 ? -1 : (tile & 7));
         const int bn = (tile == 32 || tile == 35 || tile == 38) ? 80 : (tile == 33 || tile == 34) ? 160 : (tile == 39 || tile == 45) ? 128 : (tile == 40 || tile == 42) ? 256 : (sel == 1 || sel == 3) ? 64 : (sel == 5 ? 256 : 128);
         if ((N + bn - 1) / bn > rs_ld || (rs_ld & 1)) return SUPIR_ERR_ARG;
     }
@@ -387,7 +400,7 @@ static void pack_common(GemmArgs& a, const supir_gemm_shape& sh, const supir_gem
     a.A = (const bf16_t*)q.A; a.Wt = (const bf16_t*)q.W; a.C = q.C; a.C2 = q.C2;
     a.bias = q.bias; a.rowbias = (const bf16_t*)q.rowbias; a.res = (const bf16_t*)q.residual;
     a.lda = q.lda; a.ldc = q.ldc; a.ldc2 = q.ldc2; a.ldr = q.ldr; a.ld_rb = q.ld_rowbias;
-    a.act = sh.act; a.out_mode = sh.out_mode; a.alpha = sh.alpha; a.n_split = sh.n_split;
+    set_act(a, sh.act); a.out_mode = sh.out_mode; a.alpha = sh.alpha; a.n_split = sh.n_split;
     a.rowstats_out = q.rowstats_out; a.rs_ld = q.rs_ld;
     a.ln_stats = q.ln_stats; a.ln_ld = q.ln_ld; a.ln_slots = q.ln_slots; a.ln_colsum = q.ln_colsum; a.ln_eps = sh.ln_eps;
     a.gn_part_out = q.gn_partials_out;
@@ -399,7 +412,7 @@ static void pack_common(GemmArgs& a, const supir_gemm_shape& sh, const supir_gem
 int supir_gemm_grouped(const supir_gemm_shape* shape, const supir_gemm_problem* problems, int n, void* stream) {
     if (!shape || !problems || n < 1 || n > 2) return SUPIR_ERR_ARG;
     const supir_gemm_shape& sh = *shape;
-    if (sh.kind < 0 || sh.kind > 2 || sh.act < 0 || sh.act > 4 || sh.out_mode < 0 || sh.out_mode > 2) return SUPIR_ERR_ARG;
+    if (sh.kind < 0 || sh.kind > 2 || sh.act < 0 || sh.act > SUPIR_ACT_GEGLU_ERF || sh.out_mode < 0 || sh.out_mode > 2) return SUPIR_ERR_ARG;
     GemmArgs a[2] = {};
     for (int i = 0; i < n; ++i) {
         const supir_gemm_problem& q = problems[i];
@@ -418,7 +431,7 @@ int supir_gemm_grouped(const supir_gemm_shape* shape, const supir_gemm_problem* 
             a[i].M = sh.M; a[i].N = sh.N; a[i].K = sh.K;
             if ((q.rowbias || sh.out_mode == 2 || sh.kind == SUPIR_GROUP_QKV) && sh.rows_per_batch <= 0) return SUPIR_ERR_ARG;
             a[i].rows_per_batch = sh.rows_per_batch > 0 ? sh.rows_per_batch : sh.M;
-            if (q.rowstats_out && (sh.out_mode != 0 || sh.act == 2 || q.rs_ld <= 0 || (q.rs_ld & 1))) return SUPIR_ERR_ARG;
+            if (q.rowstats_out && (sh.out_mode != 0 || sh.act == SUPIR_ACT_GEGLU || sh.act == SUPIR_ACT_GEGLU_ERF || q.rs_ld <= 0 || (q.rs_ld & 1))) return SUPIR_ERR_ARG;
         }
         if (a[i].M <= 0 || a[i].N <= 0 || a[i].K <= 0) return SUPIR_ERR_ARG;
     }

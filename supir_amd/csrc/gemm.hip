@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
                         for (int e = 0; e < 4; ++e) {
                             const float v = rs * (acc[i][0][rg * 4 + e] - mu * cv[e]) + bv[e];
                             const float g = rs * (acc[i][1][rg * 4 + e] - mu * cg[e]) + bg[e];
-                            r[e] = v * gelu_f(g);
+                            r[e] = v * (p.fast_gelu ? gelu_fast_f(g) : gelu_f(g));
                         }
                         u32x2 o = {f2bf_pk(r[0], r[1]), f2bf_pk(r[2], r[3])};
                         const int no = (n0 >> 1) + wn * 32 + 8 * rg + 4 * half;

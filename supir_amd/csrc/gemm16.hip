@@ -981,7 +981,6 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     GemmArgsN<NP> pp;
     for (int q = 0; q < NP; ++q) {
         pp.p[q] = a_in[q];
-        pp.p[q].fast_gelu = supir_debug_knob_value(0) ? 0 : 1;   // one switch for every GEGLU epilogue (tile 37 reads the same knob)
         pp.p[q].korder = (CONV && S == 8 && supir_debug_knob_value(6) != 1) ? 1 : 0;   // tile 42 / 45 convolutions: chunk-major K order (knob 6 = 1: tap-major)
     }
     GemmArgs& a = pp.p[0];

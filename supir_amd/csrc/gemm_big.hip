@@ -73,8 +73,8 @@ constexpr int LOADS = A_LOADS + W_LOADS;
 constexpr int C_RS = 80 * 2 + 16;                  // staged output row: 80 bf16 + 16 B pad
 
 // NP = 2: two problems of identical shape in one grid, problem q on XCDs [4 q, 4 q + 4) (see gemm16.hip)
-// FASTGELU: gelu2_fast instead of gelu2 in the epilogue (the product default since round 4; the exact-erf instantiation is kept
-// selectable for A/B runs: supir_debug_knob(0, 1))
+// FASTGELU: gelu2_fast (SUPIR_ACT_GEGLU, the fitted GELU) or gelu2 (SUPIR_ACT_GEGLU_ERF, the reference's erf) in the epilogue: the caller's
+// activation code selects the instantiation (GemmArgs::fast_gelu)
 template <int NP, bool FASTGELU = true>
 __global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgsN<NP> pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -333,7 +333,7 @@ static int launch_big(const GemmArgs* a_in, hipStream_t st) {
             return SUPIR_ERR_HIP;
         attr_set = true;
     }
-    if (supir_debug_knob_value(0)) {
+    if (!a.fast_gelu) {   // SUPIR_ACT_GEGLU_ERF: the reference's erf
         SUPIR_LAUNCH((geglu_big_kernel<NP, false>), dim3(NP * tiles), dim3(512), smem, st, pp);
     } else {
         SUPIR_LAUNCH((geglu_big_kernel<NP, true>), dim3(NP * tiles), dim3(512), smem, st, pp);

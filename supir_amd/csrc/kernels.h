@@ -15,8 +15,9 @@ struct GemmArgs {
     int H, W, Cin, OH, OW, stride, pad_t, pad_l, up;  // conv geometry (virtual input = 2H x 2W when up)
     int act;                // 0 none, 1 SiLU, 2 GEGLU (value/gate interleaved per 32 columns)
     int korder;             // convolutions on the eight-phase tile: 1 = K loop as (channel chunk, tap), 0 = (tap, channel chunk) (set by the launcher)
-    int fast_gelu;          // GEGLU epilogues: 1 = the fitted GELU (gelu_fast_f, |error| <= 2.5e-5), 0 = erf; set by the launchers from ONE
-                            // switch for every GEGLU tile (supir_debug_knob 0), so a layer's arithmetic does not depend on the tile that ran it
+    int fast_gelu;          // GEGLU epilogues: 1 = the fitted GELU (gelu_fast_f, |error| <= 2.5e-5; SUPIR_ACT_GEGLU), 0 = erf (SUPIR_ACT_GEGLU_ERF); set
+                            // by csrc/api.hip from the caller's activation code and honoured by EVERY GEGLU tile (gemm.hip, gemm16.hip,
+                            // gemm_big.hip), so a layer's arithmetic does not depend on the tile that ran it
     int out_mode;           // 0 bf16 [M][ldc], 1 fp32 [M][ldc], 2 bf16 transposed [batch][N][ldc]
     float alpha;            // result = alpha * act(acc + bias + rowbias) + residual
     int order;              // tile order inside an XCD's id range: 0 = tile_m fastest (W panel shared), 1 = tile_n fastest
@@ -141,7 +142,11 @@ int supir_gemm16_qkv_launch_n(const GemmArgs* a, int n, hipStream_t st);
 // knob 4: fused q|k|v tile: 0 = product policy, 1 = 256 x 160, 2 = 256 x 128
 // knob 6: K order of tile 42's convolutions: 0 = (channel chunk, tap) (product), 1 = (tap, channel chunk) as every other tile
 // knob 5: xattn_q workgroup order: 0 = 2-D XCD grid (product), 1 = 1-D ranges with the heads fastest (round 4)
-int supir_debug_knob_value(int which);
+#ifdef SUPIR_TOOLS
+int supir_debug_knob_value(int which);      // libsupir_hip_tools.so: process-global variant switches (csrc/api.hip)
+#else
+static inline int supir_debug_knob_value(int) { return 0; }   // product libraries: no switch state exists; every variant test folds away
+#endif
 bool supir_gemm_big_supported(const GemmArgs& a);
 int supir_gemm_big_launch(const GemmArgs& a, hipStream_t st);
 int supir_gemm_big_launch_n(const GemmArgs* a, int n, hipStream_t st);

@@ -641,6 +641,17 @@ def paired_run(fn_a, fn_b, side=None):
 
 
 # --------------------------------------------------------------------------------------------- GEMM family
+# GEGLU arithmetic (include/supir_hip.h): act code 2 = SUPIR_ACT_GEGLU, the fitted GELU (|error| <= 2.5e-5, the speed default); code 5 =
+# SUPIR_ACT_GEGLU_ERF, the reference's erf (sgm/modules/attention.py:89-91).  SUPIR_EXACT_GELU=1 (or ops.EXACT_GELU = True before the
+# first call / graph capture) routes every GEGLU launch of the module layer to the erf form -- an argument of each launch, not a state
+# of the library; same tiles, same layouts.
+EXACT_GELU = _os.environ.get("SUPIR_EXACT_GELU", "0") == "1"
+
+
+def _abi_act(act):
+    return 5 if (act == 2 and EXACT_GELU) else act
+
+
 def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=0, alpha=1.0, out=None,
          out_dtype=None, tile=-1, alt16=None, gn_part=False):
     """out[M,N] = alpha*act(a[M,K] @ w[N,K]^T + bias + rowbias[batch]) + residual.  act=2 (GEGLU) -> N/2 columns.
@@ -679,7 +690,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
     def launch(t, outp=None, hints=None):
         wq, bq = wb(t)
         return lib.supir_gemm_bf16_ex(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
-                                      _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, act, om, alpha, t,
+                                      _p(bq), _p(rowbias), ld_rb, rows_per_batch, _p(residual), ldr, _abi_act(act), om, alpha, t,
                                       None if hints is None else _ct.byref(hints), _stream())
 
     inplace = residual is not None and residual.data_ptr() == out.data_ptr()
@@ -713,7 +724,7 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
     def make(t, outp=None):
         wq, bq = wb(t)
-        sh = _lib.GemmShape(kind=_lib.GROUP_GEMM, tile=t, M=M, N=N, K=K, rows_per_batch=rows_per_batch, act=act, out_mode=om, alpha=alpha)
+        sh = _lib.GemmShape(kind=_lib.GROUP_GEMM, tile=t, M=M, N=N, K=K, rows_per_batch=rows_per_batch, act=_abi_act(act), out_mode=om, alpha=alpha)
         pr = _lib.GemmProblem(A=a.data_ptr(), W=wq.data_ptr(), C=(out if outp is None else outp).data_ptr(), bias=_p(bq),
                               rowbias=_p(rowbias), residual=_p(residual), gn_partials_out=None if part is None else part.buf.data_ptr(),
                               lda=lda, ldc=ldc, ldr=ldr, ld_rowbias=ld_rb)
@@ -845,7 +856,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
     def launch(t, outp=None, hints=None):
         wq, cq, bq = wcb(t)
         return lib.supir_gemm_bf16_ln_ex(a.data_ptr(), wq.data_ptr(), (out if outp is None else outp).data_ptr(), M, N, K, lda, ldc,
-                                         _p(bq), _p(residual), ldr, act, om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots,
+                                         _p(bq), _p(residual), ldr, _abi_act(act), om, rpb, alpha, t, _p(stats), rs_ld, ln_p, ln_ld, ln_slots,
                                          _p(cq), ln_eps, None if hints is None else _ct.byref(hints), _stream())
 
     inplace = residual is not None and residual.data_ptr() == out.data_ptr()
@@ -874,7 +885,7 @@ def gemm_ln(a, w, bias=None, *, residual=None, act=0, alpha=1.0, out=None, tile=
 
     def make(t, outp=None):
         wq, cq, bq = wcb(t)
-        sh = _lib.GemmShape(kind=_lib.GROUP_GEMM, tile=t, M=M, N=N, K=K, rows_per_batch=rpb, act=act, out_mode=om, alpha=alpha, ln_eps=ln_eps)
+        sh = _lib.GemmShape(kind=_lib.GROUP_GEMM, tile=t, M=M, N=N, K=K, rows_per_batch=rpb, act=_abi_act(act), out_mode=om, alpha=alpha, ln_eps=ln_eps)
         pr = _lib.GemmProblem(A=a.data_ptr(), W=wq.data_ptr(), C=(out if outp is None else outp).data_ptr(), bias=_p(bq),
                               residual=_p(residual), rowstats_out=_p(stats), ln_stats=ln_p, ln_colsum=_p(cq), lda=lda, ldc=ldc, ldr=ldr,
                               rs_ld=rs_ld, ln_ld=ln_ld, ln_slots=ln_slots)

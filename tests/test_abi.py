@@ -230,3 +230,42 @@ def test_hinted_entry_points_take_their_requests_as_an_argument():
     ln = (fake, fake, fake, 200, 80, 128, 128, 80, None, None, 0, 0, 0, 0, 1.0, 32, None, 0, None, 0, 0, None, 1e-5)
     assert lib.supir_gemm_bf16_ln_ex(*ln, ctypes.byref(bad), None) == -1
     assert lib.supir_gemm_bf16_ln_ex(*ln, None, None) == -2
+
+
+def test_arithmetic_choices_are_arguments_and_variant_switches_are_tools_only():
+    """VERDICT r05 item 6.  The GELU of a GEGLU epilogue is chosen by the activation CODE of each launch (SUPIR_ACT_GEGLU = fitted,
+    SUPIR_ACT_GEGLU_ERF = the reference's erf, sgm/modules/attention.py:89-91), both declared in the header and validated by every GEMM entry
+    point; the process-global kernel-variant switches (`supir_debug_knob`) exist only in libsupir_hip_tools.so -- `nm -D` of the three product
+    libraries shows no such symbol -- so the header's "only mutable state is the last-error code" is true of what ships."""
+    import subprocess
+    src = open(os.path.join(ROOT, "include", "supir_hip.h")).read()
+    codes = dict(re.findall(r"#define (SUPIR_ACT_\w+) (\d+)", src))
+    assert codes["SUPIR_ACT_GEGLU"] == "2" and codes["SUPIR_ACT_GEGLU_ERF"] == "5" and len(set(codes.values())) == len(codes) == 6
+    assert "supir_debug_knob" not in _header_functions()
+    for path in (_lib.LIB_PATH, _lib.LIB_PATH_F16, _lib.LIB_PATH_F32):
+        syms = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+        assert "supir_abi_version" in syms and "debug_knob" not in syms, path
+    lib = _lib.load()
+    assert not hasattr(lib, "supir_debug_knob")
+    tools = _lib.load_tools()
+    assert tools is not lib and tools.supir_debug_knob(0, 0) == 0 and tools.supir_debug_knob(8, 1) == -1
+    for name in _header_functions():
+        assert hasattr(tools, name), name
+    fake = 0x10000
+    # code 5 passes validation and reaches the tile's shape check (tile 34 does not fit M = 200); code 6 is an argument error
+    assert lib.supir_gemm_bf16(fake, fake, fake, 200, 320, 128, 128, 160, None, None, 0, 0, None, 0, 5, 0, 1.0, 34, None) == -2
+    assert lib.supir_gemm_bf16(fake, fake, fake, 200, 320, 128, 128, 160, None, None, 0, 0, None, 0, 6, 0, 1.0, 34, None) == -1
+    assert lib.supir_gemm_bf16_ln(fake, fake, fake, 256, 320, 128, 128, 160, None, None, 0, 6, 0, 256, 1.0, 34, None, 0, None, 0, 0, None, 1e-5, None) == -1
+    assert lib.supir_gemm_tile_for(2048, 10240, 5) == lib.supir_gemm_tile_for(2048, 10240, 2)
+    # the tools context hands bf16 operands to the tools build and gives the product library back
+    with _lib.tools_knob(6, 1) as t:
+        assert _lib.load() is t is tools
+    assert _lib.load() is lib
+
+
+def test_exact_gelu_switch_of_the_host_mirror(monkeypatch):
+    from supir_amd import ops
+    monkeypatch.setattr(ops, "EXACT_GELU", False)
+    assert [ops._abi_act(a) for a in range(5)] == [0, 1, 2, 3, 4]
+    monkeypatch.setattr(ops, "EXACT_GELU", True)
+    assert [ops._abi_act(a) for a in range(5)] == [0, 1, 5, 3, 4]

@@ -148,6 +148,25 @@ def test_wrapper_vs_oracle_with_measured_bf16_floor(wrap):
         assert e <= max(2e-2, 1.5 * floor)
 
 
+def test_wrapper_with_the_references_erf_gelu(wrap, monkeypatch):
+    """SUPIR_EXACT_GELU=1 / ops.EXACT_GELU: every GEGLU launch of the network call takes SUPIR_ACT_GEGLU_ERF -- the reference's F.gelu
+    (sgm/modules/attention.py:89-91) instead of the fitted form.  Same bar against the fp32 oracle; the two runs differ (the switch reaches
+    the kernels) by less than the bf16 floor."""
+    from supir_amd import ops
+    x, t, cond = _wrapper_inputs()
+    sd = _oracle_sd(wrap)
+    ref, floor = _bf16_floor(sd, x, t, cond, 1.0)
+    with torch.no_grad():
+        fitted = wrap(x, t, cond, 1.0).clone()
+        monkeypatch.setattr(ops, "EXACT_GELU", True)
+        exact = wrap(x, t, cond, 1.0).clone()
+        assert torch.equal(exact, wrap(x, t, cond, 1.0))
+    monkeypatch.setattr(ops, "EXACT_GELU", False)
+    e_fit, e_erf, d = rel_l2(fitted, ref), rel_l2(exact, ref), rel_l2(exact, fitted)
+    print(f"mini wrapper: fitted GELU vs fp32 oracle {e_fit:.3e}; erf GELU {e_erf:.3e}; erf vs fitted {d:.3e}; ATen-bf16 floor {floor:.3e}")
+    assert e_erf <= max(2e-2, 1.5 * floor) and 0 < d < floor
+
+
 def test_wrapper_graph_replay_matches_eager(wrap):
     x, t, cond = _wrapper_inputs()
     with torch.no_grad():

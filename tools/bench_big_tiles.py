@@ -52,14 +52,10 @@ for (B, H, W, Cin, Cout, up) in CONVS:
     fns = {f"tile{t}": (lambda t=t: ops.conv3x3(x, w, bias, upsample=up, tile=t)) for t in tiles}
     if 42 in tiles:      # tile 42 with the tap-major K order of every other tile (tools knob 6 = 1) beside its chunk-major default
         from supir_amd import _lib
-        _l = _lib.load(BF)
 
         def tapmajor():
-            _l.supir_debug_knob(6, 1)
-            try:
+            with _lib.tools_knob(6, 1):      # libsupir_hip_tools.so: the only build with variant switches
                 return ops.conv3x3(x, w, bias, upsample=up, tile=42)
-            finally:
-                _l.supir_debug_knob(6, 0)
         fns["tile42_tapmajor"] = tapmajor
     r = ab(fns, max(3, int(2000.0 / (fl / 1e9))))   # fl / 1e9 = microseconds at 1 PFLOP/s: ~2 ms of launches per round
     row = {"kind": "conv3x3", "shape": [B, H, W, Cin, Cout, int(up)], "M": M}

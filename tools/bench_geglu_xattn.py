@@ -63,12 +63,11 @@ for (B, H, T, Tk, C) in [(2, 20, 1024, 77, 1280), (2, 10, 4096, 77, 640), (8, 20
     state = {"i": 0}
 
     def run(knob):
-        lib.supir_debug_knob(5, knob)
         state["i"] = (state["i"] + 1) % 16
-        return ops.xattn_q(x, wqs[state["i"]], None, k, vt, B, H, T, Tk)
+        with _lib.tools_knob(5, knob):      # both arms on libsupir_hip_tools.so (the only build with variant switches)
+            return ops.xattn_q(x, wqs[state["i"]], None, k, vt, B, H, T, Tk)
 
     r = ab({"grid2d": lambda: run(0), "ranges1d": lambda: run(1)}, 40)
-    lib.supir_debug_knob(5, 0)
     row = {"kind": "xattn_q", "shape": [B, H, T, Tk, C]}
     for kk, (med, mn) in r.items():
         row[kk] = {"us_median": round(med, 2), "us_min": round(mn, 2), "tflops_median": round(fl / med / 1e6, 1)}

@@ -45,12 +45,11 @@ def main():
         outs = {}
         for rep in range(3):
             for form, knob in (("mfma", 0), ("valu", 1)):
-                lib.supir_debug_knob(7, knob)
-                for _ in range(3):
-                    run()
-                us[form].append(round(timed(run, 20), 2))
-                outs[form] = out.clone()
-        lib.supir_debug_knob(7, 0)
+                with _lib.tools_knob(7, knob):      # both arms on libsupir_hip_tools.so (the only build with variant switches)
+                    for _ in range(3):
+                        run()
+                    us[form].append(round(timed(run, 20), 2))
+                    outs[form] = out.clone()
         d = (outs["mfma"].float() - outs["valu"].float())
         flop = 2.0 * B * H * W * Cout * 9 * Cin
         byt = B * H * W * (4.0 * Cin + 2.0 * Cout * (2 if with_add else 1))

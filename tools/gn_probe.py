@@ -12,10 +12,8 @@ if os.environ.get("SUPIR_LIB"):
 from supir_amd import ops
 
 if os.environ.get("SUPIR_KNOB2"):      # debug knob 2 of csrc/norm.hip (apply chunking), see csrc/kernels.h
-    import ctypes
-    _l = _lib.load()
-    _l.supir_debug_knob.argtypes = [ctypes.c_int, ctypes.c_int]
-    _l.supir_debug_knob(2, int(os.environ["SUPIR_KNOB2"]))
+    _ctx = _lib.tools_knob(2, int(os.environ["SUPIR_KNOB2"]))      # libsupir_hip_tools.so for the rest of the process
+    _ctx.__enter__()
 BF = torch.bfloat16
 torch.manual_seed(0)
 SHAPES = [(2, 16384, 320, 0), (2, 16384, 640, 320), (2, 4096, 640, 0), (2, 4096, 1280, 640), (2, 1024, 1280, 0), (2, 1024, 1280, 1280),
