@@ -270,7 +270,10 @@ def kdiff_get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0, device="cpu"):
     sigma_min = sigmas[-2].cpu(), sigma_max = sigmas[0].cpu() (0-dim fp32 tensors) and device = x.device: the ramp is a default-dtype
     (fp32) linspace on the CPU, the rho-th roots and the rho-th power are fp32 TENSOR pows, and the zero is appended before the move.
     Independent of supir_amd.modules.sampling.get_sigmas_karras, which tests/test_host_logic.py checks against THIS function.
-    Still third-party: "parity unpinned" against an installed k-diffusion, pinned against the published formula."""
+    Still third-party: "parity unpinned" against an installed k-diffusion, pinned against the published FORMULA only.  In particular the
+    published releases may build the ramp with `torch.linspace(0, 1, n, device=device)`, i.e. evaluate the linspace and both pows on
+    x.device (the GPU) where this restatement evaluates them on the host: the two differ by at most an ulp of fp32 per sigma, and which of
+    them a given k-diffusion release does cannot be checked here -- "held bitwise" in tests means bitwise to THIS restatement."""
     ramp = torch.linspace(0, 1, n)
     min_inv_rho = sigma_min ** (1 / rho)
     max_inv_rho = sigma_max ** (1 / rho)

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const GemmP p) {
     __shared__ float Ws[2][BN][LD];
     const supir_f32_gemm_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;   // M tiles on grid.x (limit 2^31 - 1: the 3-channel conv_out of a 2048^2 image is 64 K+ row tiles)
     const int z0 = blockIdx.z % d.nz0, z1 = blockIdx.z / d.nz0;
     const float* A = d.A + (size_t)z0 * d.a_s0 + (size_t)z1 * d.a_s1;
     const float* W = d.W + (size_t)z0 * d.w_s0 + (size_t)z1 * d.w_s1;
@@ -209,11 +209,11 @@ extern "C" int supir_f32_gemm(const supir_f32_gemm_desc* dp, void* stream) {
     if (nz > 65535) return SUPIR_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     if (d.M >= 1024 && d.N >= 96) {
-        dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, (unsigned)nz);
+        dim3 grid((d.M + 127) / 128, (d.N + 127) / 128, (unsigned)nz);
         if (grid.y > 65535) return SUPIR_ERR_SHAPE;
         F32_LAUNCH((f32_gemm_kernel<128, 128>), grid, dim3(256), 0, s, p);
     } else {
-        dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, (unsigned)nz);
+        dim3 grid((d.M + 63) / 64, (d.N + 63) / 64, (unsigned)nz);
         if (grid.y > 65535) return SUPIR_ERR_SHAPE;
         F32_LAUNCH((f32_gemm_kernel<64, 64>), grid, dim3(256), 0, s, p);
     }

@@ -418,7 +418,10 @@ class TiledRestoreEDMSampler(RestoreEDMSampler):
             x = x.contiguous()
             dist.broadcast(x, src=src, group=self.process_group)
         ctx = None
-        if not use_local_prompt and type(self).sampler_step is RestoreEDMSampler.sampler_step and x_center is not None:
+        # the fused step's two tile kernels stack at most 64 tiles per group (SUPIR_MAX_TILES, csrc/kernels.h) and take exact T x T windows
+        # inside the canvas; anything else (tile_batch > 64, a canvas smaller than a tile) runs the generic loop below
+        fits = kb <= 64 and x.shape[-2] >= self.tile_size and x.shape[-1] >= self.tile_size
+        if fits and not use_local_prompt and type(self).sampler_step is RestoreEDMSampler.sampler_step and x_center is not None:
             ctx = self._fused_ctx(denoiser, x)
         if ctx is not None:
             return self._call_fused(ctx, x, tiles, tile_weights, lq, static[0], sf, num_sigmas, x_center, control_scale,
@@ -588,6 +591,25 @@ class IntervalNoiseSampler:
         return torch.randn(self.shape, device=self.device, dtype=self.dtype, generator=self.gen)
 
 
+def default_noise_sampler_cls():
+    """The class the DPM++ samplers construct their noise source from (sampling.py:494, 687).  The reference imports
+    `k_diffusion.sampling.BrownianTreeNoiseSampler` (k-diffusion 0.1.1.post1 over torchsde, requirements.txt:41): when BOTH packages import
+    in this process -- a user running with the reference's own requirements installed -- that very class is used, so identical seeds give
+    the reference's exact noise stream.  Otherwise (this image: neither is installable) `brownian.BrownianTreeNoiseSampler`, the restatement
+    of the published virtual Brownian tree behind the same interface (stream parity with torchsde unpinned: DESIGN section 4).
+    SUPIR_BROWNIAN=native forces the restatement."""
+    import os
+    if os.environ.get("SUPIR_BROWNIAN", "auto") != "native":
+        try:
+            import torchsde  # noqa: F401  (k-diffusion's class is a thin wrapper over torchsde.BrownianTree)
+            from k_diffusion.sampling import BrownianTreeNoiseSampler as theirs
+            if callable(theirs):
+                return theirs
+        except Exception:   # noqa: BLE001 -- absent or broken third-party packages: the restatement serves
+            pass
+    return BrownianTreeNoiseSampler
+
+
 def _neg_log(s):
     return s.log().neg()
 
@@ -600,7 +622,7 @@ class RestoreDPMPP2MSampler(BaseDiffusionSampler):
                  restore_cfg_s_tmin=0.05, eta=1.0, noise_sampler_cls=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.s_noise, self.eta = s_noise, eta
-        self.noise_sampler_cls = noise_sampler_cls or BrownianTreeNoiseSampler      # sampling.py:494, 687
+        self.noise_sampler_cls = noise_sampler_cls or default_noise_sampler_cls()      # sampling.py:494, 687
 
     def denoise(self, x, denoiser, sigma, cond, uc, control_scale=1.0, cond_cat=None):
         if cond_cat is None:
@@ -644,7 +666,10 @@ class RestoreDPMPP2MSampler(BaseDiffusionSampler):
 
     def _karras(self, x, cond, uc, num_steps):
         x, s_in, sigmas, num_sigmas, cond, uc, sf = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        n = self.num_steps if num_steps is None else num_steps
+        # the reference builds the Karras schedule from self.num_steps even when the call names another count (sampling.py:491, 685: the
+        # loop length follows the call, the schedule the constructor -- a longer call then indexes past the schedule and raises, a shorter
+        # one stops before sigma 0); batchify_sample always calls with num_steps=None (SUPIR_model.py:100, 128), where the two agree
+        n = self.num_steps
         smin, smax = sf[-2], sf[0]
         sig_host = get_sigmas_karras(n, smin, smax, device="cpu")
         return x, s_in, sig_host.to(x.device), num_sigmas, cond, uc, [float(v) for v in sig_host], smin, smax

@@ -580,9 +580,7 @@ def _run_pair(a, b, tile):
         # pass), and do not retry the pairing on later steps
         _run_single(a, pfs[0])
         _run_single(b, pfs[1])
-        pkey = getattr(a, "pkey", None)
-        if pkey is not None:
-            _TUNE[pkey] = -2
+        _TUNE[("pair",) + (a.tkey if gemm_like else a.key)] = -2      # the key _pair_choice looks the pairing up under
         return
     _lib.check(rc, {"attn": "supir_flash_attn_d64_grouped", "gn": "supir_groupnorm_grouped"}.get(a.kind, "supir_gemm_grouped"), a.lib)
     if a.trace is not None:

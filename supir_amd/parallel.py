@@ -42,6 +42,14 @@ def broadcast_module_(module, src=0, bucket_elems=1 << 28, skip=("sigmas",), pay
     # communication device (RCCL moves device memory only) and copied back to wherever the rank keeps the tensor
     comm = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     state = {k: t for k, t in module.state_dict().items() if not any(k.endswith(s) for s in skip)}
+    # state_dict() omits persistent=False buffers (the text towers' position_ids / causal mask, conditioner.py): on a meta-constructed
+    # replica those are uninitialised memory after to_empty() -- they travel too.  Same order on every rank: named_buffers()
+    # follows module registration order, which the shared factory fixes.
+    have = {id(t) for t in state.values()}
+    for k, t in module.named_buffers():
+        if id(t) not in have and not any(k.endswith(s) for s in skip):
+            state["<buffer>." + k] = t
+            have.add(id(t))
     for t in state.values():
         if not t.is_floating_point():
             w = t.to(comm)
@@ -82,13 +90,21 @@ def construct_replica(factory, device, materialize):
     materialize=False (every other rank of a replicated job): construct on the META device -- no allocation, no initialiser kernels,
     no host RAM -- then `to_empty(device)`: parameters AND buffers exist uninitialised and must ALL be received
     (`broadcast_module_(module, skip=())`: buffers computed in constructors, e.g. the denoiser's sigma table, are not recomputed on
-    this rank).  SURVEY 8(e): weights replicated, one broadcast; this keeps rank > 0 start-up at allocation + receive."""
+    this rank; non-persistent buffers travel too).  What cannot travel is a plain tensor ATTRIBUTE a constructor computes (neither parameter
+    nor buffer): none may be left on meta -- asserted here, so such a module fails at construction instead of computing on garbage.
+    SURVEY 8(e): weights replicated, one broadcast; this keeps rank > 0 start-up at allocation + receive."""
     if materialize:
         with torch.device(device):
             return factory()
     with torch.device("meta"):
         module = factory()
-    return module.to_empty(device=device)
+    module = module.to_empty(device=device)
+    for name, sub in module.named_modules():
+        for attr, val in vars(sub).items():
+            if isinstance(val, torch.Tensor) and val.device.type == "meta":
+                raise RuntimeError(f"construct_replica: {name or type(sub).__name__}.{attr} is a constructor-computed tensor attribute left on the "
+                                   "meta device (register it as a buffer so that the weight broadcast carries it)")
+    return module
 
 
 def shard_items(n_items, rank=None, world=None):

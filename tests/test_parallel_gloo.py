@@ -74,6 +74,27 @@ def _worker(rank, world, port, q):
         same = same and all(torch.equal(v, rsd[k]) for k, v in mdl.state_dict().items())
     except NotImplementedError:
         same = False
+    # persistent=False buffers (absent from state_dict: the text towers' position_ids / causal mask) travel too, and a plain
+    # tensor ATTRIBUTE computed in a constructor -- which cannot travel -- makes the meta construction fail instead of leaving garbage
+    class WithHidden(torch.nn.Module):
+        def __init__(self, attr=False):
+            super().__init__()
+            self.lin = torch.nn.Linear(4, 4)
+            self.register_buffer("mask", torch.arange(12.0).view(3, 4), persistent=False)
+            if attr:
+                self.table = torch.arange(5.0)
+    m = parallel.construct_replica(WithHidden, "cpu", materialize=(rank == 0))
+    if rank != 0:
+        with torch.no_grad():
+            m.mask.fill_(-1.0)          # whatever to_empty left there
+    parallel.broadcast_module_(m, src=0, skip=())
+    same = same and "mask" not in m.state_dict() and torch.equal(m.mask, torch.arange(12.0).view(3, 4))
+    if rank != 0:
+        try:
+            parallel.construct_replica(lambda: WithHidden(attr=True), "cpu", materialize=False)
+            same = False
+        except RuntimeError as e:
+            same = same and "table" in str(e)
     # autotune winners: ranks that tuned differently end with rank 0's picks
     from supir_amd import ops
     ops._TUNE.clear(); ops._CHOICE.clear()
