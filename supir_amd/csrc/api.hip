@@ -151,7 +151,7 @@ int supir_conv3x3_bf16_ex(const void* X, const void* W, void* Y, int B, int H, i
                           float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!X || !W || !Y) return SUPIR_ERR_ARG;
     if (B <= 0 || H <= 0 || Wd <= 0 || OH <= 0 || OW <= 0) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || (tile > 35 && (tile < 38 || tile > 40) && tile != 42 && tile != 45)) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || (tile > 35 && (tile < 38 || tile > 40) && tile != 42 && tile != 45 && (tile < 48 || tile > 51))) return SUPIR_ERR_ARG;
     if (stride != 1 && stride != 2) return SUPIR_ERR_SHAPE;
     if (upsample && stride != 1) return SUPIR_ERR_SHAPE;
     if (ldy % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)) return SUPIR_ERR_SHAPE;

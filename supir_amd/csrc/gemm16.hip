@@ -79,7 +79,27 @@ __device__ __attribute__((aligned(256))) uint32_t g16_zero_page[64];
 // tile 35, so that TWO workgroups fit a CU -- in the two-stream step one of GLVControl's and one of the UNet encoder's (VERDICT r03
 // item 2: every other tile of this family takes 104-156 KB and a CU then runs one workgroup of one chain at a time).  Same loader,
 // same fragment layout, same epilogue; the K-group exchange disappears.
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1>
+//
+// LDS-staged HALO form of the 3x3 convolutions (HW_ > 0 = the map width; round 6, tiles 48-50).  The implicit-GEMM loader above stages every
+// input pixel of a tile nine times (once per tap: (BM + BN) x 128 B per 64-wide K step); the counter passes show the price (fetch + write
+// 2.2-6.1 x the operands, profiles/pmc_traffic.json) and the L2 -> LDS fill is what bounds these tiles.  Here a tile is BM / W whole rows of
+// the map; per 64-channel chunk its (rows + 2) x (W + 2) input pixels -- the halo tile, zero page for what lies outside the image -- are
+// staged ONCE, and the nine taps read their token fragments out of it at shifted addresses: the K loop runs (chunk, tap), the ring stages
+// carry the W tiles only.  Per chunk a 128 x 80 tile on a 32 x 32 map stages 26 + 90 KB instead of 144 + 90 KB.
+//   * halo pixel P = hy (W + 2) + hx lives at P * 128 B, its 16-byte chunk c at physical slot c ^ (P & 7): the 16 lanes of a ds_read_b128
+//     group read 16 CONSECUTIVE pixels starting anywhere (the tap shift) and two adjacent chunks -- slot = (P & 1) * 8 + (c ^ (P & 7)) is a
+//     bijection on any such window (enumerated: tools/probes/halo_swizzle_check.py), so every tap's fragment reads are conflict-free;
+//   * two halo buffers (chunk parity).  The eight waves load chunk c + 2 into the buffer chunk c leaves, 8-pixel pieces (1 KB per wave
+//     instruction, wave w takes pieces w, w + 8, ...), HQ pieces per wave and iteration in the NLI iterations after the last step of chunk
+//     c -- early enough that the counted wait of the W ring (S = 3: everything but the previous iteration's loads has landed) covers them
+//     S - 1 iterations later, before the first step of chunk c + 2;
+//   * two K groups: group g takes steps g, g + 2, ... of the (chunk, tap) sequence -- taps of one chunk alternate between the groups, both
+//     read the same halo buffers; the schedule above is in ITERATIONS (one step of each group), which both groups share;
+//   * a wave's number of loads now varies by iteration (0..HQ halo pieces on top of the W chunks): the counted wait is selected, wave
+//     uniformly, by the count of the previous iteration.
+// Everything after the main loop (K-group exchange, epilogue, GroupNorm partials, prefetch) is the code of the other forms: a tile is still
+// BM consecutive rows of the [M][N] output.
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1, int HW_ = 0>
 __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) void gemm16_kernel(const GemmArgsN<NP> pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NX = 8 / NP;                                               // XCDs per problem
@@ -90,8 +110,21 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     constexpr int NW = WM * WN;                          // waves per K group
     constexpr bool PH8 = S == 8;                         // the eight-phase schedule (tile 42): S names the schedule, the ring is 2 deep
     constexpr int SD = PH8 ? 2 : S;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, RING = SD * STAGE_BYTES;
-    constexpr int A_Q = BM / 8 / NW;                     // 8-row chunks of A per wave and K step (chunk id = wave + NW q)
+    constexpr bool HALO = HW_ > 0;
+    static_assert(!HALO || (CONV && S != 8 && !MIXED && !TRANS && NP == 1 && BM % HW_ == 0 && HW_ % 16 == 0 && WM * WN * KS == 8), "halo form");
+    constexpr int H_ROWS = HALO ? BM / HW_ : 1;          // output rows of the map per tile
+    constexpr int H_RS = HW_ + 2;                        // halo row stride in pixels
+    constexpr int H_PIX = (H_ROWS + 2) * H_RS;
+    constexpr int H_PIECES = (H_PIX + 7) / 8;            // 8-pixel (1 KB) pieces of one halo tile
+    constexpr int H_BYTES = H_PIECES * 1024;
+    constexpr int H_PQ = (H_PIECES + 7) / 8;             // pieces per wave (piece id = wave + 8 q, all eight waves of the workgroup)
+    constexpr int H_NLI_MAX = KS == 2 ? (S == 3 ? 3 : 4) : (S == 3 ? 7 : 8);   // iterations between "chunk c's buffer is free" and "chunk c + 2's data must be covered by the wait"
+    constexpr int H_HQ = (H_PQ + H_NLI_MAX - 1) / H_NLI_MAX;                   // pieces per wave and load iteration
+    constexpr int H_NLI = (H_PQ + H_HQ - 1) / H_HQ;                            // load iterations per halo tile
+    static_assert(!HALO || H_HQ <= 2, "halo pieces per iteration: the counted wait has three variants");
+    constexpr int A_BYTES = HALO ? 0 : BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, RING = SD * STAGE_BYTES;
+    constexpr int H_OFF = KS * RING;                     // LDS: [ring of group 0 | ring of group 1 | halo 0 | halo 1]
+    constexpr int A_Q = HALO ? 0 : BM / 8 / NW;          // 8-row chunks of A per wave and K step (chunk id = wave + NW q)
     constexpr int B_CH = BN / 8, B_Q = (B_CH + NW - 1) / NW;   // chunks of W per tile / per wave (the last q may be partial)
     constexpr int LOADS = A_Q + B_Q;                     // global->LDS instructions per wave and stage
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, MIH = MI / KS;
@@ -125,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     constexpr int C_STAGE = 16 * C_RS;                         // one 16-token block per wave
     constexpr int OFF_CST = XCH, OFF_BIAS = OFF_CST + NWT * C_STAGE, OFF_RED = OFF_BIAS + 2 * BN * 4;
     constexpr int OFF_GN = OFF_RED + WN * BM * 8;               // GroupNorm column partials: [wave 0..NWT-1][WTN][2] fp32
-    static_assert(OFF_GN + NWT * WTN * 8 <= KS * RING - (PH8 ? 256 : 0), "epilogue scratch must fit the LDS rings");
+    static_assert(OFF_GN + NWT * WTN * 8 <= KS * RING + (HALO ? 2 * H_BYTES : 0) - (PH8 ? 256 : 0), "epilogue scratch must fit the LDS rings");
 
     // wave-uniform ids as scalars (readfirstlane): LDS destinations / branches on them stay on the scalar unit
     const int bwave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // wave inside the workgroup, 0..7
@@ -163,14 +196,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
     const bf16_t* a_src = p.A + (size_t)(m0 + wave * 8 + lrow) * p.lda + lchunk * 8 + kg * 64;
-    const bf16_t* b_src = p.Wt + (size_t)(n0 + wave * 8 + lrow) * p.K + lchunk * 8 + kg * 64;
+    const bf16_t* b_src = p.Wt + (size_t)(n0 + wave * 8 + lrow) * p.K + lchunk * 8 + (HALO ? 0 : kg * 64);
     const size_t a_qstride = (size_t)(8 * NW) * p.lda, b_qstride = (size_t)(8 * NW) * p.K;
     // 3x3 convolution as implicit GEMM (same scheme as gemm.hip): K runs (ky, kx, cin) and a 64-wide K step never straddles a tap
     // (Cin % 64 == 0; Cin % 128 == 0 with two K groups); the gather address of each of this lane's A rows is computed once per
     // tap; halo / padding rows read the zero page; stride 2, asymmetric padding and nearest-2x upsampling fold into the gather
-    int c_iy0[CONV ? A_Q : 1], c_ix0[CONV ? A_Q : 1];
-    const bf16_t* c_base[CONV ? A_Q : 1];
-    const bf16_t* c_tap[CONV ? A_Q : 1];
+    int c_iy0[CONV && !HALO ? A_Q : 1], c_ix0[CONV && !HALO ? A_Q : 1];
+    const bf16_t* c_base[CONV && !HALO ? A_Q : 1];
+    const bf16_t* c_tap[CONV && !HALO ? A_Q : 1];
     int c_cin0 = kg * 64, c_ky = 0, c_kx = 0;
     const int VH = p.up ? 2 * p.H : p.H, VW = p.up ? 2 * p.W : p.W;
     // eight-phase schedule: a tile's 256 rows lie in ONE batch element (dispatcher), so the image base is wave-uniform and a lane keeps a
@@ -178,7 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     int ph8_toff[CONV && PH8 ? A_Q : 1];
     const bf16_t* ph8_cbase = nullptr;
     auto conv_set_tap = [&]() {
-        if constexpr (CONV) {
+        if constexpr (CONV && !HALO) {
 #pragma unroll
             for (int q = 0; q < A_Q; ++q) {
                 int iy = c_iy0[q] + c_ky, ix = c_ix0[q] + c_kx;
@@ -189,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             }
         }
     };
-    if constexpr (CONV) {
+    if constexpr (CONV && !HALO) {
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
             // eight-phase schedule: q = 2 h + qq is this lane's row of A-half h (token fragments [4h, 4h + 4) of both wave rows), wave row qq
@@ -204,6 +237,53 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         if constexpr (PH8) ph8_cbase = p.A + (size_t)(m0 / p.rows_per_batch) * p.H * p.W * p.lda + lchunk * 8;
         conv_set_tap();
     }
+    // ---- halo form: scalar (wave-uniform) state.  Step t of the (chunk, tap) sequence has chunk t / 9, tap t % 9, weight K offset
+    // tap * Cin + chunk * 64; group g walks t = g, g + KS, ...  h_s*: the step whose W tile is staged next; h_r*: the step being read
+    int h_stap = kg, h_schunk = 0, h_rtap = kg, h_rchunk = 0;
+    int h_it = 0;                   // iteration (one step of each group) about to run
+    int h_next = 2;                 // next chunk whose halo tile is loaded in the loop (0 and 1: prologue)
+    int h_it0 = 8 / KS + 1;         // first load iteration of chunk h_next: the iteration after the last step of chunk h_next - 2, (9 c + 8) / KS + 1
+    int h_cnt_prev = 0;             // halo pieces this wave issued in the previous iteration (the counted wait depends on it)
+    const int h_nchunks = HALO ? p.Cin >> 6 : 0;
+    int h_poff[HALO ? H_PQ : 1];    // per lane: element offset of its 16 bytes of piece (bwave + 8 q) inside the image, < 0: zero page
+    int h_p0[HALO ? MI : 1];        // per lane: halo pixel index of token l15 of fragment i at tap (0, 0)
+    const bf16_t* h_img = nullptr;
+    if constexpr (HALO) {
+        const int b = m0 / p.rows_per_batch, y0 = (m0 - b * p.rows_per_batch) / HW_;
+        h_img = p.A + (size_t)b * p.H * p.W * p.lda;
+        const int lg = (lane & 7) ^ (lane >> 3);     // logical chunk of this lane's slot: pixel P = 8 piece + (lane >> 3), so P & 7 = lane >> 3
+#pragma unroll
+        for (int q = 0; q < H_PQ; ++q) {
+            const int P = (bwave + 8 * q) * 8 + (lane >> 3);
+            const int hy = P / H_RS, hx = P - hy * H_RS;
+            const int y = y0 - 1 + hy, x = hx - 1;
+            const bool ok = P < H_PIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)HW_;
+            h_poff[q] = ok ? (y * HW_ + x) * p.lda + lg * 8 : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = wm * WTM + i * 16;         // first token of the fragment inside the tile: 16 | W, so a fragment stays in one map row
+            h_p0[i] = (r / HW_) * H_RS + (r % HW_) + l15;
+        }
+    }
+    // pieces [q0, q1) of this wave's H_PQ (piece id bwave + 8 q), channel chunk `chunk`, into halo buffer chunk & 1; returns how many were
+    // issued (wave-uniform).  Called with compile-time q0 / q1 only (fully unrolled), so h_poff stays in registers
+    auto halo_issue = [&](int chunk, int q0, int q1) {
+        int n = 0;
+        if constexpr (HALO) {
+            char* dst = smem + H_OFF + (chunk & 1) * H_BYTES + bwave * 1024;
+            const bf16_t* base = h_img + chunk * 64;
+#pragma unroll
+            for (int q = 0; q < H_PQ; ++q) {
+                if (q >= q0 && q < q1 && bwave + 8 * q < H_PIECES) {
+                    const bf16_t* src = h_poff[q] >= 0 ? base + h_poff[q] : (const bf16_t*)g16_zero_page;
+                    glds16(src, dst + q * 8192);
+                    ++n;
+                }
+            }
+        }
+        return n;
+    };
     // one global->LDS instruction: q < A_Q -> A chunk wave + NW q, else W chunk wave + NW (q - A_Q).  A wave whose last W chunk
     // would fall beyond the tile skips it when the ring is drained with vmcnt(0) (S == 2); with counted waits (S == 3) it re-loads
     // its first W chunk instead (same bytes to the same place), so that every wave has the same number of loads in flight
@@ -218,13 +298,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             }
         } else {
             const int qb = q - A_Q;
+            const bf16_t* bs = HALO ? b_src + (h_stap * p.Cin + h_schunk * 64) : b_src;
             if ((B_CH % NW == 0) || qb < B_Q - 1 || wave < (B_CH % NW))
-                glds16(b_src + qb * b_qstride, sA + A_BYTES + (wave + NW * qb) * 1024);
+                glds16(bs + qb * b_qstride, sA + A_BYTES + (wave + NW * qb) * 1024);
             else if (S > 2)
-                glds16(b_src, sA + A_BYTES + wave * 1024);
+                glds16(bs, sA + A_BYTES + wave * 1024);
         }
     };
     auto stage_advance = [&]() {
+        if constexpr (HALO) {
+            h_stap += KS;
+            if (h_stap >= 9) { h_stap -= 9; ++h_schunk; }
+            return;
+        }
         a_src += 64 * KS;
         b_src += 64 * KS;
         if constexpr (CONV) {
@@ -376,6 +462,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         ph8_adv_a();
         ph8_wt1 = 2;
     } else {
+        if constexpr (HALO) {   // the halo tiles of chunks 0 and 1 first: the first counted wait leaves only the youngest W stage in flight
+            halo_issue(0, 0, H_PQ);
+            if (h_nchunks > 1) halo_issue(1, 0, H_PQ);
+        }
 #pragma unroll
         for (int s = 0; s < S - 1; ++s) {
 #pragma unroll
@@ -469,10 +559,20 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         constexpr bool STAGE = decltype(stage_c)::value;
         constexpr int INFLIGHT = decltype(inflight_c)::value;
         constexpr bool TR = decltype(trans_c)::value;
-        g16_wait_vmcnt<INFLIGHT * LOADS>();
+        if constexpr (HALO && INFLIGHT == 1) {   // the previous iteration's loads stay in flight: its W chunks + the halo pieces it issued
+            if (h_cnt_prev == 0) g16_wait_vmcnt<LOADS>();
+            else if (h_cnt_prev == 1) g16_wait_vmcnt<LOADS + 1>();
+            else g16_wait_vmcnt<LOADS + 2>();
+        } else {
+            static_assert(!HALO || INFLIGHT == 0, "halo form: rings of depth 2 or 3");
+            g16_wait_vmcnt<INFLIGHT * LOADS>();
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* sT = ring + buf * STAGE_BYTES;
+        // halo form: this step's tap shift inside the halo tile of its chunk
+        const int h_ky = (h_rtap * 11) >> 5, h_toff = h_ky * H_RS + (h_rtap - 3 * h_ky);
+        const char* h_buf = smem + H_OFF + (h_rchunk & 1) * H_BYTES;
         // both 32-wide K slices of fragments are read ahead of the MFMAs -- except where the accumulators already take half the
         // register file (256 x 256: MI * NI = 32 fragments = 128 registers; 96 more for two slices spilled): one slice at a time
         // there, the second one read behind the first slice's MFMAs (the SIMD's other wave covers the wait)
@@ -481,8 +581,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
         bf16x8 af[FS][MI], bfr[FS][NI];
         auto read_frags = [&](int kk, int slot) {
             const int coff = ((4 * kk + quad) ^ sw) * 16;
+            if constexpr (HALO) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[slot][i] = *(const bf16x8*)(sT + a_row_off + i * 16 * 128 + coff);
+                for (int i = 0; i < MI; ++i) {
+                    const int P = h_p0[i] + h_toff;
+                    af[slot][i] = *(const bf16x8*)(h_buf + P * 128 + ((((4 * kk + quad) ^ P) & 7) << 4));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[slot][i] = *(const bf16x8*)(sT + a_row_off + i * 16 * 128 + coff);
+            }
 #pragma unroll
             for (int j = 0; j < NI; ++j) bfr[slot][j] = *(const bf16x8*)(sT + b_row_off + j * 16 * 128 + coff);
         };
@@ -508,6 +616,25 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             if (ONE_SLICE && kk == 0) read_frags(1, 0);
         }
         if constexpr (STAGE) stage_advance();
+        if constexpr (HALO) {
+            int cnt = 0;
+            if constexpr (STAGE) {
+                if (h_next < h_nchunks && h_it >= h_it0) {     // wave-uniform
+                    const int j = h_it - h_it0;
+#pragma unroll
+                    for (int J = 0; J < H_NLI; ++J)
+                        if (j == J) cnt = halo_issue(h_next, J * H_HQ, (J + 1) * H_HQ);
+                    if (j == H_NLI - 1) {
+                        ++h_next;
+                        h_it0 = (9 * (h_next - 2) + 8) / KS + 1;
+                    }
+                }
+            }
+            h_cnt_prev = cnt;
+            ++h_it;
+            h_rtap += KS;
+            if (h_rtap >= 9) { h_rtap -= 9; ++h_rchunk; }
+        }
         buf = buf + 1 == S ? 0 : buf + 1;
         sbuf = sbuf + 1 == S ? 0 : sbuf + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -712,7 +839,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             unsigned line = i * 64 + lane;
             line = line < pf_lines ? line : pf_lines - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.pf_ptr + (size_t)line * 128),
-                                             (__attribute__((address_space(3))) void*)(smem + (PH8 ? RING - 256 : KS * RING)), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + (PH8 ? RING - 256 : KS * RING + (HALO ? 2 * H_BYTES : 0))), 4, 0, 0);
         }
     };
     using K0_ = std::integral_constant<int, 0>;
@@ -976,7 +1103,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1>
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1, int HW_ = 0>
 static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     GemmArgsN<NP> pp;
     for (int q = 0; q < NP; ++q) {
@@ -987,7 +1114,7 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     const int tiles = (a.M / BM) * (a.N / BN);
     if (NP > 1 && tiles % (8 / NP)) return SUPIR_ERR_SHAPE;
     const double a_bytes = CONV ? 2.0 * (double)a.M * (a.up ? 0.25 : (double)(a.stride * a.stride)) * a.Cin : 2.0 * (double)a.M * a.K;
-    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, a_bytes, 2.0 * (double)a.N * a.K, CONV ? 9 : 1, 1, 8 / NP);
+    supir_choose_xcd_grid(a, a.M / BM, a.N / BN, a_bytes, 2.0 * (double)a.N * a.K, CONV ? (HW_ > 0 ? 2 : 9) : 1, 1, 8 / NP);
     for (int q = 1; q < NP; ++q) {   // identical shapes: identical tile maps
         pp.p[q].gm = a.gm;
         pp.p[q].gn = a.gn;
@@ -995,9 +1122,11 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     }
     // the ring(s) + the prefetch scratch row (the eight-phase tiles dump the prefetch into the last 256 bytes of their ring, which the
     // epilogue scratch never reaches: the 512 x 128 tile uses all 160 KB)
-    constexpr int smem = KS * (S == 8 ? 2 : S) * (BM + BN) * 128 + (S == 8 ? 0 : 256);
+    // halo form: the rings hold W tiles only, two halo tiles of ((BM / W + 2) (W + 2) pixels, rounded up to 8) x 128 B behind them
+    constexpr int halo_bytes = HW_ > 0 ? 2 * ((((BM / (HW_ > 0 ? HW_ : 1) + 2) * (HW_ + 2) + 7) / 8) * 1024) : 0;
+    constexpr int smem = HW_ > 0 ? KS * S * BN * 128 + halo_bytes + 256 : KS * (S == 8 ? 2 : S) * (BM + BN) * 128 + (S == 8 ? 0 : 256);
     static_assert(smem <= 163840, "LDS");
-    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED, NP>;
+    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED, NP, HW_>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
@@ -1009,11 +1138,18 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42 && tile != 45) return false;
-    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42 || tile == 45;
+    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42 && tile != 45 && (tile < 48 || tile > 51)) return false;
+    const bool halo = tile >= 48;       // LDS-staged halo convolutions: 48 = 128 x 80 @ W 32, 49 = 128 x 160 @ W 64, 50 = 256 x 160 @ W 32, 51 = 256 x 160 @ W 64
+    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42 || tile == 45 || tile == 50 || tile == 51;
     const int bm = tile == 45 ? 512 : wide ? 256 : 128;
-    const int bn = (tile == 39 || tile == 45) ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38) ? 80 : 160;
-    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40) ? 2 : 3;   // tiles 42 / 45: at least two K-tiles
+    const int bn = (tile == 39 || tile == 45) ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38 || tile == 48) ? 80 : 160;
+    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40 || tile == 49 || tile == 51) ? 2 : 3;   // tiles 42 / 45: at least two K-tiles
+    if (halo) {
+        const int hw = (tile == 49 || tile == 51) ? 64 : 32;
+        // whole map rows per tile, stride 1, pad 1, no upsampling; 32-bit element offsets inside one image
+        if (!conv || a.W != hw || a.OW != hw || a.OH != a.H || a.stride != 1 || a.up || a.pad_t != 1 || a.pad_l != 1) return false;
+        if (a.rows_per_batch != a.OH * a.OW || a.rows_per_batch % bm || (long)a.H * a.W * a.lda >= (1L << 31)) return false;
+    }
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
     // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU); their GroupNorm
@@ -1049,6 +1185,10 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
             case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false, true>(&a, st);
             case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false, true>(&a, st);
             case 45: return launch_gemm16<512, 128, 4, 2, 1, 8, false, true>(&a, st);
+            case 48: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 1, 32>(&a, st);
+            case 49: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true, false, 1, 64>(&a, st);
+            case 50: return launch_gemm16<256, 160, 4, 2, 1, 3, false, true, false, 1, 32>(&a, st);
+            case 51: return launch_gemm16<256, 160, 4, 2, 1, 2, false, true, false, 1, 64>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
@@ -1081,7 +1221,7 @@ static bool g16_same_shape(const GemmArgs& x, const GemmArgs& y) {
 
 int supir_gemm16_launch_n(const GemmArgs* a, int n, hipStream_t st, int tile, bool conv) {
     if (n == 1) return supir_gemm16_launch(a[0], st, tile, conv);
-    if (n != 2 || tile == 32 || tile >= 38) return SUPIR_ERR_SHAPE;
+    if (n != 2 || tile == 32 || tile >= 38) return SUPIR_ERR_SHAPE;      // (the halo tiles 48-51 have no grouped form)
     if (!supir_gemm16_supported(a[0], tile, conv) || !supir_gemm16_supported(a[1], tile, conv) || !g16_same_shape(a[0], a[1])) return SUPIR_ERR_SHAPE;
     // the wave arrangement of the 256 x 160 tile follows the single-launch policy (4 x 2 for convolutions and M >= 8192): a grouped launch
     // must stay bitwise the two single launches, GroupNorm partials and row statistics included (their cross-wave sums are ordered by it)

@@ -79,7 +79,8 @@ def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1, group=1):
         return f"gemm_bf16_kernel<{name},conv,split9>+finalize"
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv",
-              38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2", 41: "256,128,1k,s3,qkv", 42: "256,256,1k,8ph", 45: "512,128,1k,8ph"}[tile]
+              38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2", 41: "256,128,1k,s3,qkv", 42: "256,256,1k,8ph", 45: "512,128,1k,8ph",
+              48: "128,80,2k,s3,halo32", 49: "128,160,2k,s2,halo64", 50: "256,160,1k,s3,halo32", 51: "256,160,1k,s2,halo64"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}{g}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
@@ -736,14 +737,20 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
 
 _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
-               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2), 38: (80, 1), 39: (128, 2), 40: (256, 2), 42: (256, 4), 45: (128, 2)}
-G16_TILES = {32, 33, 34, 35, 39, 40, 42, 45}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
+               32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2), 38: (80, 1), 39: (128, 2), 40: (256, 2), 42: (256, 4), 45: (128, 2),
+               48: (80, 1), 49: (160, 2), 50: (160, 2), 51: (160, 2)}
+G16_TILES = {32, 33, 34, 35, 39, 40, 42, 45, 48, 49, 50, 51}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
 # tile: (BM, BN, K groups, ring).  38 = 128 x 80 with FOUR waves and a 78 KB ring (two workgroups per CU): known to the mirror, enabled
 # by adding it to G16_TILES (tools/archive/step_ab4.py); not in the default lists -- see docs/roundlog.md section 3 for what it measured
 # 39 / 40 = 256 x 128 and 256 x 256 (round 4): the VAE's 128 / 256 / 512-channel layers; ordinary epilogue only, and offered only where no
 # 80-column tile fits (N % 80 != 0), so the candidate lists -- and with them the picks -- of the UNet's shapes are what they were
 _G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3), 38: (128, 80, 1, 3),
-        39: (256, 128, 1, 3), 40: (256, 256, 1, 2), 42: (256, 256, 1, 3), 45: (512, 128, 1, 3)}
+        39: (256, 128, 1, 3), 40: (256, 256, 1, 2), 42: (256, 256, 1, 3), 45: (512, 128, 1, 3),
+        48: (128, 80, 2, 3), 49: (128, 160, 2, 2), 50: (256, 160, 1, 3), 51: (256, 160, 1, 2)}
+# 48-51 (round 6): the LDS-staged HALO form of the stride-1 3 x 3 convolutions (csrc/gemm16.hip): a tile is whole rows of a map of the
+# width below; per 64-channel chunk its (rows + 2) x (W + 2) input pixels are staged once and the nine taps read them at shifted LDS
+# addresses, K order (chunk, tap).  Convolutions only
+_G16_HALO_W = {48: 32, 49: 64, 50: 32, 51: 64}
 # 42 / 45 = 256 x 256 / 512 x 128 on the eight-phase ping-pong schedule (round 5; ring column = 3: they need at least two K-tiles);
 # ordinary epilogue only; convolutions: whole tiles inside one batch element (OH * OW % BM == 0).
 # (The same schedule as 256 x 160 and as a 256 x 320 GEGLU tile measured slower than / equal to tiles 34 / 37: not built.)
@@ -765,7 +772,7 @@ def _gemm_candidates(M, N, K, act, om, ldc, ln_slots=0, epilogue_ok=True, geglu1
         return base
     extra = []
     for t, (bm, bn, ks, s) in _G16.items():
-        if t not in G16_TILES:
+        if t not in G16_TILES or t in _G16_HALO_W:
             continue
         if M % bm or N % bn or K % (64 * ks) or (K // 64) // ks < s - 1:
             continue
@@ -1107,6 +1114,9 @@ def conv3x3(x, w, bias=None, *, stride=1, pad=(1, 1), upsample=False, out_hw=Non
             for t, (bm, bn, ks, s_) in _G16.items():   # same predicate as supir_gemm16_supported(conv)
                 if t in G16_TILES and M_ % bm == 0 and Cout % bn == 0 and Cin % (64 * ks) == 0 and (9 * Cin // 64) // ks >= s_ - 1 \
                         and not (t in _G16_PLAIN_ONLY and Cout % 80 == 0) and not (t == 42 and (OH * OW) % bm) and t != 45:   # 45: plain GEMMs only (it ties or loses on every convolution measured: profiles/r05/big_tiles_tile45.json)
+                    if t in _G16_HALO_W and not (W == _G16_HALO_W[t] and stride == 1 and not upsample and tuple(pad) == (1, 1) and (OH, OW) == (H, W)
+                                                 and (OH * OW) % bm == 0 and H * W * ldx < (1 << 31)):
+                        continue      # halo form: whole rows of a map of its width, stride 1, pad 1 (same predicate as supir_gemm16_supported)
                     cands.append(t)
         # tap-split candidates for convolutions whose tile grid is a fraction of the machine: one workgroup set per filter tap
         if USE_CONV_SPLIT and om == 0 and act in (0, 1) and residual is None and rowbias is None and alpha == 1.0 and Cin % 64 == 0 \
