@@ -35,6 +35,38 @@ if len(sys.argv) > 1 and sys.argv[1] == "large":   # round 5: the large-M regime
 if len(sys.argv) > 1 and sys.argv[1] == "geglu":   # the GEGLU projection on the 256 x 160 and the 256 x 320 tile, several K and M
     CASES = [(2048, 10240, 1280, 34), (2048, 10240, 1280, 37), (2048, 10240, 640, 37), (2048, 10240, 2560, 37), (4096, 10240, 1280, 37),
              (8192, 5120, 640, 37)]
+if len(sys.argv) > 1 and sys.argv[1] == "round6":
+    # round 6: where a K step of the 128 x 80 loops goes -- counted wait / barrier / reads + MFMAs -- for the one-barrier loop (35), the
+    # ping-pong K groups (54), and the same on convolutions: implicit GEMM (35, 54), halo form (48), halo + ping-pong (55)
+    lib.supir_conv3x3_bf16.argtypes = [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, I, I, I, F, I, P]
+    for (B, H, W, Cin, Cout, tile) in [(2, 32, 32, 1280, 1280, 35), (2, 32, 32, 1280, 1280, 54), (2, 32, 32, 1280, 1280, 57), (2, 32, 32, 1280, 1280, 48),
+                                        (2, 32, 32, 1280, 1280, 55), (2, 32, 32, 1280, 1280, 58), (2, 64, 64, 640, 640, 33), (2, 64, 64, 640, 640, 49)]:
+        x = torch.randn(B, H, W, Cin, device="cuda").to(BF)
+        w = (torch.randn(Cout, 3, 3, Cin, device="cuda") * (9 * Cin) ** -0.5).to(BF)
+        bias = torch.randn(Cout, device="cuda")
+        out = torch.empty(B, H, W, Cout, device="cuda", dtype=BF)
+        bm, bn = {33: (128, 160), 49: (128, 160)}.get(tile, (128, 80))
+        nwg = (B * H * W // bm) * (Cout // bn)
+        buf = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+
+        def runc():
+            return lib.supir_conv3x3_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cin, Cin, Cout, Cout, H, W, 1, 1, 1, 0, bias.data_ptr(),
+                                          None, 0, None, 0, 0, 0, 1.0, tile, st)
+        for _ in range(3):
+            assert runc() == 0
+        torch.cuda.synchronize()
+        lib.supir_g16_tl_set(buf.data_ptr())
+        assert runc() == 0
+        torch.cuda.synchronize()
+        lib.supir_g16_tl_set(None)
+        t = buf.view(nwg * 8, 16).cpu().double()
+        nk = (9 * Cin // 64) // 2
+        print(f"conv B={B} {H}x{W} {Cin}->{Cout} tile={tile} wgs={nwg} | per wave (cycles): prologue {t[:, 1].mean():.0f}  loop {t[:, 2].mean():.0f} "
+              f"({t[:, 2].mean() / nk:.0f} per iteration x {nk}: wait {t[:, 8].mean() / nk:.0f}, barrier {t[:, 9].mean() / nk:.0f}, reads+loads+MFMA "
+              f"{t[:, 10].mean() / nk:.0f}; ideal MFMA {bm * bn * 64 * 2 * 2 / 4096:.0f})  exchange {t[:, 3].mean():.0f}  epilogue {t[:, 4].mean():.0f}  "
+              f"total {t[:, 5].mean():.0f} (max {t[:, 5].max():.0f}); first start -> last end {t[:, 6].max() - t[:, 0].min():.0f}", flush=True)
+    CASES = [(2048, 1280, 1280, 35), (2048, 1280, 1280, 54), (2048, 1280, 1280, 57), (2048, 1280, 5120, 35), (2048, 1280, 5120, 54), (2048, 1280, 5120, 57)]
 for (M, N, K, tile) in CASES:
     a = torch.randn(M, K, device="cuda").to(BF)
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
@@ -42,9 +74,11 @@ for (M, N, K, tile) in CASES:
     bias = torch.randn(N, device="cuda")
     out = torch.empty(M, N, device="cuda", dtype=BF)
     geglu = len(sys.argv) > 1 and sys.argv[1] == "geglu"
-    bm, bn = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320), 39: (256, 128), 40: (256, 256), 42: (256, 256), 45: (512, 128)}[tile]
+    bm, bn = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320), 39: (256, 128), 40: (256, 256), 42: (256, 256), 45: (512, 128),
+              54: (128, 80), 57: (128, 80)}[tile]
     nwg = (M // bm) * (N // bn)
-    buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device="cuda")
+    SL = 8 if tile == 37 else 16      # slots per wave (gemm16: + the in-loop split of round 6)
+    buf = torch.zeros(nwg * 8 * SL, dtype=torch.int64, device="cuda")
     (lib.supir_big_tl_set if tile == 37 else lib.supir_g16_tl_set)(buf.data_ptr())
     st = torch.cuda.current_stream().cuda_stream
 
@@ -64,8 +98,10 @@ for (M, N, K, tile) in CASES:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    t = buf.view(nwg * 8, 8).cpu().double()
+    t = buf.view(nwg * 8, SL).cpu().double()
     nk = (K // 64) // (1 if tile in (34, 37, 39, 40, 42, 45) else 2)
+    if SL == 16:
+        print(f"    in-loop split per K step: counted wait {t[:, 8].mean() / nk:.0f}, barrier {t[:, 9].mean() / nk:.0f}, reads + loads + MFMA {t[:, 10].mean() / nk:.0f}", flush=True)
     print(f"M={M} N={N} K={K} tile={tile} wgs={nwg} | event {us:.1f} us | per wave (cycles): prologue "
           f"{t[:, 1].mean():.0f}  loop {t[:, 2].mean():.0f} ({t[:, 2].mean() / nk:.0f} per K step x {nk})  exchange {t[:, 3].mean():.0f}  "
           f"epilogue {t[:, 4].mean():.0f}  total {t[:, 5].mean():.0f} (max {t[:, 5].max():.0f})", flush=True)
