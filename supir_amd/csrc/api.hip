@@ -59,7 +59,7 @@ int supir_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int 
                        const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual, int ldr, int act,
                        int out_mode, float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > SUPIR_ACT_GEGLU_ERF || out_mode < 0 || out_mode > 2 || (tile > 45 && tile != 54 && tile != 57) || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
+    if (act < 0 || act > SUPIR_ACT_GEGLU_ERF || out_mode < 0 || out_mode > 2 || tile > 45 || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
     if ((rowbias || out_mode == 2) && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.Wt = (const bf16_t*)W; a.C = C;
@@ -85,7 +85,7 @@ int supir_gemm_bf16_ln_ex(const void* A, const void* W, void* C, int M, int N, i
                           float* rowstats_out, int rs_ld, const float* ln_stats, int ln_ld, int ln_slots,
                           const float* ln_colsum, float ln_eps, const supir_launch_hints* hints, void* stream) {
     if (!A || !W || !C) return SUPIR_ERR_ARG;
-    if (act < 0 || act > SUPIR_ACT_GEGLU_ERF || out_mode < 0 || out_mode > 2 || (tile > 45 && tile != 54 && tile != 57) || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
+    if (act < 0 || act > SUPIR_ACT_GEGLU_ERF || out_mode < 0 || out_mode > 2 || tile > 45 || tile == 36 || tile == 41 || tile == 43 || tile == 44) return SUPIR_ERR_ARG;
     if (out_mode == 2 && rows_per_batch <= 0) return SUPIR_ERR_ARG;
     if (ln_stats && (!ln_colsum || ln_slots < 0 || (ln_slots > 0 && (ln_ld < ln_slots || (ln_ld & 1))))) return SUPIR_ERR_ARG;
     if (rowstats_out && (out_mode != 0 || act == SUPIR_ACT_GEGLU || act == SUPIR_ACT_GEGLU_ERF || rs_ld <= 0)) return SUPIR_ERR_ARG;
@@ -151,7 +151,7 @@ int supir_conv3x3_bf16_ex(const void* X, const void* W, void* Y, int B, int H, i
                           float alpha, int tile, const supir_launch_hints* hints, void* stream) {
     if (!X || !W || !Y) return SUPIR_ERR_ARG;
     if (B <= 0 || H <= 0 || Wd <= 0 || OH <= 0 || OW <= 0) return SUPIR_ERR_ARG;
-    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || (tile > 35 && (tile < 38 || tile > 40) && tile != 42 && tile != 45 && (tile < 48 || tile > 59))) return SUPIR_ERR_ARG;
+    if (act < 0 || act > 1 || out_mode < 0 || out_mode > 1 || (tile > 35 && (tile < 38 || tile > 40) && tile != 42 && tile != 45 && (tile < 48 || tile > 51))) return SUPIR_ERR_ARG;
     if (stride != 1 && stride != 2) return SUPIR_ERR_SHAPE;
     if (upsample && stride != 1) return SUPIR_ERR_SHAPE;
     if (ldy % 4 != 0 || (residual && ldr % 4 != 0) || (rowbias && ld_rowbias % 4 != 0)) return SUPIR_ERR_SHAPE;

@@ -900,7 +900,7 @@ int supir_gemm_launch(const GemmArgs& a_in, bool conv, hipStream_t st, int force
             a.rowstats_out || a.ln_stats || a.gn_part_out || a.K % (64 * a.ksplit) != 0)
             return SUPIR_ERR_SHAPE;
     }
-    if (a.gn_part_out && ((force_tile < 32 || force_tile > 35) && (force_tile < 38 || force_tile > 40) && force_tile != 42 && force_tile != 45 && (force_tile < 48 || force_tile > 59))) return SUPIR_ERR_SHAPE;   // GroupNorm partials: gemm16 epilogues only
+    if (a.gn_part_out && ((force_tile < 32 || force_tile > 35) && (force_tile < 38 || force_tile > 40) && force_tile != 42 && force_tile != 45 && (force_tile < 48 || force_tile > 51))) return SUPIR_ERR_SHAPE;   // GroupNorm partials: gemm16 epilogues only
     if (force_tile == 37) return conv ? SUPIR_ERR_SHAPE : supir_gemm_big_launch(a, st);   // 256 x 320 GEGLU tile (gemm_big.hip)
     if (force_tile >= 32) {   // the 16x16x32-MFMA, 256-workgroup tiles (gemm16.hip): exact shapes only
         return supir_gemm16_launch(a, st, force_tile, conv);

@@ -53,27 +53,6 @@ __device__ __forceinline__ void g16_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// counted wait with a wave-uniform run-time count n = the loads that may stay in flight (the immediate must be a constant: a short scalar
-// branch chain picks it).  L = loads of one W / A stage per wave, D = iterations allowed in flight.  In steady state n = D L + (0 .. 4 halo
-// pieces): exact; at the ends of the loop n is smaller: the largest multiple of L below it (waiting for MORE than necessary is always safe)
-template <int L, int D>
-__device__ __forceinline__ void g16_wait_vmcnt_rt(int n) {
-    if (n >= D * L) {
-        const int e = n - D * L;
-        if (e == 0) g16_wait_vmcnt<D * L>();
-        else if (e == 1) g16_wait_vmcnt<D * L + 1>();
-        else if (e == 2) g16_wait_vmcnt<D * L + 2>();
-        else if (e == 3) g16_wait_vmcnt<D * L + 3>();
-        else g16_wait_vmcnt<D * L + 4>();
-    } else if (D >= 3 && n >= 2 * L) {
-        g16_wait_vmcnt<2 * L>();
-    } else if (D >= 2 && n >= L) {
-        g16_wait_vmcnt<L>();
-    } else {
-        g16_wait_vmcnt<0>();
-    }
-}
-
 #ifdef SUPIR_G16_TIMELINE
 // tools/probes/g16_timeline.py only (never defined in the product build): per-wave s_memtime stamps of the kernel's phases
 __device__ unsigned long long* g16_tl_buf;
@@ -126,34 +105,14 @@ __device__ __attribute__((aligned(256))) uint32_t g16_zero_page[64];
 //     uniformly, by the count of the previous iteration.
 // Everything after the main loop (K-group exchange, epilogue, GroupNorm partials, prefetch) is the code of the other forms: a tile is still
 // BM consecutive rows of the [M][N] output.
-//
-// PING-PONG between the two K groups (PP; round 6, KS = 2, S >= 3).  With one barrier per K step all eight waves read their fragments at the
-// same time and then issue their MFMAs at the same time: the LDS pipe (14 ds_read_b128 per wave and step) and the matrix pipe (20 MFMAs)
-// take turns -- an iteration of the 128 x 80 loop measured 1.4-1.8 k cycles against 0.64 k of MFMA, and halving the global -> LDS fill
-// (the halo form) did not move it: the loop was phase-serialised, not fill-bound.  Here an iteration is TWO barrier-delimited intervals,
-//     [fragment reads of step i, loads of step i + S - 1, the counted wait, lgkmcnt(0)]  s_barrier  [the step's MFMAs, setprio 1]  s_barrier
-// and group 1 runs one interval behind group 0.  Every SIMD holds one wave of each group, so in every interval one of its waves feeds the
-// matrix pipe while the other reads LDS and issues loads.  Hazards (group g reads step i in interval 2 i + g; each group has its own ring):
-//   RAW  a wave waits for its loads of step i + 1 at the END of the read segment of step i (everything but the youngest S - 2 iterations'
-//        loads has landed); the barrier that ends that interval publishes them to its group two intervals before they are read;
-//   WAR  the buffer of step i is refilled by the loads of step i + S, issued in the read segment of step i + 1 -- two barriers after the
-//        reads of step i completed (lgkmcnt(0) precedes the barrier);
-//   halo tiles are shared by both groups: pieces issued in iteration j are covered by the wait of iteration j + S - 2 and published by the
-//        barrier after it -- interval 2 (j + S - 1) at the latest, for both groups; the refill of chunk c's buffer starts in the iteration
-//        after the last step of chunk c (either group), i.e. at least one barrier after its last read.
-// Group 0 takes one extra barrier after the loop, group 1 one before it: equal barrier counts.
-//
-// SOFTWARE-PIPELINED fragments (SWP = PP == 2; round 6).  The in-loop stamps (tools/probes/g16_timeline.py round6,
-// profiles/r06/g16_timeline_round6.log) say where a 128 x 80 iteration goes: counted wait 8 cycles (the loads are never late), barrier
-// ~250, fragment reads + MFMAs ~1070 against 640 of MFMA -- the eight waves' 112 ds_read_b128 are 448 LDS cycles, and with one barrier per
-// step every wave reads first and multiplies afterwards: LDS pipe and matrix pipe take turns.  The ping-pong form above overlaps them
-// ACROSS the K groups and pays the saving back in its second barrier.  This form overlaps them INSIDE each wave: iteration i issues the
-// fragment reads of step i + 1 into a second register set (+56 VGPRs), then the MFMAs of step i from the set filled an iteration ago; one
-// barrier per iteration as before.  The ring holds steps i + 1 .. i + S (the buffer of step i was read an iteration ago and is refilled
-// now), so the prefetch distance in time is that of the one-barrier loop.  Same MFMA order per accumulator: bitwise the one-barrier result.
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1, int HW_ = 0, int PP_ = 0>
+// Measured (profiles/r06): fetch + write per launch falls to 1.1-1.4 x the operands; texture-addresser busy 60 % -> 37 %; TIME is equal to
+// the implicit-GEMM tiles within the box noise (0.94-1.09 x) -- the in-loop stamps show the loop is not bound by the fill (counted wait: 8
+// cycles per step), nor by LDS (index pipe 28 % busy, no bank conflicts in either form), nor by the matrix pipe (39 %): a step is wait 8 /
+// barrier 250 / reads + loads + MFMAs 1070 cycles against 640 of MFMA.  Three re-orderings of that step were built and measured on top of this
+// form and of the implicit one -- the two K groups ping-ponging across two barriers, fragments software-pipelined inside each wave, the
+// groups' load / MFMA order staggered -- all bitwise equal, all 5-15 % SLOWER (docs/roundlog.md section 6); they are not in the tree.
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1, int HW_ = 0>
 __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) void gemm16_kernel(const GemmArgsN<NP> pp) {
-    constexpr bool PP = PP_ == 1, SWP = PP_ == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NX = 8 / NP;                                               // XCDs per problem
     const int prob = NP == 1 ? 0 : (int)(blockIdx.x & 7) / NX;               // wave-uniform: a scalar offset into the kernarg segment
@@ -165,21 +124,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     constexpr int SD = PH8 ? 2 : S;
     constexpr bool HALO = HW_ > 0;
     static_assert(!HALO || (CONV && S != 8 && !MIXED && !TRANS && NP == 1 && BM % HW_ == 0 && HW_ % 16 == 0 && WM * WN * KS == 8), "halo form");
-    static_assert(!PP || (KS == 2 && S >= 3 && S <= 5 && !MIXED && !TRANS && NP == 1), "ping-pong form: two K groups, counted waits");
-    static_assert(!SWP || (S >= 3 && S <= 5 && !MIXED && !TRANS && NP == 1 && (BM / WM / 16) * (BN / WN / 16) < 32), "software-pipelined fragments: counted waits, two fragment sets in registers");
     constexpr int H_ROWS = HALO ? BM / HW_ : 1;          // output rows of the map per tile
     constexpr int H_RS = HW_ + 2;                        // halo row stride in pixels
     constexpr int H_PIX = (H_ROWS + 2) * H_RS;
     constexpr int H_PIECES = (H_PIX + 7) / 8;            // 8-pixel (1 KB) pieces of one halo tile
     constexpr int H_BYTES = H_PIECES * 1024;
     constexpr int H_PQ = (H_PIECES + 7) / 8;             // pieces per wave (piece id = wave + 8 q, all eight waves of the workgroup)
-    // load iterations available between "chunk c's buffer is free" and "chunk c + 2's pieces must be covered by the counted wait": the
-    // iterations F(c) .. first(c + 2) - (S - 1); first(c + 2) - F(c) = 4 with two K groups, 9 with one
-    constexpr int H_NLI_MAX = KS == 2 ? (6 - S < 1 ? 1 : 6 - S) : 10 - S;
+    constexpr int H_NLI_MAX = KS == 2 ? (S == 3 ? 3 : 4) : (S == 3 ? 7 : 8);   // iterations between "chunk c's buffer is free" and "chunk c + 2's data must be covered by the wait"
     constexpr int H_HQ = (H_PQ + H_NLI_MAX - 1) / H_NLI_MAX;                   // pieces per wave and load iteration
     constexpr int H_NLI = (H_PQ + H_HQ - 1) / H_HQ;                            // load iterations per halo tile
-    static_assert(!HALO || PP || H_HQ <= 2, "halo pieces per iteration: the counted wait of the one-barrier loop has three variants");
-    static_assert(!HALO || KS == 1 || S <= 5, "halo form with two K groups: at most a 5-deep ring (one load iteration per halo tile)");
+    static_assert(!HALO || H_HQ <= 2, "halo pieces per iteration: the counted wait has three variants");
     constexpr int A_BYTES = HALO ? 0 : BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, RING = SD * STAGE_BYTES;
     constexpr int H_OFF = KS * RING;                     // LDS: [ring of group 0 | ring of group 1 | halo 0 | halo 1]
     constexpr int A_Q = HALO ? 0 : BM / 8 / NW;          // 8-row chunks of A per wave and K step (chunk id = wave + NW q)
@@ -189,7 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     constexpr int NWT = NW * KS, NTHREADS = 64 * NWT;   // waves / threads per workgroup (8 / 512; tile 38: 4 / 256)
     static_assert((NWT == 8 || (NWT == 4 && KS == 1 && !MIXED && NP == 1)) && (BM / 8) % NW == 0 && (NW & 1) == 0,
                   "512 threads (or the four-wave single-group form); A chunks divide over the waves");
-    static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3 || S == 8 || ((PP || SWP) && S <= 5)), "tile / wave grid");
+    static_assert(MI >= KS && MI % KS == 0 && WTN % 16 == 0 && (KS == 1 || KS == 2) && (S == 2 || S == 3 || S == 8), "tile / wave grid");
     // eight-phase schedule: 256 token rows, 8 waves; the wave tile's MI token fragments split into two halves, its NI channel fragments
     // into NA + NB parts.  Shipped: 256 x 256 as 2 x 4 waves (128 x 64 per wave, 2 + 2 fragments: tile 42).  The same code was measured
     // as 256 x 160 (4 x 2 waves, 3 + 2) and as 256 x 320 for the GEGLU projections (4 x 2, 5 + 5): bitwise the one-barrier tiles' results,
@@ -300,8 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     int h_stap = kg, h_schunk = 0, h_rtap = kg, h_rchunk = 0;
     int h_it = 0;                   // iteration (one step of each group) about to run
     int h_next = 2;                 // next chunk whose halo tile is loaded in the loop (0 and 1: prologue)
-    constexpr int H_IT_SHIFT = SWP ? 0 : 1;   // SWP reads step i + 1 in iteration i: chunk c's buffer is free from the iteration of its last step on
-    int h_it0 = 8 / KS + H_IT_SHIFT;   // first load iteration of chunk h_next: the iteration after the last step of chunk h_next - 2, (9 c + 8) / KS + 1
+    int h_it0 = 8 / KS + 1;         // first load iteration of chunk h_next: the iteration after the last step of chunk h_next - 2, (9 c + 8) / KS + 1
     int h_cnt_prev = 0;             // halo pieces this wave issued in the previous iteration (the counted wait depends on it)
     const int h_nchunks = HALO ? p.Cin >> 6 : 0;
     int h_poff[HALO ? H_PQ : 1];    // per lane: element offset of its 16 bytes of piece (bwave + 8 q) inside the image, < 0: zero page
@@ -526,8 +479,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
             if (h_nchunks > 1) halo_issue(1, 0, H_PQ);
         }
 #pragma unroll
-        for (int s = 0; s < (SWP ? S : S - 1); ++s) {
-            if (SWP && s >= nk) break;             // fewer K steps than ring stages (nk >= S - 1: dispatcher)
+        for (int s = 0; s < S - 1; ++s) {
 #pragma unroll
             for (int q = 0; q < LOADS; ++q) stage_one(s, q);
             stage_advance();
@@ -692,7 +644,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                         if (j == J) cnt = halo_issue(h_next, J * H_HQ, (J + 1) * H_HQ);
                     if (j == H_NLI - 1) {
                         ++h_next;
-                        h_it0 = (9 * (h_next - 2) + 8) / KS + H_IT_SHIFT;
+                        h_it0 = (9 * (h_next - 2) + 8) / KS + 1;
                     }
                 }
             }
@@ -711,214 +663,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    // ---- ping-pong form: see the comment above the kernel
-    int pp_iss1 = LOADS, pp_iss2 = LOADS;     // loads this wave issued in the previous / the one-before iteration (prologue: one W stage each)
-    auto kstep_pp = [&](auto stage_c) {
-        constexpr bool STAGE = decltype(stage_c)::value;
-        G16_TLS(tl_s0);
-        const char* sT = ring + buf * STAGE_BYTES;
-        const int h_ky = (h_rtap * 11) >> 5, h_toff = h_ky * H_RS + (h_rtap - 3 * h_ky);
-        const char* h_buf = smem + H_OFF + (h_rchunk & 1) * H_BYTES;
-        bf16x8 af[2][MI], bfr[2][NI];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int coff = ((4 * kk + quad) ^ sw) * 16;
-            if constexpr (HALO) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int P = h_p0[i] + h_toff;
-                    af[kk][i] = *(const bf16x8*)(h_buf + P * 128 + ((((4 * kk + quad) ^ P) & 7) << 4));
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[kk][i] = *(const bf16x8*)(sT + a_row_off + i * 16 * 128 + coff);
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[kk][j] = *(const bf16x8*)(sT + b_row_off + j * 16 * 128 + coff);
-        }
-        int iss = 0;
-        if constexpr (STAGE) {
-#pragma unroll
-            for (int q = 0; q < LOADS; ++q) stage_one(sbuf, q);
-            stage_advance();
-            iss = LOADS;
-        }
-        if constexpr (HALO) {
-            if constexpr (STAGE) {
-                if (h_next < h_nchunks && h_it >= h_it0) {     // wave-uniform
-                    const int j = h_it - h_it0;
-#pragma unroll
-                    for (int J = 0; J < H_NLI; ++J)
-                        if (j == J) iss += halo_issue(h_next, J * H_HQ, (J + 1) * H_HQ);
-                    if (j == H_NLI - 1) {
-                        ++h_next;
-                        h_it0 = (9 * (h_next - 2) + 8) / KS + H_IT_SHIFT;
-                    }
-                }
-            }
-            ++h_it;
-            h_rtap += KS;
-            if (h_rtap >= 9) { h_rtap -= 9; ++h_rchunk; }
-        }
-        // step i + 1 has landed once at most the loads of the youngest S - 2 iterations (this one included) are outstanding
-        g16_wait_vmcnt_rt<LOADS, (S - 2 > 0 ? S - 2 : 1)>(iss + (S >= 4 ? pp_iss1 : 0) + (S >= 5 ? pp_iss2 : 0));
-        pp_iss2 = pp_iss1;
-        pp_iss1 = iss;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        G16_TLS(tl_s1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        G16_TLS(tl_s2);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = SUPIR_MFMA_16x16x32(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        G16_TLS(tl_s3);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        G16_TLACC(tl_wait, tl_s0, tl_s1);      // ping-pong: read segment incl. the counted wait
-        G16_TLACC(tl_bar, tl_s1, tl_s2);       //            first barrier
-        G16_TLACC(tl_comp, tl_s2, tl_s3);      //            MFMA segment (the second barrier's wait lands in the next read segment's stamp gap)
-        buf = buf + 1 == S ? 0 : buf + 1;
-        sbuf = sbuf + 1 == S ? 0 : sbuf + 1;
-    };
-    // ---- software-pipelined form: see the comment above the kernel
-    bf16x8 sw_a[SWP ? 2 : 1][2][SWP ? MI : 1], sw_b[SWP ? 2 : 1][2][SWP ? NI : 1];
-    int sw_iss[3] = {nk < S ? 0 : LOADS, LOADS, LOADS};      // loads this wave issued 1 / 2 / 3 iterations ago (prologue: one W stage each; nk == S - 1: the last one is missing)
-    auto swp_read = [&](auto par_c) {          // fragments of the step at ring position `buf` (halo: tap / chunk h_r*) -> register set PAR
-        constexpr int PAR = decltype(par_c)::value;
-        const char* sT = ring + buf * STAGE_BYTES;
-        const int h_ky = (h_rtap * 11) >> 5, h_toff = h_ky * H_RS + (h_rtap - 3 * h_ky);
-        const char* h_buf = smem + H_OFF + (h_rchunk & 1) * H_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int coff = ((4 * kk + quad) ^ sw) * 16;
-            if constexpr (HALO) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int P = h_p0[i] + h_toff;
-                    sw_a[PAR][kk][i] = *(const bf16x8*)(h_buf + P * 128 + ((((4 * kk + quad) ^ P) & 7) << 4));
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) sw_a[PAR][kk][i] = *(const bf16x8*)(sT + a_row_off + i * 16 * 128 + coff);
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) sw_b[PAR][kk][j] = *(const bf16x8*)(sT + b_row_off + j * 16 * 128 + coff);
-        }
-        buf = buf + 1 == S ? 0 : buf + 1;
-        if constexpr (HALO) {
-            h_rtap += KS;
-            if (h_rtap >= 9) { h_rtap -= 9; ++h_rchunk; }
-        }
-    };
-    // iteration i (register set PAR holds step i): wait for step i + 1, barrier, read it into the other set, refill the buffer of step i
-    // with step i + S, multiply step i
-    auto swp_step = [&](auto par_c, int i) {
-        constexpr int PAR = decltype(par_c)::value;
-        const bool more = i + 1 < nk;           // wave-uniform
-        if (more) {
-            G16_TLS(tl_s0);
-            // step i + 1 was issued S - 1 iterations ago: at most the loads of the last S - 2 iterations may still be in flight
-            g16_wait_vmcnt_rt<LOADS, (S - 2 > 0 ? S - 2 : 1)>((S >= 3 ? sw_iss[0] : 0) + (S >= 4 ? sw_iss[1] : 0) + (S >= 5 ? sw_iss[2] : 0));
-            G16_TLS(tl_s1);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            G16_TLS(tl_s2);
-            swp_read(std::integral_constant<int, PAR ^ 1>{});
-        }
-        // the refill of step i's buffer (step i + S) is issued between the MFMAs, half of it per 32-wide K slice
-        const bool stage = i + S < nk;          // wave-uniform
-        int iss = 0;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (stage) {
-#pragma unroll
-                for (int q = (kk * LOADS) / 2; q < ((kk + 1) * LOADS) / 2; ++q) stage_one(sbuf, q);
-                if (kk == 1) {
-                    stage_advance();
-                    iss = LOADS;
-                    if constexpr (HALO) {
-                        if (h_next < h_nchunks && h_it >= h_it0) {
-                            const int j = h_it - h_it0;
-#pragma unroll
-                            for (int J = 0; J < H_NLI; ++J)
-                                if (j == J) iss += halo_issue(h_next, J * H_HQ, (J + 1) * H_HQ);
-                            if (j == H_NLI - 1) {
-                                ++h_next;
-                                h_it0 = (9 * (h_next - 2) + 8) / KS + H_IT_SHIFT;
-                            }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int ii = 0; ii < MI; ++ii)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[ii][j] = SUPIR_MFMA_16x16x32(sw_b[PAR][kk][j], sw_a[PAR][kk][ii], acc[ii][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        sbuf = sbuf + 1 == S ? 0 : sbuf + 1;
-        ++h_it;
-        sw_iss[2] = sw_iss[1];
-        sw_iss[1] = sw_iss[0];
-        sw_iss[0] = iss;
-        // a real S_WAITCNT (not inline asm): the compiler's wait-count pass sees that the fragment reads are complete at the back edge and does
-        // not put its own lgkmcnt(0) in front of the next iteration's MFMAs (it did: the overlap was lost in every other iteration)
-        __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
-        asm volatile("" ::: "memory");
-        if (more) {
-            G16_TLS(tl_s3);
-            G16_TLACC(tl_wait, tl_s0, tl_s1);
-            G16_TLACC(tl_bar, tl_s1, tl_s2);
-            G16_TLACC(tl_comp, tl_s2, tl_s3);
-        }
-    };
     G16_TL(tl_loop0);
     auto main_loop = [&](auto trans_c) {
-        if constexpr (SWP) {
-            // the ring is full (steps 0 .. S - 1); step 0 (and the halo tiles of chunks 0 / 1, issued before it) must have landed
-            if (nk < S) g16_wait_vmcnt<(S - 2) * LOADS>();      // S - 1 stages issued
-            else g16_wait_vmcnt<(S - 1) * LOADS>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            sbuf = 0;                           // the first refill (step S) goes into the buffer of step 0
-            swp_read(std::integral_constant<int, 0>{});
-            __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0), as a real S_WAITCNT (see swp_step)
-            asm volatile("" ::: "memory");
-            for (int i = 0; i < nk; i += 2) {
-                swp_step(std::integral_constant<int, 0>{}, i);
-                if (i + 1 < nk) swp_step(std::integral_constant<int, 1>{}, i + 1);
-            }
-        } else if constexpr (PP) {
-            g16_wait_vmcnt<(S - 2) * LOADS>();      // step 0 (and the halo tiles of chunks 0 / 1) landed; steps 1 .. S - 2 stay in flight
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kg == 1) {                          // group 1 runs one interval behind group 0 from here on
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            for (int kt = 0; kt + S - 1 < nk; ++kt) kstep_pp(T_{});
-#pragma unroll
-            for (int r = 0; r < S - 1; ++r) kstep_pp(F_{});
-            if (kg == 0) {
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-        } else {
-            for (int kt = 0; kt + S - 1 < nk; ++kt) kstep(T_{}, std::integral_constant<int, S - 2>{}, trans_c);
-            if constexpr (S == 3) kstep(F_{}, std::integral_constant<int, 1>{}, trans_c);
-            kstep(F_{}, std::integral_constant<int, 0>{}, trans_c);
-        }
+        for (int kt = 0; kt + S - 1 < nk; ++kt) kstep(T_{}, std::integral_constant<int, S - 2>{}, trans_c);
+        if constexpr (S == 3) kstep(F_{}, std::integral_constant<int, 1>{}, trans_c);
+        kstep(F_{}, std::integral_constant<int, 0>{}, trans_c);
     };
     if constexpr (PH8) {
         const int fa_off = (wm * PH_HR + l15) * 128;
@@ -1379,7 +1128,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1, int HW_ = 0, int PP = 0>
+template <int BM, int BN, int WM, int WN, int KS, int S, bool TRANS, bool CONV = false, bool MIXED = false, int NP = 1, int HW_ = 0>
 static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     GemmArgsN<NP> pp;
     for (int q = 0; q < NP; ++q) {
@@ -1402,7 +1151,7 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
     constexpr int halo_bytes = HW_ > 0 ? 2 * ((((BM / (HW_ > 0 ? HW_ : 1) + 2) * (HW_ + 2) + 7) / 8) * 1024) : 0;
     constexpr int smem = HW_ > 0 ? KS * S * BN * 128 + halo_bytes + 256 : KS * (S == 8 ? 2 : S) * (BM + BN) * 128 + (S == 8 ? 0 : 256);
     static_assert(smem <= 163840, "LDS");
-    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED, NP, HW_, PP>;
+    auto kern = gemm16_kernel<BM, BN, WM, WN, KS, S, TRANS, CONV, MIXED, NP, HW_>;
     static bool attr_set = false;
     if (!attr_set) {
         if (supir_note_hip_status(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)) != SUPIR_OK) return SUPIR_ERR_HIP;
@@ -1413,35 +1162,19 @@ static int launch_gemm16(const GemmArgs* a_in, hipStream_t st) {
 }
 
 // tiles 32 (128 x 80), 33 (128 x 160), 34 (256 x 160, GEGLU-capable), 35 (128 x 80, 3-deep rings): exact fits only
-// tile -> geometry.  hw > 0: the LDS-staged halo form (convolutions only, whole rows of a map of that width per tile); pp: the two K groups
-// ping-pong (two barriers per iteration, group 1 one interval behind)
-//   48  128 x  80  2 K groups  3-deep  halo W 32            52  128 x 80  2 K groups  4-deep  halo W 32, ping-pong
-//   49  128 x 160  2 K groups  2-deep  halo W 64            53  128 x 80  2 K groups  3-deep  halo W 64, ping-pong
-//   50  256 x 160  1 K group   3-deep  halo W 32            54  128 x 80  2 K groups  3-deep  ping-pong (plain GEMMs and implicit-GEMM convolutions)
-//   51  256 x 160  1 K group   2-deep  halo W 64            55  128 x 80  2 K groups  3-deep  halo W 32, ping-pong
-//                                                           56  128 x 80  2 K groups  5-deep  halo W 32, ping-pong
-//   57  128 x 80  2 K groups  3-deep  software-pipelined fragments (plain GEMMs and implicit-GEMM convolutions)
-//   58  128 x 80  2 K groups  3-deep  halo W 32, software-pipelined fragments        59  the same at W 64
-static bool g16_tile_info(int tile, int& bm, int& bn, int& ks, int& s, int& hw) {
-    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42 && tile != 45 && (tile < 48 || tile > 59)) return false;
-    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42 || tile == 45 || tile == 50 || tile == 51;
-    bm = tile == 45 ? 512 : wide ? 256 : 128;
-    bn = (tile == 39 || tile == 45) ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 33 || tile == 34 || tile == 49 || tile == 50 || tile == 51) ? 160 : 80;
-    ks = (wide || tile == 38) ? 1 : 2;
-    s = (tile == 32 || tile == 33 || tile == 40 || tile == 49 || tile == 51) ? 2 : tile == 52 ? 4 : tile == 56 ? 5 : 3;   // tiles 42 / 45: at least two K-tiles
-    hw = (tile == 49 || tile == 51 || tile == 53 || tile == 59) ? 64 : (tile == 48 || tile == 50 || tile == 52 || tile == 55 || tile == 56 || tile == 58) ? 32 : 0;
-    return true;
-}
-
 bool supir_gemm16_supported(const GemmArgs& a, int tile, bool conv) {
-    int bm, bn, ks, s, hw;
-    if (!g16_tile_info(tile, bm, bn, ks, s, hw)) return false;
-    if (hw > 0) {
+    if ((tile < 32 || tile > 35) && (tile < 38 || tile > 40) && tile != 42 && tile != 45 && (tile < 48 || tile > 51)) return false;
+    const bool halo = tile >= 48;       // LDS-staged halo convolutions: 48 = 128 x 80 @ W 32, 49 = 128 x 160 @ W 64, 50 = 256 x 160 @ W 32, 51 = 256 x 160 @ W 64
+    const bool wide = tile == 34 || tile == 39 || tile == 40 || tile == 42 || tile == 45 || tile == 50 || tile == 51;
+    const int bm = tile == 45 ? 512 : wide ? 256 : 128;
+    const int bn = (tile == 39 || tile == 45) ? 128 : (tile == 40 || tile == 42) ? 256 : (tile == 32 || tile == 35 || tile == 38 || tile == 48) ? 80 : 160;
+    const int ks = (wide || tile == 38) ? 1 : 2, s = (tile == 32 || tile == 33 || tile == 40 || tile == 49 || tile == 51) ? 2 : 3;   // tiles 42 / 45: at least two K-tiles
+    if (halo) {
+        const int hw = (tile == 49 || tile == 51) ? 64 : 32;
         // whole map rows per tile, stride 1, pad 1, no upsampling; 32-bit element offsets inside one image
         if (!conv || a.W != hw || a.OW != hw || a.OH != a.H || a.stride != 1 || a.up || a.pad_t != 1 || a.pad_l != 1) return false;
         if (a.rows_per_batch != a.OH * a.OW || a.rows_per_batch % bm || (long)a.H * a.W * a.lda >= (1L << 31)) return false;
     }
-    if ((tile == 54 || tile == 57) && a.out_mode != 0) return false;      // the ping-pong / software-pipelined loops have no transposed / fp32 form
     if (a.M % bm || a.N % bn || a.K % (64 * ks) || a.lda % 8 || (a.K >> 6) / ks < s - 1) return false;
     if (a.out_mode == 1 || a.ln_slots > 32) return false;
     // tiles 39 / 40: plain and convolution forms with the ordinary epilogue only (no transposed output, no GEGLU); their GroupNorm
@@ -1481,21 +1214,11 @@ int supir_gemm16_launch(const GemmArgs& a, hipStream_t st, int tile, bool conv) 
             case 49: return launch_gemm16<128, 160, 2, 2, 2, 2, false, true, false, 1, 64>(&a, st);
             case 50: return launch_gemm16<256, 160, 4, 2, 1, 3, false, true, false, 1, 32>(&a, st);
             case 51: return launch_gemm16<256, 160, 4, 2, 1, 2, false, true, false, 1, 64>(&a, st);
-            case 52: return launch_gemm16<128, 80, 4, 1, 2, 4, false, true, false, 1, 32, 1>(&a, st);
-            case 53: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 1, 64, 1>(&a, st);
-            case 54: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 1, 0, 1>(&a, st);
-            case 55: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 1, 32, 1>(&a, st);
-            case 56: return launch_gemm16<128, 80, 4, 1, 2, 5, false, true, false, 1, 32, 1>(&a, st);
-            case 57: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 1, 0, 2>(&a, st);
-            case 58: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 1, 32, 2>(&a, st);
-            case 59: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true, false, 1, 64, 2>(&a, st);
             default: return launch_gemm16<128, 80, 4, 1, 2, 3, false, true>(&a, st);
         }
     }
     const bool t = a.out_mode == 2;
     switch (tile) {
-        case 54: return launch_gemm16<128, 80, 4, 1, 2, 3, false, false, false, 1, 0, 1>(&a, st);
-        case 57: return launch_gemm16<128, 80, 4, 1, 2, 3, false, false, false, 1, 0, 2>(&a, st);
         case 39: return launch_gemm16<256, 128, 4, 2, 1, 3, false>(&a, st);
         case 40: return launch_gemm16<256, 256, 4, 2, 1, 2, false>(&a, st);
         case 42: return launch_gemm16<256, 256, 2, 4, 1, 8, false>(&a, st);

@@ -80,9 +80,7 @@ def gemm_tile_name(M, N, act=0, conv=False, trans=False, tile=-1, group=1):
     if tile is not None and tile >= 32:
         nm = {32: "128,80,2k,s2", 33: "128,160,2k,s2", 34: "256,160,1k,s3", 35: "128,80,2k,s3", 36: "256,160,1k,s3,qkv",
               38: "128,80,1k,s3,4w", 39: "256,128,1k,s3", 40: "256,256,1k,s2", 41: "256,128,1k,s3,qkv", 42: "256,256,1k,8ph", 45: "512,128,1k,8ph",
-              48: "128,80,2k,s3,halo32", 49: "128,160,2k,s2,halo64", 50: "256,160,1k,s3,halo32", 51: "256,160,1k,s2,halo64",
-              52: "128,80,2k,s4,halo32,pp", 53: "128,80,2k,s3,halo64,pp", 54: "128,80,2k,s3,pp", 55: "128,80,2k,s3,halo32,pp",
-              56: "128,80,2k,s5,halo32,pp", 57: "128,80,2k,s3,swp", 58: "128,80,2k,s3,halo32,swp", 59: "128,80,2k,s3,halo64,swp"}[tile]
+              48: "128,80,2k,s3,halo32", 49: "128,160,2k,s2,halo64", 50: "256,160,1k,s3,halo32", 51: "256,160,1k,s2,halo64"}[tile]
         return f"gemm16_kernel<{nm}{',conv' if conv else ''}{',T' if trans else ''}{g}>"
     t = (tile & 7) if tile is not None and tile >= 0 else _lib.load().supir_gemm_tile_for(M, N, act)
     name = ["128,128,2x2", "128,64,2x2", "64,128,2x2", "64,64,2x2", "256,128,4x2", "256,256,2x4", "256,128,2x2",
@@ -740,29 +738,23 @@ def gemm(a, w, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, act=
 
 _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5: (256, 4), 6: (128, 2), 7: (128, 2),
                32: (80, 1), 33: (160, 2), 34: (160, 1), 35: (80, 1), 37: (320, 2), 38: (80, 1), 39: (128, 2), 40: (256, 2), 42: (256, 4), 45: (128, 2),
-               48: (80, 1), 49: (160, 2), 50: (160, 2), 51: (160, 2), 52: (80, 1), 53: (80, 1), 54: (80, 1), 55: (80, 1), 56: (80, 1),
-               57: (80, 1), 58: (80, 1), 59: (80, 1)}
-G16_TILES = {32, 33, 34, 35, 39, 40, 42, 45, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
+               48: (80, 1), 49: (160, 2), 50: (160, 2), 51: (160, 2)}
+G16_TILES = {32, 33, 34, 35, 39, 40, 42, 45, 48, 49, 50, 51}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
 # tile: (BM, BN, K groups, ring).  38 = 128 x 80 with FOUR waves and a 78 KB ring (two workgroups per CU): known to the mirror, enabled
 # by adding it to G16_TILES (tools/archive/step_ab4.py); not in the default lists -- see docs/roundlog.md section 3 for what it measured
 # 39 / 40 = 256 x 128 and 256 x 256 (round 4): the VAE's 128 / 256 / 512-channel layers; ordinary epilogue only, and offered only where no
 # 80-column tile fits (N % 80 != 0), so the candidate lists -- and with them the picks -- of the UNet's shapes are what they were
 _G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3), 38: (128, 80, 1, 3),
         39: (256, 128, 1, 3), 40: (256, 256, 1, 2), 42: (256, 256, 1, 3), 45: (512, 128, 1, 3),
-        48: (128, 80, 2, 3), 49: (128, 160, 2, 2), 50: (256, 160, 1, 3), 51: (256, 160, 1, 2),
-        52: (128, 80, 2, 4), 53: (128, 80, 2, 3), 54: (128, 80, 2, 3), 55: (128, 80, 2, 3), 56: (128, 80, 2, 5),
-        57: (128, 80, 2, 3), 58: (128, 80, 2, 3), 59: (128, 80, 2, 3)}
+        48: (128, 80, 2, 3), 49: (128, 160, 2, 2), 50: (256, 160, 1, 3), 51: (256, 160, 1, 2)}
 # 48-51 (round 6): the LDS-staged HALO form of the stride-1 3 x 3 convolutions (csrc/gemm16.hip): a tile is whole rows of a map of the
 # width below; per 64-channel chunk its (rows + 2) x (W + 2) input pixels are staged once and the nine taps read them at shifted LDS
 # addresses, K order (chunk, tap).  Convolutions only
-# 52-56 (round 6): the two K groups of the 128 x 80 tile PING-PONG (two barriers per iteration, group 1 one interval behind: on every SIMD one
-# wave feeds the matrix pipe while the other reads LDS and issues loads); 54 = the plain / implicit-GEMM form, the others halo forms
-# 57-59: fragments software-pipelined inside each wave (the reads of step i + 1 overlap the MFMAs of step i); 57 plain, 58 / 59 halo forms
-_G16_HALO_W = {48: 32, 49: 64, 50: 32, 51: 64, 52: 32, 53: 64, 55: 32, 56: 32, 58: 32, 59: 64}
+_G16_HALO_W = {48: 32, 49: 64, 50: 32, 51: 64}
 # 42 / 45 = 256 x 256 / 512 x 128 on the eight-phase ping-pong schedule (round 5; ring column = 3: they need at least two K-tiles);
 # ordinary epilogue only; convolutions: whole tiles inside one batch element (OH * OW % BM == 0).
 # (The same schedule as 256 x 160 and as a 256 x 320 GEGLU tile measured slower than / equal to tiles 34 / 37: not built.)
-_G16_NO_TRANS = (39, 40, 42, 45, 54, 57)
+_G16_NO_TRANS = (39, 40, 42, 45)
 _G16_PLAIN_ONLY = (39, 40, 42, 45)
 USE_GEMM16 = _os.environ.get("SUPIR_GEMM16", "1") != "0"   # tiles 32 / 33 (csrc/gemm16.hip) in the autotune lists
 USE_GEMM_BIG = _os.environ.get("SUPIR_GEMM_BIG", "1") != "0"   # tile 37 (csrc/gemm_big.hip) in the GEGLU autotune lists

@@ -502,16 +502,16 @@ G16_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (8192,
               (384, 320, 256)]
 
 
-_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 38: (128, 80), 54: (128, 80), 57: (128, 80)}   # 38: four waves, one K group (round 4); 54: ping-pong K groups, 57: software-pipelined fragments (round 6)
+_G16_TILE = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 38: (128, 80)}   # 38: four waves, one K group (round 4)
 
 
 @pytest.mark.parametrize("M,N,K", G16_SHAPES)
-@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38, 54, 57])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
 def test_gemm16_plain_and_epilogues(M, N, K, tile):
     """128 x 80 / 128 x 160 / 256 x 160 tiles (v_mfma_f32_16x16x32_bf16; two K groups per workgroup or eight waves on a 3-deep
     ring): plain, residual + alpha, row bias + SiLU, strided operands, run-to-run bitwise equality."""
     bm, bn = _G16_TILE[tile]
-    if N % bn or M % bm or (tile in (35, 54, 57) and K < 256) or (tile == 38 and K < 128):
+    if N % bn or M % bm or (tile == 35 and K < 256) or (tile == 38 and K < 128):
         pytest.skip("tile needs M % BM == 0, N % BN == 0 and at least ring-depth - 1 K steps per K group")
     a = rnd(M, K).to(BF)
     w = rnd(N, K, scale=K ** -0.5, seed=1).to(BF)
@@ -553,7 +553,7 @@ def test_gemm16_transposed(B, T, N, K, tile):
 
 
 @pytest.mark.parametrize("M,C,N", [(2048, 1280, 2560), (8192, 640, 640), (256, 640, 1280)])
-@pytest.mark.parametrize("ptile,ctile", [(32, 32), (33, 33), (32, 0), (3, 32), (0, 33), (34, 35), (35, 34), (38, 38), (38, 33), (54, 54), (35, 54), (57, 57), (35, 57)])
+@pytest.mark.parametrize("ptile,ctile", [(32, 32), (33, 33), (32, 0), (3, 32), (0, 33), (34, 35), (35, 34), (38, 38), (38, 33)])
 def test_gemm16_layernorm_folding(M, C, N, ptile, ctile):
     """Row statistics emitted by / consumed from the 16x16x32 tiles, mixed with the 32x32x16 tiles on the other side."""
     from supir_amd.weights import fold_layernorm
@@ -786,7 +786,7 @@ G16_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", G16_CONV_CASES)
-@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38, 54, 57])
+@pytest.mark.parametrize("tile", [32, 33, 34, 35, 38])
 def test_gemm16_conv3x3(case, tile):
     """Implicit-GEMM 3x3 convolution on the 16x16x32 tiles: plain, and with bias + time-embedding row bias + SiLU + residual."""
     B, H, W, Cin, Cout, stride, pad, up, out_hw = case
@@ -818,9 +818,7 @@ def test_gemm16_conv3x3(case, tile):
     check(out, 0.5 * F.silu(ref + rb.float()[:, None, None, :]) + res.float(), name="conv16 epilogue")
 
 
-HALO_TILE = {48: (128, 80, 2, 32), 49: (128, 160, 2, 64), 50: (256, 160, 1, 32), 51: (256, 160, 1, 64),     # tile: BM, BN, K groups, map width
-             52: (128, 80, 2, 32), 53: (128, 80, 2, 64), 55: (128, 80, 2, 32), 56: (128, 80, 2, 32),         # the ping-pong forms (4- / 3- / 3- / 5-deep rings)
-             58: (128, 80, 2, 32), 59: (128, 80, 2, 64)}                                                 # software-pipelined fragments
+HALO_TILE = {48: (128, 80, 2, 32), 49: (128, 160, 2, 64), 50: (256, 160, 1, 32), 51: (256, 160, 1, 64)}     # tile: BM, BN, K groups, map width
 HALO_CASES = [
     # B, H, W, Cin, Cout     (stride 1, pad 1: ResBlock in_layers / out_layers, sgm/modules/diffusionmodules/openaimodel.py:260-264, 295-308)
     (2, 32, 32, 1280, 1280),      # the 17 convolutions of the 1280-wide levels
@@ -841,7 +839,7 @@ HALO_CASES = [
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
-@pytest.mark.parametrize("tile", [48, 49, 50, 51, 52, 53, 55, 56, 58, 59])
+@pytest.mark.parametrize("tile", [48, 49, 50, 51])
 def test_conv3x3_halo_tiles(case, tile):
     """Tiles 48-51 of csrc/gemm16.hip (round 6): the LDS-staged HALO form -- a tile is whole rows of the map; per 64-channel chunk its
     (rows + 2) x (W + 2) input pixels are staged once (zero page outside the image) and the nine taps read token fragments at shifted,
@@ -851,8 +849,7 @@ def test_conv3x3_halo_tiles(case, tile):
     SiLU, alpha, residual) and the GroupNorm partials of the epilogue."""
     B, H, W, Cin, Cout = case
     bm, bn, ks, hw = HALO_TILE[tile]
-    depth = {52: 4, 56: 5}.get(tile, 3)
-    if W != hw or (H * W) % bm or Cout % bn or Cin % (64 * ks) or (9 * Cin // 64) // ks < depth - 1:
+    if W != hw or (H * W) % bm or Cout % bn or Cin % (64 * ks):
         pytest.skip("not a shape of this halo tile")
     x = rnd(B, H, W, Cin).to(BF)
     w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1).to(BF)

@@ -35,10 +35,8 @@ def ab(fns, iters):
     return {k: (statistics.median(v), min(v)) for k, v in ts.items()}
 
 
-HALO = {48: (128, 80, 2, 32), 49: (128, 160, 2, 64), 50: (256, 160, 1, 32), 51: (256, 160, 1, 64),
-        55: (128, 80, 2, 32), 53: (128, 80, 2, 64),      # ping-pong K groups
-        58: (128, 80, 2, 32), 59: (128, 80, 2, 64)}      # software-pipelined fragments
-OLD = {32: (128, 80, 2), 33: (128, 160, 2), 34: (256, 160, 1), 35: (128, 80, 2), 54: (128, 80, 2), 57: (128, 80, 2)}   # 54 / 57: tile 35's loader, ping-pong K groups / software-pipelined fragments
+HALO = {48: (128, 80, 2, 32), 49: (128, 160, 2, 64), 50: (256, 160, 1, 32), 51: (256, 160, 1, 64)}
+OLD = {32: (128, 80, 2), 33: (128, 160, 2), 34: (256, 160, 1), 35: (128, 80, 2)}
 CONVS = [(2, 32, 32, 1280, 1280), (2, 32, 32, 2560, 1280), (2, 32, 32, 1920, 1280), (2, 64, 64, 640, 640), (2, 64, 64, 1280, 640),
          (2, 64, 64, 1920, 640), (2, 32, 32, 640, 1280), (2, 32, 32, 128, 2560), (2, 64, 64, 128, 1280),
          (8, 32, 32, 1280, 1280), (8, 64, 64, 640, 640)]
@@ -64,7 +62,7 @@ for (B, H, W, Cin, Cout) in CONVS:
     row = {"shape": [B, H, W, Cin, Cout], "gflop": round(fl / 1e9, 2)}
     for k, (med, mn) in r.items():
         row[k] = {"us_median": round(med, 1), "us_min": round(mn, 1), "tflops_median": round(fl / med / 1e6, 1)}
-    best_old = min((row[f"tile{t}"]["us_median"], t) for t in tiles if t in OLD and t not in (54, 57))
+    best_old = min((row[f"tile{t}"]["us_median"], t) for t in tiles if t in OLD)
     halo = [(row[f"tile{t}"]["us_median"], t) for t in tiles if t in HALO]
     if halo:
         best_halo = min(halo)
@@ -75,31 +73,6 @@ for (B, H, W, Cin, Cout) in CONVS:
         b = ops.conv3x3(x, ws[0], bias, rowbias=rb, tile=best_halo[1]).float()
         row["max_abs_diff"] = round((a - b).abs().max().item(), 5)
         row["rel_l2_diff"] = float(f"{((a - b).norm() / a.norm()).item():.3e}")
-    rows.append(row)
-    print(json.dumps(row), flush=True)
-# the same question for the plain GEMMs of the transformer blocks: tile 35 (one barrier per K step) vs tile 54 (ping-pong K groups)
-for (M, N, K) in [(2048, 1280, 1280), (2048, 1280, 5120), (8192, 640, 640), (8192, 640, 2560), (2048, 1280, 640)]:
-    a = torch.randn(M, K, device=dev).to(BF)
-    ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(BF) for _ in range(16)]
-    bias = torch.randn(N, device=dev)
-    res = torch.randn(M, N, device=dev).to(BF)
-    out = torch.empty(M, N, device=dev, dtype=BF)
-    state = {"i": 0}
-
-    def rung(t):
-        state["i"] = (state["i"] + 1) % 16
-        return ops.gemm(a, ws[state["i"]], bias, residual=res, tile=t, out=out)
-
-    fl = 2.0 * M * N * K
-    fns = {f"tile{t}": (lambda t=t: rung(t)) for t in (35, 54, 57)}
-    r = ab(fns, max(5, int(3000.0 / (fl / 1e9))))
-    row = {"gemm": [M, N, K], "gflop": round(fl / 1e9, 2)}
-    for k, (med, mn) in r.items():
-        row[k] = {"us_median": round(med, 2), "us_min": round(mn, 2), "tflops_median": round(fl / med / 1e6, 1)}
-    row["pp_speedup"] = round(row["tile35"]["us_median"] / row["tile54"]["us_median"], 3)
-    row["swp_speedup"] = round(row["tile35"]["us_median"] / row["tile57"]["us_median"], 3)
-    row["bitwise_35_vs_54_57"] = bool(torch.equal(ops.gemm(a, ws[0], bias, residual=res, tile=35), ops.gemm(a, ws[0], bias, residual=res, tile=54))
-                                      and torch.equal(ops.gemm(a, ws[0], bias, residual=res, tile=35), ops.gemm(a, ws[0], bias, residual=res, tile=57)))
     rows.append(row)
     print(json.dumps(row), flush=True)
 os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)

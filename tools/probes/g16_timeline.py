@@ -36,11 +36,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "geglu":   # the GEGLU projection on the
     CASES = [(2048, 10240, 1280, 34), (2048, 10240, 1280, 37), (2048, 10240, 640, 37), (2048, 10240, 2560, 37), (4096, 10240, 1280, 37),
              (8192, 5120, 640, 37)]
 if len(sys.argv) > 1 and sys.argv[1] == "round6":
-    # round 6: where a K step of the 128 x 80 loops goes -- counted wait / barrier / reads + MFMAs -- for the one-barrier loop (35), the
-    # ping-pong K groups (54), and the same on convolutions: implicit GEMM (35, 54), halo form (48), halo + ping-pong (55)
+    # round 6: where a K step of the 128 x 80 / 128 x 160 loops goes -- counted wait / barrier / reads + loads + MFMAs -- on convolutions in
+    # the implicit-GEMM form (35, 33) and the halo form (48, 49), and on the transformer GEMMs.  (profiles/r06/g16_timeline_loop_forms.log is
+    # the run that also held the ping-pong / software-pipelined loops, since removed.)
     lib.supir_conv3x3_bf16.argtypes = [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P, I, I, I, F, I, P]
-    for (B, H, W, Cin, Cout, tile) in [(2, 32, 32, 1280, 1280, 35), (2, 32, 32, 1280, 1280, 54), (2, 32, 32, 1280, 1280, 57), (2, 32, 32, 1280, 1280, 48),
-                                        (2, 32, 32, 1280, 1280, 55), (2, 32, 32, 1280, 1280, 58), (2, 64, 64, 640, 640, 33), (2, 64, 64, 640, 640, 49)]:
+    for (B, H, W, Cin, Cout, tile) in [(2, 32, 32, 1280, 1280, 35), (2, 32, 32, 1280, 1280, 48), (2, 64, 64, 640, 640, 33), (2, 64, 64, 640, 640, 49)]:
         x = torch.randn(B, H, W, Cin, device="cuda").to(BF)
         w = (torch.randn(Cout, 3, 3, Cin, device="cuda") * (9 * Cin) ** -0.5).to(BF)
         bias = torch.randn(Cout, device="cuda")
@@ -66,7 +66,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "round6":
               f"({t[:, 2].mean() / nk:.0f} per iteration x {nk}: wait {t[:, 8].mean() / nk:.0f}, barrier {t[:, 9].mean() / nk:.0f}, reads+loads+MFMA "
               f"{t[:, 10].mean() / nk:.0f}; ideal MFMA {bm * bn * 64 * 2 * 2 / 4096:.0f})  exchange {t[:, 3].mean():.0f}  epilogue {t[:, 4].mean():.0f}  "
               f"total {t[:, 5].mean():.0f} (max {t[:, 5].max():.0f}); first start -> last end {t[:, 6].max() - t[:, 0].min():.0f}", flush=True)
-    CASES = [(2048, 1280, 1280, 35), (2048, 1280, 1280, 54), (2048, 1280, 1280, 57), (2048, 1280, 5120, 35), (2048, 1280, 5120, 54), (2048, 1280, 5120, 57)]
+    CASES = [(2048, 1280, 1280, 35), (2048, 1280, 5120, 35), (2048, 2560, 1280, 33), (2048, 10240, 1280, 34)]
 for (M, N, K, tile) in CASES:
     a = torch.randn(M, K, device="cuda").to(BF)
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
@@ -75,7 +75,7 @@ for (M, N, K, tile) in CASES:
     out = torch.empty(M, N, device="cuda", dtype=BF)
     geglu = len(sys.argv) > 1 and sys.argv[1] == "geglu"
     bm, bn = {32: (128, 80), 33: (128, 160), 34: (256, 160), 35: (128, 80), 37: (256, 320), 39: (256, 128), 40: (256, 256), 42: (256, 256), 45: (512, 128),
-              54: (128, 80), 57: (128, 80)}[tile]
+              }[tile]
     nwg = (M // bm) * (N // bn)
     SL = 8 if tile == 37 else 16      # slots per wave (gemm16: + the in-loop split of round 6)
     buf = torch.zeros(nwg * 8 * SL, dtype=torch.int64, device="cuda")
