@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+T_PROCESS_START = time.time()      # --rank-report: seconds from here to the first timed image (imports, RCCL init, construction, broadcast, warm-up)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -492,6 +494,7 @@ def main():
                          "dominant kernel's average duration under graph replay (roofline.frac_graph_replay)")
     args = ap.parse_args()
 
+    BUILD_STATS["imports_s"] = round(time.time() - T_PROCESS_START, 2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -526,6 +529,7 @@ def main():
         ops._CHOICE.clear()
         ops.load_tuning(args.tune_file)
 
+    BUILD_STATS["process_group_and_library_s"] = round(time.time() - T_PROCESS_START - BUILD_STATS["imports_s"], 2)
     model, t_fill, t_bcast = build_model(device, rank, world, dist_on)
     if args.diff_dtype == "fp16":
         model.model.dtype = torch.float16
@@ -584,6 +588,8 @@ def main():
         replay_tune = os.path.join(tempfile.gettempdir(), f"supir_bench_picks_{os.getpid()}.json")   # the picks the timed region runs with
         ops.save_tuning(replay_tune)
     sync()
+    # what the first real SCALE run needs to explain itself: everything this rank did before its first timed image
+    BUILD_STATS["start_to_first_timed_image_s"] = round(time.time() - T_PROCESS_START, 2)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_image(model, x, (c, uc), 1234 + rank + 1000 * (i + 1), args.edm_steps)

@@ -650,7 +650,8 @@ def test_geglu_erf_is_an_argument_every_tile_honours(M, K, N2, monkeypatch):
         diff = (got[True, t].float() - got[False, t].float()).abs() > 0
         assert 0 < diff.float().mean().item() < 0.15, (t, diff.float().mean().item())      # reaches the kernel; one-ulp differences only (measured: 4 %)
         d = (got[True, t].float() - got[False, t].float()).abs()
-        assert bool((d <= 2.0 ** -7 * got[True, t].float().abs() + 1e-4).all())                        # one bf16 ulp of the value itself
+        # one bf16 ulp of the value, plus the fitted form's own 2.5e-5 x |value operand| before the rounding (it matters where the product is tiny)
+        assert bool((d <= 2.0 ** -7 * got[True, t].float().abs() + 1e-3).all())
     # erf is the arithmetic of gelu_f on every tile: the two 16-row-interleave tiles take the same K order -> bitwise
     assert torch.equal(got[True, 34], got[True, 37]) or (got[True, 34].float() - got[True, 37].float()).abs().max().item() < 0.05
     e_fit = (got[False, 37].float() - ref).abs().mean().item()

@@ -25,7 +25,9 @@ for r in sorted(reps, key=lambda r: r["rank"]):
     print(f"rank {r['rank']}: construct {r.get('construct_s')} s ({'meta' if r.get('meta_construction') else 'device'}), fill {r.get('fill_s')} s, "
           f"broadcast {r.get('broadcast_s')} s = {r.get('broadcast_GBps')} GB/s of {r.get('broadcast_GB')} GB, warm-up {r.get('warmup_s')} s, "
           f"autotune entries changed {r.get('autotune_entries_changed_on_this_rank')}, re-capture image {r.get('recapture_image_s')} s, "
-          f"host RSS {r.get('host_peak_rss_GB')} GB, device peak {r.get('device_mem_peak_GB')} GB, {r.get('images_per_s_this_rank')} images/s")
+          f"host RSS {r.get('host_peak_rss_GB')} GB, device peak {r.get('device_mem_peak_GB')} GB, {r.get('images_per_s_this_rank')} images/s; "
+          f"process start -> first timed image {r.get('start_to_first_timed_image_s')} s (imports {r.get('imports_s')}, RCCL init + library "
+          f"{r.get('process_group_and_library_s')})")
 try:
     line = json.loads(open(f"{out}/bench_line.json").read().strip().splitlines()[-1])
     print("whole job:", line["value"], line["unit"], "on", line["n_gpus"], "GPU(s); ms per image (max over ranks)", round(line["ms_per_step"], 1),
