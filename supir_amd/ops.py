@@ -741,7 +741,7 @@ _TILE_BN_WN = {0: (128, 2), 1: (64, 2), 2: (128, 2), 3: (64, 2), 4: (128, 2), 5:
                48: (80, 1), 49: (160, 2), 50: (160, 2), 51: (160, 2)}
 G16_TILES = {32, 33, 34, 35, 39, 40, 42, 45, 48, 49, 50, 51}   # enabled members of the family (tools/step_ab.py switches them for A/B runs)
 # tile: (BM, BN, K groups, ring).  38 = 128 x 80 with FOUR waves and a 78 KB ring (two workgroups per CU): known to the mirror, enabled
-# by adding it to G16_TILES (tools/archive/step_ab4.py); not in the default lists -- see docs/roundlog.md section 3 for what it measured
+# by adding it to G16_TILES (tools/archive/step_ab4.py in the history at commit 5dd2326); not in the default lists -- see docs/roundlog.md section 3 for what it measured
 # 39 / 40 = 256 x 128 and 256 x 256 (round 4): the VAE's 128 / 256 / 512-channel layers; ordinary epilogue only, and offered only where no
 # 80-column tile fits (N % 80 != 0), so the candidate lists -- and with them the picks -- of the UNet's shapes are what they were
 _G16 = {32: (128, 80, 2, 2), 33: (128, 160, 2, 2), 34: (256, 160, 1, 3), 35: (128, 80, 2, 3), 38: (128, 80, 1, 3),
