@@ -31,7 +31,7 @@ for r in sorted(reps, key=lambda r: r["rank"]):
 try:
     line = json.loads(open(f"{out}/bench_line.json").read().strip().splitlines()[-1])
     print("whole job:", line["value"], line["unit"], "on", line["n_gpus"], "GPU(s); ms per image (max over ranks)", round(line["ms_per_step"], 1),
-          "; weight broadcast", line.get("weight_broadcast_s"), "s; process group", line.get("process_group"))
+          "; process group", line.get("process_group"))
 except Exception as e:   # noqa: BLE001
     print("no bench line:", e)
 PY
