@@ -342,12 +342,14 @@ def vae_colorfix_profile(model, P, device):
 
 
 def _rocprof_kernel_name(kernel):
-    """Name rocprofv3 prints for a gemm-family instantiation the trace names `kernel` (ops.gemm_tile_name)."""
-    names = {"gemm16_kernel<128,80,2k,s3>": "gemm16_kernel<128, 80, 4, 1, 2, 3, false, false, false, 1>",
-             "gemm16_kernel<128,80,2k,s2>": "gemm16_kernel<128, 80, 4, 1, 2, 2, false, false, false, 1>",
+    """PREFIX of the name rocprofv3 prints for a gemm-family instantiation the trace names `kernel` (ops.gemm_tile_name): the leading template
+    arguments up to the one that tells the instantiations of a tile apart -- later template parameters (round 6 appended the halo width) must
+    not break the match (BENCH of the round's first build lost frac_graph_replay to exactly that)."""
+    names = {"gemm16_kernel<128,80,2k,s3>": "gemm16_kernel<128, 80, 4, 1, 2, 3, false, false, false, 1",
+             "gemm16_kernel<128,80,2k,s2>": "gemm16_kernel<128, 80, 4, 1, 2, 2, false, false, false, 1",
              "geglu_big_kernel<256,320,4x2>": "geglu_big_kernel<1, true>", "attn": "attn_d64_pipe_kernel<3, 4, true, 1, true>",
-             "gemm16_kernel<256,160,1k,s3,qkv>": "gemm16_kernel<256, 160, 8, 1, 1, 3, false, false, true, 1>",
-             "gemm16_kernel<256,128,1k,s3,qkv>": "gemm16_kernel<256, 128, 4, 2, 1, 3, false, false, true, 1>",
+             "gemm16_kernel<256,160,1k,s3,qkv>": "gemm16_kernel<256, 160, 8, 1, 1, 3, false, false, true, 1",
+             "gemm16_kernel<256,128,1k,s3,qkv>": "gemm16_kernel<256, 128, 4, 2, 1, 3, false, false, true, 1",
              "xattn_q": "xattn_q_kernel"}
     return names.get(kernel)
 
