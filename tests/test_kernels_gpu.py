@@ -652,8 +652,9 @@ def test_geglu_erf_is_an_argument_every_tile_honours(M, K, N2, monkeypatch):
         d = (got[True, t].float() - got[False, t].float()).abs()
         # one bf16 ulp of the value, plus the fitted form's own 2.5e-5 x |value operand| before the rounding (it matters where the product is tiny)
         assert bool((d <= 2.0 ** -7 * got[True, t].float().abs() + 1e-3).all())
-    # erf is the arithmetic of gelu_f on every tile: the two 16-row-interleave tiles take the same K order -> bitwise
-    assert torch.equal(got[True, 34], got[True, 37]) or (got[True, 34].float() - got[True, 37].float()).abs().max().item() < 0.05
+    # erf is the arithmetic of gelu_f on every tile family (another MFMA shape, another summation order: equal to rounding)
+    check(got[True, 34], got[True, 37].float(), rel=3e-3, name="erf: tile 34 vs tile 37")
+    check(got[True, 0], got[True, 37].float(), rel=3e-3, name="erf: gemm.hip tile 0 vs tile 37")
     e_fit = (got[False, 37].float() - ref).abs().mean().item()
     e_erf = (got[True, 37].float() - ref).abs().mean().item()
     assert e_erf <= e_fit * 1.02, (e_erf, e_fit)
