@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_d64_pipe_kernel(const AttnArg
                     u16x4 ov;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[df][rg * 4 + e] * inv);
-                    *(u16x4*)(Op + df * 32 + 8 * rg + 4 * half) = ov;
+                    supir_store8(Op + df * 32 + 8 * rg + 4 * half, __builtin_bit_cast(u32x2, ov));
                 }
         }
     } else {
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_d64_pipe_kernel(const AttnArg
                 const int row = it * 8 + (lane >> 3), ch = lane & 7;
                 if (q0 + row < p.Tq) {
                     const f32x4 piece = *(const f32x4*)(o_stage + row * ORS + ch * 16);
-                    *(f32x4*)(Ob + (size_t)row * p.ldo + ch * 8) = piece;
+                    supir_store16(Ob + (size_t)row * p.ldo + ch * 8, piece);
                 }
             }
         }

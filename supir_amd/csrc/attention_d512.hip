@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
                     f32x4 ov;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = o[db][rg * 4 + e] * inv;
-                    *(f32x4*)(Pp + db * 32 + 8 * rg + 4 * half) = ov;
+                    supir_store16(Pp + db * 32 + 8 * rg + 4 * half, ov);
                 }
             if (half == 0) {
                 p.ml[row * 2] = -nm;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * NW) void attn_d512_kernel(const Attn512Args p)
                 u16x4 ov;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[db][rg * 4 + e] * inv);
-                *(u16x4*)(Op + db * 32 + 8 * rg + 4 * half) = ov;
+                supir_store8(Op + db * 32 + 8 * rg + 4 * half, __builtin_bit_cast(u32x2, ov));
             }
     }
 }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_d512_combine_kernel(const float* __r
     u16x4 ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = f2bf(acc[e]);
-    *(u16x4*)(O + (size_t)row * ldo + cg * 4) = ov;
+    supir_store8(O + (size_t)row * ldo + cg * 4, __builtin_bit_cast(u32x2, ov));
 }
 
 }  // namespace

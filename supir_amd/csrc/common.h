@@ -143,6 +143,42 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Cache policy of the big OUTPUT stores (16 / 8 bytes per lane, row-contiguous: GEMM / convolution / attention / GroupNorm / LayerNorm
+// epilogues).  A build-time PROBE switch (tools/store_policy_ab.py builds one extra library per policy and swaps it in inside one process);
+// the product build is 0 = plain C++ stores.  1 = `sc1` (agent-scope, write-through: the line does not stay dirty in the XCD's L2, so the
+// release at the end of the kernel has nothing to write back -- the guide's "boundary" / "publish-large" rows), 2 = nt, 3 = sc0 sc1.
+// Measured on the replayed 1024^2 step, interleaved, bitwise-equal outputs (profiles/r06/store_policy_ab.json): plain 27.33 ms, sc1
+// 27.57, sc0 sc1 27.45 -- the end-of-kernel write-back of 5-16 MB is not what a boundary costs here; plain stays.  (A first build without
+// the s_nop below produced a few corrupt elements per launch, NaN downstream -- and ran the step in 25.1 ms: operands that do not toggle
+// let the chip clock ~10 % higher.  Never read a speed-up off a variant whose output has not been compared.)
+#ifndef SUPIR_STORE_POLICY
+#define SUPIR_STORE_POLICY 0
+#endif
+// (The stores are inline assembly -- the compiler offers no 16-byte store with a scope bit -- so its hazard recogniser does not see a
+// store: a VALU write to the data registers of a > 8-byte store within one wait state is the programmer's to avoid, hence the s_nop.)
+__device__ __forceinline__ void supir_store16(void* p, f32x4 v) {
+#if SUPIR_STORE_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif SUPIR_STORE_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif SUPIR_STORE_POLICY == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+    *(f32x4*)p = v;
+#endif
+}
+__device__ __forceinline__ void supir_store8(void* p, u32x2 v) {
+#if SUPIR_STORE_POLICY == 1
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif SUPIR_STORE_POLICY == 2
+    asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#elif SUPIR_STORE_POLICY == 3
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *(u32x2*)p = v;
+#endif
+}
+
 // XCD-aware bijective remap of a linear workgroup id: block b runs on XCD b%8; give every XCD a
 // contiguous chunk of the logical id space so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

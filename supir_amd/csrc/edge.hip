@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_kernel(const float* __re
             u16x8 ov;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[q][e]);
-            *(u16x8*)(out + (size_t)(pix + q) * ldo + co) = ov;
+            supir_store16(out + (size_t)(pix + q) * ldo + co, __builtin_bit_cast(f32x4, ov));
         }
     }
 }

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
                         u16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = f2bf(val[e]);
-                        *(u16x4*)(Cb + ((size_t)b * p.N + n) * p.ldc + t) = o;
+                        supir_store8(Cb + ((size_t)b * p.N + n) * p.ldc + t, __builtin_bit_cast(u32x2, o));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
                         }
                         u32x2 o = {f2bf_pk(r[0], r[1]), f2bf_pk(r[2], r[3])};
                         const int no = (n0 >> 1) + wn * 32 + 8 * rg + 4 * half;
-                        if (m_ok && n0 + nl + 32 < p.N) *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
+                        if (m_ok && n0 + nl + 32 < p.N) supir_store8((bf16_t*)p.C + (size_t)m * p.ldc + no, o);
                     }
                 }
             }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
                             if constexpr (MODE == 2) {
                                 *(u32x2*)(c_stage + l31 * C_RS + (j * 32 + 8 * rg + 4 * half) * 2) = o;
                             } else {
-                                if (ok) *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                                if (ok) supir_store8((bf16_t*)p.C + (size_t)m * p.ldc + n, o);
                             }
                         }
                     }
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, gemm_min_waves(BM, BN, WM, WN, S
                         const int row = rr * RPI + lane / CPR, ch = lane % CPR;
                         const int m2 = m0 + wm * WTM + i * 32 + row, n2 = n0 + wn * WTN + ch * 8;
                         const f32x4 piece = *(const f32x4*)(c_stage + row * C_RS + ch * 16);
-                        if (m2 < p.M && n2 < p.N) *(f32x4*)((bf16_t*)p.C + (size_t)m2 * p.ldc + n2) = piece;
+                        if (m2 < p.M && n2 < p.N) supir_store16((bf16_t*)p.C + (size_t)m2 * p.ldc + n2, piece);
                     }
                 }
                 if (p.rowstats_out) {
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
         y[e] = t;
     }
     const u32x2 o = {f2bf_pk(y[0], y[1]), f2bf_pk(y[2], y[3])};
-    *(u32x2*)(out + (size_t)m * ldo + n) = o;
+    supir_store8(out + (size_t)m * ldo + n, o);
 }
 
 int supir_splitk_finalize_launch(const float* part, int ksplit, int M, int N, int ld_part, const float* bias, int act, bf16_t* out, int ldo,

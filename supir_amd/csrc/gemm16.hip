@@ -893,7 +893,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = p.alpha * (rs[r] * (acc[KG * MIH + h][j][r] - mu[r] * cs) + bz);
                     const u32x2 o = {f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3])};
-                    *(u32x2*)(Cb + ((size_t)b * n_out_total + (n - n_base)) * ldc_t + t) = o;
+                    supir_store8(Cb + ((size_t)b * n_out_total + (n - n_base)) * ldc_t + t, o);
                 }
             }
         };
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 8 ? 2 : 1)) voi
                 if (PIECES % 64 == 0 || id < PIECES) {
                     const int row = id / PPR, ch = id - row * PPR;
                     const f32x4 piece = *(const f32x4*)(c_stage + row * C_RS + ch * 16);
-                    *(f32x4*)((bf16_t*)p.C + (size_t)(row_base + row) * p.ldc + col_base + ch * 8) = piece;
+                    supir_store16((bf16_t*)p.C + (size_t)(row_base + row) * p.ldc + col_base + ch * 8, piece);
                 }
             }
         };

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void geglu_big_kernel(const GemmArgsN<NP> p
             const int row = rr * 6 + lane / 10, ch = lane % 10;
             if (lane < 60 && row < 32) {
                 const f32x4 piece = *(const f32x4*)(c_stage + row * C_RS + ch * 16);
-                *(f32x4*)((bf16_t*)p.C + (size_t)(row_base + row) * p.ldc + col_base + ch * 8) = piece;
+                supir_store16((bf16_t*)p.C + (size_t)(row_base + row) * p.ldc + col_base + ch * 8, piece);
             }
         }
     }

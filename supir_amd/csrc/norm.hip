@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const GnArgsN<NP> pp, int
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int r = here + u * TY;
-            if (r < row1) *(u16x8*)(p.out + ((size_t)b * p.HW + r) * p.ldo + c) = ov[u];
+            if (r < row1) supir_store16(p.out + ((size_t)b * p.HW + r) * p.ldo + c, __builtin_bit_cast(f32x4, ov[u]));
         }
     }
 }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel_v1(const GnArgsN<NP> pp, 
         u16x8 ov;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ov[e] = f2bf(y[e]);
-        *(u16x8*)(p.out + ((size_t)b * p.HW + row) * p.ldo + c) = ov;
+        supir_store16(p.out + ((size_t)b * p.HW + row) * p.ldo + c, __builtin_bit_cast(f32x4, ov));
     }
 }
 
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                 ov[e] = f2bf((v[i][e] - mean) * rstd * g0[e] + b0[e]);
                 ov[4 + e] = f2bf((v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
             }
-            *(u16x8*)(yr + vi * 8) = ov;
+            supir_store16(yr + vi * 8, __builtin_bit_cast(f32x4, ov));
         }
     }
 }

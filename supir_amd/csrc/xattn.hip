@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void xattn_q_kernel(const XattnArgs p) {
     for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + (lane >> 3), ch = lane & 7;
         const f32x4 piece = *(const f32x4*)(o_stage + row * ORS + ch * 16);
-        *(f32x4*)(Ob + (size_t)row * p.ldo + ch * 8) = piece;
+        supir_store16(Ob + (size_t)row * p.ldo + ch * 8, piece);
     }
 }
 

@@ -67,6 +67,43 @@ if len(sys.argv) > 1 and sys.argv[1] == "round6":
               f"{t[:, 10].mean() / nk:.0f}; ideal MFMA {bm * bn * 64 * 2 * 2 / 4096:.0f})  exchange {t[:, 3].mean():.0f}  epilogue {t[:, 4].mean():.0f}  "
               f"total {t[:, 5].mean():.0f} (max {t[:, 5].max():.0f}); first start -> last end {t[:, 6].max() - t[:, 0].min():.0f}", flush=True)
     CASES = [(2048, 1280, 1280, 35), (2048, 1280, 5120, 35), (2048, 2560, 1280, 33), (2048, 10240, 1280, 34)]
+if len(sys.argv) > 1 and sys.argv[1] == "qkv":
+    # round 6 (late): the fused q | k | v projection (256 x 128 tile, normal + transposed epilogue) at the step's shape
+    lib.supir_gemm_bf16_qkv.argtypes = [P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, F, P]
+    for (M, N, K, T) in [(2048, 3840, 1280, 1024), (8192, 1920, 640, 4096)]:
+        a = torch.randn(M, K, device="cuda").to(BF)
+        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
+        ns = 2 * N // 3
+        cqk = torch.empty(M, ns, device="cuda", dtype=BF)
+        cvt = torch.empty(M // T, N - ns, T, device="cuda", dtype=BF)
+        nwg = (M // 256) * (N // 128)
+        buf = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+
+        def runq():
+            return lib.supir_gemm_bf16_qkv(a.data_ptr(), w.data_ptr(), cqk.data_ptr(), cvt.data_ptr(), M, N, ns, K, K, ns, T, T, None, None, 0, 0, None, 1e-5, st)
+        for _ in range(5):
+            assert runq() == 0
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            runq()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        lib.supir_g16_tl_set(buf.data_ptr())
+        assert runq() == 0
+        torch.cuda.synchronize()
+        lib.supir_g16_tl_set(None)
+        t = buf.view(nwg * 8, 16).cpu().double()
+        t = t[t[:, 5] > 0]          # the workgroups of the transposed (V^T) third return through another epilogue that is not stamped
+        nk = K // 64
+        print(f"qkv M={M} N={N} K={K} wgs={nwg} | event {us:.1f} us (untimed build) | per wave (cycles): prologue {t[:, 1].mean():.0f}  loop {t[:, 2].mean():.0f} "
+              f"({t[:, 2].mean() / nk:.0f} per K step x {nk}: wait {t[:, 8].mean() / nk:.0f}, barrier {t[:, 9].mean() / nk:.0f}, reads+loads+MFMA "
+              f"{t[:, 10].mean() / nk:.0f}; ideal MFMA 1024)  epilogue {t[:, 4].mean():.0f}  total {t[:, 5].mean():.0f} (max {t[:, 5].max():.0f}); "
+              f"first start -> last end {t[:, 6].max() - t[:, 0].min():.0f}", flush=True)
+    sys.exit(0)
 for (M, N, K, tile) in CASES:
     a = torch.randn(M, K, device="cuda").to(BF)
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
