@@ -458,6 +458,27 @@ def write_details(full):
         return None
 
 
+class StdoutForTheLine:
+    """fd 1 carries the ONE line of the contract and nothing else.  From construction on, whatever anything writes to stdout on its own
+    -- RCCL prints a five-line version banner when its first communicator comes up (seen under torch.distributed.run) -- goes to stderr;
+    inside `with`, the real stdout is back for the final print."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.real = os.dup(1)
+        os.dup2(2, 1)
+
+    def __enter__(self):
+        sys.stdout.flush()
+        os.dup2(self.real, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(2, 1)
+        return False
+
+
 def _fused_step_on():
     from supir_amd.modules import sampling
     return bool(sampling.FUSED_EDM_STEP)
@@ -495,6 +516,8 @@ def main():
                     help="skip the same-box sub-step that re-runs this command (1 image) under rocprofv3 --kernel-trace --stats for the "
                          "dominant kernel's average duration under graph replay (roofline.frac_graph_replay)")
     args = ap.parse_args()
+
+    the_line = StdoutForTheLine()
 
     BUILD_STATS["imports_s"] = round(time.time() - T_PROCESS_START, 2)
     rank = int(os.environ.get("RANK", "0"))
@@ -808,7 +831,8 @@ def main():
         # everything measured goes to a side file; stdout carries ONE short line (the driver keeps only a few KB of the tail, and a
         # 20 KB line left round 5 without a parsed record).  Nothing is printed after it, on either stream.
         details = write_details(full)
-        print(compact_line(full, details), flush=True)
+        with the_line:
+            print(compact_line(full, details), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,6 +1,7 @@
 """The bench contract's stdout line stays small enough for the driver to parse (a 20 KB line -> `parsed: null`)."""
 import json
 import os
+import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -65,6 +66,19 @@ def test_main_prints_the_compact_line_last():
     assert body.count("print(") == 1 and "print(compact_line(full, details), flush=True)" in body
     after = body[body.index("print(compact_line"):]
     assert "log(" not in after
+
+
+def test_only_the_line_reaches_stdout_even_when_a_library_writes_to_fd_1():
+    """RCCL prints a version banner on fd 1 when its first communicator is created (five lines in front of the bench line under
+    torch.distributed.run); bench.StdoutForTheLine sends every such write to stderr and hands the real stdout back for the line only."""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "g = bench.StdoutForTheLine()\n"
+            "os.write(1, b'RCCL version : banner\\n'); print('python-level noise', flush=True)\n"
+            "with g:\n    print('{\"the\": \"line\"}', flush=True)\n"
+            "os.write(1, b'late noise\\n')\n") % os.path.dirname(os.path.abspath(bench.__file__))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
+    assert r.stdout == '{"the": "line"}\n', r.stdout
+    assert "banner" in r.stderr and "python-level noise" in r.stderr and "late noise" in r.stderr
 
 
 def test_replay_profile_kernel_names_match_the_kernels_template_arity():
